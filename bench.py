@@ -1,0 +1,183 @@
+#!/usr/bin/env python3
+"""Headline benchmark: env-steps/sec at 65 536 parallel arenas per GPU (BASELINE.json).
+
+Workload (BASELINE.json configs[2]): 65 536 arenas per GPU, flat terrain, KAMMA_medium task,
+scripted PPO-style actor (the train scripts' MLP 6->512->512->128->4, ELU, Sigmoid head,
+train_kamma_4d_nofifo_random_RLIL.py:21-36; fixed-seed random weights, fp32 PyTorch-ROCm
+inference) in the loop: obs -> actor -> ois_step, all on one stream, no host sync.
+
+One "step" = one policy step of all arenas of this rank. N>1: one process per GPU
+(torch.distributed / RCCL), arenas sharded by rank (weak scaling: 65 536 per GPU, global
+arena ids keep every stream identical to a 1-GPU run), ONE all-gather of the episode-return
+statistics per logging interval (800 steps, train_kamma_4d_nofifo_random_RLIL.py:176) — the
+path's only exchange.
+
+Prints ONE JSON line on rank 0 (contract in the task statement) with two extra objects:
+  roofline      HBM roofline of the step kernel: algorithmic bytes (352 B/env-step, SURVEY.md
+                §8d) x arenas / mean kernel time measured with events on the launch stream.
+  cpu_baseline  the CPU oracle (oracle/, test infrastructure) timed on this host's cores on a
+                bounded sample of the same workload (rank 0, N=1 only).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+ALGO_BYTES_PER_ENV_STEP = 352.0
+HBM_PEAK_GBS = 8000.0             # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
+ARENAS_PER_GPU = 65536
+
+
+def build_actor(torch, device):
+    """train_kamma_4d_nofifo_random_RLIL.py:21-36: 6 -> 512 -> 512 -> 128 -> 4, ELU, Sigmoid"""
+    nn = torch.nn
+    torch.manual_seed(0)
+    net = nn.Sequential(nn.Linear(6, 512), nn.ELU(), nn.Linear(512, 512), nn.ELU(), nn.Linear(512, 128), nn.ELU(),
+                        nn.Linear(128, 4), nn.Sigmoid())
+    return net.to(device).eval()
+
+
+def cpu_baseline(n_arenas, seconds_target=12.0):
+    """time the oracle on the host cores: same task, same actor-free step (random actions)."""
+    import numpy as np
+    from options_in_simulation_amd import _abi, build_config
+    from oracle.binding import OracleEnv
+    cores = len(os.sched_getaffinity(0))
+    n = min(n_arenas, 4096)
+    env = OracleEnv(build_config(variant="KAMMA_medium", num_envs=n, seed=42), threads=cores)
+    env.reset(42)
+    env.rollout(2, _abi.POLICY_RANDOM)  # warm the thread pool
+    t0 = time.perf_counter()
+    env.rollout(4, _abi.POLICY_RANDOM)
+    per_step = (time.perf_counter() - t0) / 4
+    steps = int(max(8, min(2000, seconds_target / max(per_step, 1e-6))))
+    t0 = time.perf_counter()
+    env.rollout(steps, _abi.POLICY_RANDOM)
+    dt = time.perf_counter() - t0
+    env.close()
+    return {"value": n * steps / dt, "unit": "env-steps/s", "cores": cores, "kind": "port",
+            "sample": f"{n} arenas x {steps} policy steps of the same KAMMA_medium task (in-oracle random actions, "
+                      f"no actor), OpenMP over arenas, {dt:.1f} s"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=300)
+    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--arenas", type=int, default=ARENAS_PER_GPU, help="arenas per GPU")
+    ap.add_argument("--log-interval", type=int, default=800)
+    ap.add_argument("--no-actor", action="store_true", help="env-only loop (fixed random actions)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--variant", default="KAMMA_medium")
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+    from options_in_simulation_amd import _abi, build_config
+    from options_in_simulation_amd.dist import gather_stats
+    from options_in_simulation_amd.vecenv import NativeEnv
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus > 1 and world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} needs a torch.distributed.run launch with {args.gpus} ranks "
+                         f"(WORLD_SIZE={world})")
+    torch.cuda.set_device(local_rank)
+    device = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
+
+    N = args.arenas
+    cfg = build_config(variant=args.variant, num_envs=N, seed=42, arena_offset=rank * N)
+    env = NativeEnv(cfg, device)
+    env.reset(42)
+    actor = None if args.no_actor else build_actor(torch, device)
+    obs = env.buffer(_abi.BUF_OBS)
+    fixed_actions = torch.rand((N, cfg.action_dim), device=device, generator=torch.Generator(device).manual_seed(1))
+
+    ev_pairs = []
+
+    def one_step(timed):
+        with torch.no_grad():
+            a = fixed_actions if actor is None else actor(obs)
+        if timed:
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            env.step(a)
+            e1.record()
+            ev_pairs.append((e0, e1))
+        else:
+            env.step(a)
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        one_step(False)
+    if world > 1:  # warm the collective too
+        gather_stats(env.stats(reset_after=True), device)
+    barrier()
+    t0 = time.perf_counter()
+    gathered = None
+    for s in range(args.steps):
+        one_step(True)
+        if (s + 1) % args.log_interval == 0 or s + 1 == args.steps:
+            st = env.stats(reset_after=True)           # one tiny D2H per logging interval
+            gathered = gather_stats(st, device) if world > 1 else [st]
+    barrier()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=device)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    kernel_ms = sum(a.elapsed_time(b) for a, b in ev_pairs) / max(1, len(ev_pairs))
+    total_env_steps = float(N) * world * args.steps
+    value = total_env_steps / elapsed
+
+    if rank == 0:
+        achieved = ALGO_BYTES_PER_ENV_STEP * N / (kernel_ms * 1e-3) / 1e9
+        out = {
+            "metric": "env-steps/sec at 65 536 parallel arenas; achieved HBM GB/s vs roofline",
+            "value": value, "unit": "env-steps/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": f"{N} arenas/GPU, flat terrain, {args.variant} task, "
+                                   + ("fixed random actions (env only)" if actor is None else
+                                      "scripted actor MLP 6-512-512-128-4 (fp32 PyTorch-ROCm) inference in-loop")
+                                   + " [BASELINE.json configs[2]]",
+                       "arenas_per_gpu": N, "substeps_per_step": cfg.decimation + cfg.extra_substeps,
+                       "solver_iterations": cfg.solver_iterations, "sharding": f"arenas x{world}, no data-path collective",
+                       "stats_allgather_every": args.log_interval},
+            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                         "kernel": "step_kernel", "kernel_ms": kernel_ms,
+                         "algorithmic_bytes_per_launch": ALGO_BYTES_PER_ENV_STEP * N,
+                         "note": "kernel is fp32-VALU bound (20 substeps x 4-iteration contact solve per env-step); "
+                                 "see DESIGN.md for the VALU roofline"},
+            "env_only_env_steps_per_s": N / (kernel_ms * 1e-3),
+        }
+        if gathered:
+            eps = sum(g.episodes for g in gathered)
+            out["episode_stats"] = {"episodes": eps,
+                                    "return_mean": (sum(g.return_sum for g in gathered) / eps) if eps else None}
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(N)
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+    env.close()
+
+
+if __name__ == "__main__":
+    main()

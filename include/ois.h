@@ -1,0 +1,262 @@
+/*
+ * ois.h — C ABI of the MI355X-native vectorised skid-steer torque-control environment.
+ *
+ * This is the drop-in boundary for ONE hot path of meesjansen/Options_In_Simulation:
+ * the reset()/step() loop of `TorqueDistributionTask` (reference: src/my_envs/KAMMA.py
+ * and its 11 copy-paste variants) for N independent arenas.
+ * The reference has no FFI of its own (it is pure Python on top of Isaac Sim/PhysX); the
+ * entry points below are what a ctypes binding of that task would bind, one per
+ * reference call the host loop makes:
+ *
+ *   ois_create / ois_destroy    <- TorqueDistributionTask.__init__ + update_config
+ *                                  (KAMMA.py:149-228, 231-275), RLTask buffers
+ *                                  (rl_task.py:145-154)
+ *   ois_reset                   <- post_reset -> reset_idx(arange(N))   (KAMMA.py:366-414)
+ *   ois_step                    <- VecEnv.step = pre_physics_step + controlFrequencyInv
+ *                                  world steps + post_physics_step
+ *                                  (KAMMA.py:596-656, 43, 674-727)
+ *   ois_rollout                 <- K consecutive ois_step calls fused into one launch
+ *                                  (no reference counterpart; BASELINE.json configs 1/2)
+ *   ois_buffer                  <- obs_buf / rew_buf / reset_buf / timeout_buf /
+ *                                  wheel_torqs / commands / base_* tensors
+ *   ois_episode_info            <- extras["episode"] filled in reset_idx (KAMMA.py:480-488)
+ *   ois_env0_diag               <- task.observed_components (KAMMA.py:840-867)
+ *   ois_stats_fetch             <- finished-episode return tracking of the agent base
+ *                                  class (src/my_agents/base.py:305-341)
+ *
+ * Conventions
+ *   - plain C, no torch types; every pointer named *device* is a HIP device pointer.
+ *   - the library never allocates device memory: the caller hands one workspace of
+ *     ois_workspace_bytes() bytes (hipMalloc or a torch uint8 tensor) and every
+ *     buffer returned by ois_buffer() aliases into it (zero copy).
+ *   - every call returns 0 (OIS_OK) or a negative OIS_E* code; the message is in
+ *     ois_last_error() (thread local). No C++ exception crosses the boundary.
+ *   - all GPU work is enqueued on the caller's hipStream_t (`stream`, may be NULL for
+ *     the default stream); only the *_fetch / host-output calls synchronise that stream.
+ *   - one ois_env is owned by one host thread at a time (no internal locking).
+ */
+#ifndef OIS_H_
+#define OIS_H_
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define OIS_ABI_VERSION 1
+
+/* error codes */
+#define OIS_OK 0
+#define OIS_EINVAL (-1)    /* bad argument / config */
+#define OIS_ENOMEM (-2)    /* workspace too small or host allocation failed */
+#define OIS_EHIP (-3)      /* a HIP runtime call failed (message has hipGetErrorString) */
+#define OIS_ESTATE (-4)    /* call order violated (e.g. step before reset) */
+
+/* mix_mode: how the policy action and the expert ("criteria") action are combined */
+#define OIS_MIX_SWITCH 0   /* KAMMA.py:632-635      mask = U[0,1) < gamma1 */
+#define OIS_MIX_BLEND 1    /* KA_DDPG_4D.py:627-631 (1-g)*a*scale + g*criteria */
+
+/* gamma modes */
+#define OIS_GAMMA_SCHEDULE 0 /* clamp(1 - sim_steps/max_sim_steps, 0)  KAMMA.py:627-628 */
+#define OIS_GAMMA_CONST 1    /* commented-out schedule lines: KAMMA_g11_g21.py:627-628,
+                                KAMMA_g1d_g21.py:628, KA_DDPG_2D.py:627; eval: 0 */
+
+/* guiding_mode: which torque the guiding reward compares with the criteria action */
+#define OIS_GUIDE_EXECUTED 0 /* clipped executed torque   KAMMA.py:656 */
+#define OIS_GUIDE_POLICY 1   /* unclipped a*action_scale  KA_DDPG_4D.py:637 */
+
+/* cmd_sampler: how commands[:,0] is drawn at reset (sample_velocity_command) */
+#define OIS_CMD_RAND 0 /* KAMMA.py:569-575 */
+#define OIS_CMD_BOX 1  /* KAMMA_curr1.py:577-598 */
+#define OIS_CMD_GRID 2 /* KAMMA_curr2.py:602-640 */
+#define OIS_CMD_EVAL 3 /* KAMMA_eval.py:545-550 */
+
+/* rollout policies */
+#define OIS_POLICY_ZERO 0     /* actions == 0                                  */
+#define OIS_POLICY_RANDOM 1   /* actions ~ U[0,1)^A from Philox(seed, arena, step) */
+#define OIS_POLICY_EXTERNAL 2 /* actions[k][N][A] supplied by the caller       */
+
+typedef struct ois_config {
+  uint32_t struct_bytes; /* = sizeof(ois_config); checked by ois_create */
+  int32_t num_envs;      /* arenas owned by this process (this GPU)     */
+  int64_t arena_offset;  /* global id of local arena 0 (RNG key; sharding invariant) */
+  uint64_t seed;         /* TASK_CFG["seed"] (KAMMA.py:35) */
+
+  /* ---- variant switches ---- */
+  int32_t action_dim;   /* 4 (KAMMA, KA_DDPG_4D) | 2 (KA_DDPG_2D.py:623-624) | 1 (KA_DDPG_1D.py:600-603) */
+  int32_t mix_mode;     /* OIS_MIX_*   */
+  int32_t gamma1_mode;  /* OIS_GAMMA_* action assist */
+  int32_t gamma2_mode;  /* OIS_GAMMA_* reward assist */
+  float gamma1_const;
+  float gamma2_const;
+  int32_t guiding_mode; /* OIS_GUIDE_* */
+  int32_t cmd_sampler;  /* OIS_CMD_*   */
+  float max_sim_steps;  /* KAMMA.py:179 (400000), _medium 500000, KA_DDPG_4D 700000 */
+  int32_t eval_sums;    /* 1: KAMMA_eval extra episode sums (KAMMA_eval.py:677-685) */
+
+  /* ---- task constants (KAMMA.py update_config + hard-coded) ---- */
+  float sim_dt;               /* TASK_CFG sim.dt 0.01              KAMMA.py:82  */
+  int32_t decimation;         /* control.decimation 10             KAMMA.py:75  */
+  int32_t extra_substeps;     /* env.controlFrequencyInv 10        KAMMA.py:43 (loop body is third-party) */
+  float policy_dt;            /* self.dt = decimation * sim.dt = 0.1 (float32 of the Python double) KAMMA.py:260 */
+  int32_t max_episode_length; /* int(episodeLength_s / dt + 0.5) = 100   KAMMA.py:262 */
+  float episode_length_s;     /* learn.episodeLength_s 10          KAMMA.py:70  */
+  float Kp;                   /* control.stiffness (0.035 from the train scripts) KAMMA.py:263 */
+  float Kp_omega;             /* 0.665                             KAMMA.py:613 */
+  float vehicle_mass;         /* 25 (controller constant)          KAMMA.py:174 */
+  float vehicle_inertia;      /* 1.05 (controller constant)        KAMMA.py:175 */
+  float action_scale;         /* control.actionScale 3.0           KAMMA.py:78  */
+  float torque_clip;          /* 4.0                               KAMMA.py:649 */
+  float w1, w2, w3;           /* -25, -0.02, -0.09                 KAMMA.py:785 */
+  float sparse_bonus;         /* 0.2                               KAMMA.py:792 */
+  float sparse_threshold;     /* 0.01                              KAMMA.py:790-791 */
+  float terminal_reward;      /* learn.terminalReward 0.0          KAMMA.py:69, 801 */
+  float cmd_x_lo, cmd_x_hi;   /* randomCommandVelocityRanges.linear_x  KAMMA.py:71 */
+  float cmd_y_lo, cmd_y_hi;   /* linear_y                          KAMMA.py:72  */
+  float cmd_yaw_lo, cmd_yaw_hi; /* yaw                             KAMMA.py:73  */
+  float init_pos[3];          /* baseInitState.pos                 KAMMA.py:44  */
+  float init_quat[4];         /* baseInitState.rot (w,x,y,z)       KAMMA.py:45  */
+  float init_lin_vel[3];      /* vLinear                           KAMMA.py:46  */
+  float init_ang_vel[3];      /* vAngular                          KAMMA.py:47  */
+  float init_dof_vel[4];      /* dofInitVelocities                 KAMMA.py:50  */
+  float spawn_xy_range;       /* 0.5: U(-0.5,0.5)                  KAMMA.py:424 */
+  float bounds;               /* 50                                KAMMA.py:187 */
+  float clip_obs;             /* env.clipObservations 1000         KAMMA.py:42, rl_task.py:99 */
+  float eval_ramp_steps;      /* 50000                             KAMMA_eval.py:545-550 */
+
+  /* ---- physics model (build-defined, parity-unpinned: PhysX is not in the reference;
+          parameters from src/my_assets/urdf/origin_sym.urdf, origin_v18.py:61-70,
+          KAMMA.py:82-127; model in docs/SPEC.md §3) ---- */
+  float gravity;              /* 9.81 (sim.gravity z)              KAMMA.py:84  */
+  float body_mass;            /* 21 + 4*1 = 25                     urdf:11,34   */
+  float body_inertia[3];      /* composite about composite COM, wheel spin excluded (host-composed) */
+  float com_height;           /* composite COM above base-link origin (0.00896)  */
+  float wheel_pos[3];         /* |x|,|y|,z of wheel centres in base-link frame   urdf:115-139 */
+  float wheel_radius;         /* 0.1175                            urdf:40, KAMMA.py:79 */
+  float wheel_spin_inertia;   /* 0.01                              urdf:35      */
+  float wheel_damping;        /* viscous joint damping [N m s/rad], CALIBRATED */
+  float friction;             /* default mu (0.85 from scripts)    train_*.py:66-67 */
+  float baumgarte;            /* penetration bias factor                          */
+  float max_depenetration_velocity; /* 100                         KAMMA.py:105 */
+  float max_angular_velocity; /* 64 rad/s                          origin_v18.py:70 */
+  int32_t solver_iterations;  /* 4                                 KAMMA.py:96-97 */
+  int32_t reserved_[8];
+} ois_config;
+
+/* Buffer ids for ois_buffer(). Shapes are row-major; N = num_envs. */
+enum ois_buffer_id {
+  OIS_BUF_OBS = 0,         /* float [N,6]  obs_buf            KAMMA.py:833 (clamped, rl_task.py:99) */
+  OIS_BUF_REW = 1,         /* float [N]    rew_buf            KAMMA.py:798-801 */
+  OIS_BUF_DONE = 2,        /* uint8 [N]    reset_buf (0/1)    KAMMA.py:754-760 */
+  OIS_BUF_TIMEOUT = 3,     /* uint8 [N]    timeout_buf        KAMMA.py:740-744 */
+  OIS_BUF_WHEEL_TORQS = 4, /* float [N,4]  wheel_torqs        KAMMA.py:649 */
+  OIS_BUF_POSE = 5,        /* float [N,4]  p_com.xyz, v_forward_projected */
+  OIS_BUF_QUAT = 6,        /* float [N,4]  base_quat (w,x,y,z) */
+  OIS_BUF_LINVEL = 7,      /* float [N,4]  v.xyz (world), previous_linear_velocity[:,0] */
+  OIS_BUF_ANGVEL = 8,      /* float [N,4]  w.xyz (world), previous_angular_velocity[:,2] */
+  OIS_BUF_WHEEL_VEL = 9,   /* float [N,4]  dof_vel (joint velocities, order fl,rl,fr,rr) */
+  OIS_BUF_COMMANDS = 10,   /* float [N,4]  commands (x, y, yaw, heading)  KAMMA.py:378-380 */
+  OIS_BUF_COUNTERS = 11,   /* int32 [N,4]  episode_buf, sim_steps, episode_count, reserved */
+  OIS_BUF_SUMS_A = 12,     /* float [N,4]  episode sums r1, r2, r3, dense */
+  OIS_BUF_SUMS_B = 13,     /* float [N,4]  episode sums sparse, guiding, observed, final */
+  OIS_BUF_PARAMS = 14,     /* float [N,4]  per-arena mu, plane normal xyz (domain randomisation) */
+  OIS_BUF_EPISODE_INFO = 15, /* float [OIS_EPISODE_INFO_LEN] written by ois_episode_info */
+  OIS_BUF_ENV0_DIAG = 16,  /* float [OIS_ENV0_DIAG_LEN] arena-0 diagnostics of the last step */
+  OIS_BUF_SUMS_C = 17,     /* float [N,4]  eval sums smoothness, tracking error, desired v, prev-torque scratch */
+  OIS_BUF_LAMBDA_N = 18,   /* float [N,4]  cached normal contact impulses per wheel (solver warm start) */
+  OIS_BUF_LAMBDA_L = 19,   /* float [N,4]  cached longitudinal friction impulses */
+  OIS_BUF_LAMBDA_T = 20,   /* float [N,4]  cached lateral friction impulses */
+  OIS_BUF_COUNT_
+};
+
+#define OIS_EPISODE_INFO_LEN 32
+#define OIS_ENV0_DIAG_LEN 32
+
+/* index of each value inside OIS_BUF_EPISODE_INFO (names: KAMMA.py:205-221, 470-488) */
+enum ois_episode_info_slot {
+  OIS_EI_COUNT = 0,        /* number of arenas reset in the step that produced this record */
+  OIS_EI_R1 = 1, OIS_EI_R2 = 2, OIS_EI_R3 = 3, OIS_EI_DENSE = 4, OIS_EI_SPARSE = 5,
+  OIS_EI_GUIDING = 6, OIS_EI_OBSERVED = 7, OIS_EI_FINAL = 8,
+  OIS_EI_R1_OVER_FINAL = 9, OIS_EI_R2_OVER_FINAL = 10, OIS_EI_R3_OVER_FINAL = 11,
+  OIS_EI_DENSE_OVER_FINAL = 12, OIS_EI_SPARSE_OVER_FINAL = 13,
+  OIS_EI_GUIDING_OVER_FINAL = 14, OIS_EI_OBSERVED_OVER_FINAL = 15,
+  OIS_EI_GAMMA1 = 16, OIS_EI_GAMMA2 = 17, OIS_EI_TERRAIN_LEVEL = 18,
+  OIS_EI_STEP = 19,        /* sim_steps value at which the record was produced (as float) */
+  OIS_EI_SMOOTHNESS = 20, OIS_EI_TRACKING_ERROR = 21, OIS_EI_DESIRED_VELOCITY = 22
+};
+
+/* finished-episode statistics since the last ois_stats_fetch(reset_after=1)
+ * (device-side replacement of src/my_agents/base.py:305-341) */
+typedef struct ois_stats {
+  double episodes;      /* finished episodes                       */
+  double return_sum;    /* sum of episode returns ("Final reward") */
+  double return_sqsum;  /* sum of squared returns                  */
+  double return_min;
+  double return_max;
+  double length_sum;    /* sum of episode lengths in policy steps  */
+  double steps;         /* env steps executed (N * policy steps)   */
+  double reserved;
+} ois_stats;
+
+typedef struct ois_env ois_env; /* opaque */
+
+int ois_abi_version(void);
+const char* ois_last_error(void);
+
+/* Fill `cfg` with the reference defaults: TASK_CFG of KAMMA.py:29-128 with the overrides
+ * every train script applies (train_kamma_4d_nofifo_random_RLIL.py:63-91: stiffness 0.035,
+ * friction 0.85, linear_x [1,2]) and the KAMMA_medium schedule (max_sim_steps 500000). */
+int ois_config_default(ois_config* cfg);
+
+/* Bytes of device workspace ois_create needs for `cfg` (0 on error). */
+size_t ois_workspace_bytes(const ois_config* cfg);
+
+/* Bind an environment to a caller-owned device workspace (>= ois_workspace_bytes, 256-B
+ * aligned). `device` is the HIP device ordinal the workspace lives on. */
+int ois_create(const ois_config* cfg, int device, void* workspace_device, size_t workspace_bytes,
+               ois_env** out);
+void ois_destroy(ois_env* env);
+
+/* post_reset: zero all task buffers, reset_idx(all arenas) with `seed`. */
+int ois_reset(ois_env* env, uint64_t seed, void* stream);
+
+/* One policy step for all arenas. actions_device: float [N, action_dim] row-major. */
+int ois_step(ois_env* env, const float* actions_device, void* stream);
+
+/* k policy steps in ONE launch; state stays in registers between steps.
+ * policy EXTERNAL: actions_device is float [k, N, action_dim]; otherwise ignored (may be NULL).
+ * reward_sum_device (optional, may be NULL): float [N], receives the sum of the k rewards. */
+int ois_rollout(ois_env* env, int k, int policy, const float* actions_device,
+                float* reward_sum_device, void* stream);
+
+/* Device pointer + size of one buffer (aliases the workspace). */
+int ois_buffer(ois_env* env, int id, void** ptr_device, size_t* bytes);
+
+/* Per-arena domain randomisation (BASELINE.json config 4): mu ~ U(mu_lo, mu_hi) and plane
+ * slope drawn from `slopes[n_slopes]` (tan of the incline about a random heading), both
+ * from Philox keyed by the global arena id. n_slopes == 0 keeps the flat plane. */
+int ois_randomize_params(ois_env* env, float mu_lo, float mu_hi, const float* slopes_host,
+                         int n_slopes, void* stream);
+
+/* Reduce the per-wave partial sums of the most recent reset event into OIS_BUF_EPISODE_INFO
+ * (device). No host synchronisation. */
+int ois_episode_info(ois_env* env, void* stream);
+
+/* Copy finished-episode statistics to the host (synchronises `stream`). */
+int ois_stats_fetch(ois_env* env, ois_stats* host_out, int reset_after, void* stream);
+
+/* Copy the arena-0 diagnostics block to the host (synchronises `stream`). */
+int ois_env0_diag(ois_env* env, float* host_out /*[OIS_ENV0_DIAG_LEN]*/, void* stream);
+
+/* Snapshot / restore the complete environment state (all persistent buffers) to/from a
+ * host blob of ois_state_bytes(). Beyond reference parity (SURVEY.md §5 checkpoint). */
+size_t ois_state_bytes(const ois_env* env);
+int ois_save_state(ois_env* env, void* host_blob, size_t bytes, void* stream);
+int ois_load_state(ois_env* env, const void* host_blob, size_t bytes, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* OIS_H_ */

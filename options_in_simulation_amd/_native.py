@@ -1,0 +1,76 @@
+"""ctypes binding of the product library (lib/libois_hip.so, C ABI of include/ois.h).
+
+There is no CPU fallback: if the HIP library is missing or does not load, importing the
+environment fails loudly with instructions to build it.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+from . import _abi
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "libois_hip.so")
+
+# every symbol include/ois.h declares (tests/test_abi.py checks the exports against the header)
+SYMBOLS = (
+    "ois_abi_version", "ois_last_error", "ois_config_default", "ois_workspace_bytes", "ois_create",
+    "ois_destroy", "ois_reset", "ois_step", "ois_rollout", "ois_buffer", "ois_randomize_params",
+    "ois_episode_info", "ois_stats_fetch", "ois_env0_diag", "ois_state_bytes", "ois_save_state",
+    "ois_load_state",
+)
+
+_lib = None
+
+
+class NativeLibraryError(RuntimeError):
+    pass
+
+
+def load() -> C.CDLL:
+    """Load libois_hip.so (once). torch must be imported first by the caller when the env is
+    used from PyTorch so that both share one HIP runtime (same libamdhip64 SONAME)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise NativeLibraryError(
+            f"{LIB_PATH} not found. Build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+            f"or `make -C {os.path.join(_HERE, 'csrc')}`. There is no CPU fallback.")
+    try:
+        L = C.CDLL(LIB_PATH)
+    except OSError as exc:  # pragma: no cover
+        raise NativeLibraryError(f"cannot load {LIB_PATH}: {exc}") from exc
+    vp, fp = C.c_void_p, C.POINTER(C.c_float)
+    cfgp = C.POINTER(_abi.OisConfig)
+    L.ois_abi_version.restype = C.c_int
+    L.ois_last_error.restype = C.c_char_p
+    L.ois_config_default.argtypes = [cfgp]
+    L.ois_workspace_bytes.argtypes = [cfgp]
+    L.ois_workspace_bytes.restype = C.c_size_t
+    L.ois_create.argtypes = [cfgp, C.c_int, vp, C.c_size_t, C.POINTER(vp)]
+    L.ois_destroy.argtypes = [vp]
+    L.ois_destroy.restype = None
+    L.ois_reset.argtypes = [vp, C.c_uint64, vp]
+    L.ois_step.argtypes = [vp, vp, vp]
+    L.ois_rollout.argtypes = [vp, C.c_int, C.c_int, vp, vp, vp]
+    L.ois_buffer.argtypes = [vp, C.c_int, C.POINTER(vp), C.POINTER(C.c_size_t)]
+    L.ois_randomize_params.argtypes = [vp, C.c_float, C.c_float, fp, C.c_int, vp]
+    L.ois_episode_info.argtypes = [vp, vp]
+    L.ois_stats_fetch.argtypes = [vp, C.POINTER(_abi.OisStats), C.c_int, vp]
+    L.ois_env0_diag.argtypes = [vp, fp, vp]
+    L.ois_state_bytes.argtypes = [vp]
+    L.ois_state_bytes.restype = C.c_size_t
+    L.ois_save_state.argtypes = [vp, vp, C.c_size_t, vp]
+    L.ois_load_state.argtypes = [vp, vp, C.c_size_t, vp]
+    if L.ois_abi_version() != _abi.ABI_VERSION:
+        raise NativeLibraryError(
+            f"ABI mismatch: library {L.ois_abi_version()} vs python {_abi.ABI_VERSION}; rebuild the library")
+    _lib = L
+    return L
+
+
+def check(rc: int) -> None:
+    if rc != 0:
+        raise RuntimeError(f"libois_hip call failed ({rc}): {load().ois_last_error().decode()}")

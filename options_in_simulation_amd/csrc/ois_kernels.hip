@@ -1,0 +1,718 @@
+// ois_kernels.hip — fused policy-step kernel for N skid-steer arenas on gfx950 + the C ABI
+// of include/ois.h. Reference path: TorqueDistributionTask.pre_physics_step /
+// post_physics_step (src/my_envs/KAMMA.py:596-727) with PhysX replaced by the build-defined
+// rigid-body model of docs/SPEC.md §3.
+//
+// One launch = one (or k) policy step(s) for all arenas: controller -> action mixing ->
+// torque clip -> 20 contact-solver substeps -> termination -> reward -> auto-reset ->
+// observation -> forward-speed projection, state in registers throughout.
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <new>
+
+#include "ois_device.h"
+
+using namespace ois;
+
+namespace {
+
+constexpr int kBlock = 256;
+
+// ------------------------------------------------------------------ load / store ------
+OIS_DEV void load_lane(const DevConsts& K, const DevBuffers& B, int ld, Lane& S) {
+  float g;
+  g = B.pose[ld];
+  S.p[0] = quad_bcast<0>(g); S.p[1] = quad_bcast<1>(g); S.p[2] = quad_bcast<2>(g); S.vfwd = quad_bcast<3>(g);
+  g = B.quat[ld];
+  S.q[0] = quad_bcast<0>(g); S.q[1] = quad_bcast<1>(g); S.q[2] = quad_bcast<2>(g); S.q[3] = quad_bcast<3>(g);
+  g = B.linvel[ld];
+  S.v[0] = quad_bcast<0>(g); S.v[1] = quad_bcast<1>(g); S.v[2] = quad_bcast<2>(g); S.prev_lin = quad_bcast<3>(g);
+  g = B.angvel[ld];
+  S.w[0] = quad_bcast<0>(g); S.w[1] = quad_bcast<1>(g); S.w[2] = quad_bcast<2>(g); S.prev_ang = quad_bcast<3>(g);
+  g = B.commands[ld];
+  S.cmd[0] = quad_bcast<0>(g); S.cmd[1] = quad_bcast<1>(g); S.cmd[2] = quad_bcast<2>(g); S.cmd[3] = quad_bcast<3>(g);
+  int c = B.counters[ld];
+  S.ep_buf = quad_bcasti<0>(c); S.sim_steps = quad_bcasti<1>(c); S.ep_count = quad_bcasti<2>(c);
+  g = B.params[ld];
+  S.mu = quad_bcast<0>(g); S.n[0] = quad_bcast<1>(g); S.n[1] = quad_bcast<2>(g); S.n[2] = quad_bcast<3>(g);
+  S.jv = B.wheel_vel[ld];
+  S.ln = B.lam_n[ld]; S.l1 = B.lam_l[ld]; S.l2 = B.lam_t[ld];
+  S.sa = B.sums_a[ld]; S.sb = B.sums_b[ld];
+  S.sc = K.eval_sums ? B.sums_c[ld] : 0.0f;
+  S.wt = K.eval_sums ? B.wheel_torqs[ld] : 0.0f;
+}
+
+OIS_DEV void store_lane(const DevConsts& K, const DevBuffers& B, int tid, int wl, const Lane& S) {
+  B.pose[tid] = sel4(wl, S.p[0], S.p[1], S.p[2], S.vfwd);
+  B.quat[tid] = sel4(wl, S.q[0], S.q[1], S.q[2], S.q[3]);
+  B.linvel[tid] = sel4(wl, S.v[0], S.v[1], S.v[2], S.prev_lin);
+  B.angvel[tid] = sel4(wl, S.w[0], S.w[1], S.w[2], S.prev_ang);
+  B.commands[tid] = sel4(wl, S.cmd[0], S.cmd[1], S.cmd[2], S.cmd[3]);
+  int c = (wl & 2) ? ((wl & 1) ? 0 : S.ep_count) : ((wl & 1) ? S.sim_steps : S.ep_buf);
+  B.counters[tid] = c;
+  B.wheel_vel[tid] = S.jv;
+  B.lam_n[tid] = S.ln; B.lam_l[tid] = S.l1; B.lam_t[tid] = S.l2;
+  B.sums_a[tid] = S.sa; B.sums_b[tid] = S.sb;
+  if (K.eval_sums) B.sums_c[tid] = S.sc;
+  B.wheel_torqs[tid] = S.wt;
+}
+
+// ------------------------------------------------------------------ the step kernel ---
+__global__ __launch_bounds__(kBlock) void step_kernel(DevConsts K, DevBuffers B, const float* __restrict__ actions,
+                                                      float* __restrict__ reward_sum, int N, int ksteps, int policy) {
+  const int tid = blockIdx.x * kBlock + threadIdx.x;
+  const int lane = threadIdx.x & 63;
+  const int wave = tid >> 6;
+  const int wl = tid & 3;
+  const int arena = tid >> 2;
+  const bool valid = arena < N;
+  const int la = valid ? arena : N - 1;
+  const int ld = la * 4 + wl;
+  const int64_t gid = K.arena_offset + la;
+  // wheel centre of this lane relative to the COM: fl, rl, fr, rr (urdf:112-142)
+  const float cx = (wl & 1) ? -K.wx : K.wx;
+  const float cy = (wl & 2) ? -K.wy : K.wy;
+  const int A = K.action_dim;
+  const int amap = A == 4 ? wl : (A == 2 ? (wl >> 1) : 0);  // KA_DDPG_2D.py:623-624, KA_DDPG_1D.py:600-603
+
+  Lane S;
+  load_lane(K, B, ld, S);
+  float rsum = 0.0f;
+
+  for (int s = 0; s < ksteps; ++s) {
+    const bool last = s == ksteps - 1;
+    // ---- action of this lane's wheel ----
+    float a = 0.0f;
+    if (policy == OIS_POLICY_EXTERNAL) {
+      a = actions[((size_t)s * N + la) * A + amap];
+    } else if (policy == OIS_POLICY_RANDOM) {
+      float u[4];
+      draw4(K, gid, (uint32_t)S.sim_steps, PURPOSE_ACTION, u);
+      a = sel4(amap, u[0], u[1], u[2], u[3]);
+    }
+    // ---- pre_physics_step (KAMMA.py:596-656) ----
+    const float current_v = S.vfwd;     // :607
+    const float current_omega = S.w[2]; // :608
+    const float vd = S.cmd[0] - current_v;      // :609
+    const float od = S.cmd[2] - current_omega;  // :610
+    const float lin = K.Kp * (K.vehicle_mass * (vd / K.policy_dt));           // :617
+    const float ang = K.Kp_omega * (K.vehicle_inertia * (od / K.policy_dt));
+    const float ac_left = lin - ang, ac_right = lin + ang;                    // :617, :619
+    const float crit = (wl < 2) ? ac_left : ac_right;                         // :624
+    float gs = 1.0f - ((float)S.sim_steps / K.max_sim_steps);                 // :627-628
+    gs = gs < 0.0f ? 0.0f : gs;
+    const float gamma1 = K.gamma1_mode == OIS_GAMMA_CONST ? K.gamma1_const : gs;
+    const float gamma2 = K.gamma2_mode == OIS_GAMMA_CONST ? K.gamma2_const : gs;
+    const float pol = a * K.action_scale;
+    float t;
+    if (K.mix_mode == OIS_MIX_SWITCH) {
+      float u[4];
+      draw4(K, gid, (uint32_t)S.sim_steps, PURPOSE_MASK, u);  // torch.rand(num_envs, 1) :633
+      const float mask = u[0] < gamma1 ? 1.0f : 0.0f;         // :634
+      t = mask * crit + (1.0f - mask) * pol;                  // :635
+    } else {
+      t = ((1.0f - gamma1) * a) * K.action_scale + gamma1 * crit;  // KA_DDPG_4D.py:631
+    }
+    const float wt = clipf(t, -K.torque_clip, K.torque_clip);  // :649
+    const float gd = (K.guiding_mode == OIS_GUIDE_EXECUTED ? wt : pol) - crit;
+    const float guiding = -sqrtf(quad_sum(gd * gd));           // :656 / KA_DDPG_4D.py:637
+    if (K.eval_sums) {  // KAMMA_eval.py:677-685
+      const float flag = quad_bcast<3>(S.sc);
+      const float old = flag != 0.0f ? S.wt : 0.0f;
+      const float df = old - wt;
+      const float sm = quad_sum(df * df) / 10.0f;
+      const float dv = S.cmd[0] / 10.0f;
+      S.sc = wl == 0 ? S.sc + sm : (wl == 2 ? S.sc + dv : (wl == 3 ? 1.0f : S.sc));
+    }
+    S.wt = wt;
+
+    // ---- physics: decimation (:646-653) + controlFrequencyInv (:43) substeps ----
+    {
+      float R[9], wb[3];
+      rotmat(S.q, R);
+      rotT(R, S.w, wb);
+      float spin = S.jv + wb[1];
+      for (int i = 0; i < K.nsub; ++i) substep(K, wl, cx, cy, S, spin);
+      rotmat(S.q, R);
+      rotT(R, S.w, wb);
+      S.jv = spin - wb[1];
+      // base-link position for the bounds check (:758-759)
+      S.ep_buf += 1;     // :675
+      S.sim_steps += 1;  // :676
+      const float plx = __builtin_fmaf(-R[2], K.com_height, S.p[0]);
+      const float ply = __builtin_fmaf(-R[5], K.com_height, S.p[1]);
+      // ---- is_done (:736-764) ----
+      const bool timeout = S.ep_buf >= K.max_episode_length - 1;  // :740-744
+      float pg[3];
+      quat_apply(S.q, 0.0f, 0.0f, -1.0f, pg);                      // :749
+      const bool fallen = pg[2] > 0.0f;                            // :753
+      const bool oob = (plx < -K.bounds) | (plx > K.bounds) | (ply < -K.bounds) | (ply > K.bounds);
+      const bool reset = fallen | timeout | oob;
+      // ---- calculate_metrics (:767-822) ----
+      const float lin_acc = (current_v - S.prev_lin) / K.policy_dt;  // :770
+      const float ang_acc = (S.w[2] - S.prev_ang) / K.policy_dt;     // :771
+      S.prev_lin = current_v;                                        // :774
+      S.prev_ang = S.w[2];                                           // :775
+      const float r1 = vd * vd + 5.0f * (od * od);                   // :779
+      const float r2 = lin_acc * lin_acc + ang_acc * ang_acc;        // :781
+      const float r3 = quad_sum(wt * wt);                            // :783
+      const float c1 = K.w1 * r1, c2 = K.w2 * r2, c3 = K.w3 * r3;
+      const float rdense = (c1 + c2) + c3;                           // :786
+      const float sparse = (fabsf(vd) < K.sparse_threshold && fabsf(od) < K.sparse_threshold) ? K.sparse_bonus : 0.0f;
+      const float observed = rdense + sparse;                        // :795
+      float rew = (1.0f - gamma2) * observed + gamma2 * guiding;     // :798
+      rew += (K.terminal_reward * (reset ? 1.0f : 0.0f)) * (timeout ? -2.0f : -1.0f);  // :801 (~ on int64)
+      S.sa += sel4(wl, c1, c2, c3, rdense);          // :803-806
+      S.sb += sel4(wl, sparse, guiding, observed, rew);  // :807-810
+      if (K.eval_sums && wl == 1) S.sc += fabsf(vd) / 10.0f;  // KAMMA_eval.py:840
+      rsum += rew;
+      // ---- reset_idx (:417-498) ----
+      ResetContrib rc = contrib_identity(wl);
+      const bool do_reset = reset && valid;
+      if (reset) reset_arena(K, wl, gid, gamma1, gamma2, S, rc);
+      if (!valid) rc = contrib_identity(wl);
+      // ---- outputs (only the last step of a rollout is observable) ----
+      if (last && valid) {
+        // get_observations (:833); desired_* are views of commands -> post-reset values
+        const float o = sel4(wl, S.cmd[0], S.cmd[2], vd, od);
+        B.obs[(size_t)arena * 6 + wl] = clipf(o, -K.clip_obs, K.clip_obs);  // clamp: rl_task.py:99
+        if (wl < 2) B.obs[(size_t)arena * 6 + 4 + wl] = clipf(wl == 0 ? lin_acc : ang_acc, -K.clip_obs, K.clip_obs);
+        if (wl == 0) {
+          B.rew[arena] = rew;
+          B.done[arena] = reset ? 1 : 0;
+          B.timeout[arena] = timeout ? 1 : 0;
+        }
+        if (arena == 0) {  // task.observed_components ingredients (:840-867)
+          float* d = B.env0_diag;
+          d[9 + wl] = t;
+          d[15 + wl] = pol;
+          if (wl == 0) {
+            d[0] = S.cmd[0]; d[1] = current_v; d[2] = S.cmd[2]; d[3] = current_omega; d[4] = vd; d[5] = od;
+            d[6] = lin_acc; d[7] = ang_acc; d[8] = (float)S.ep_count; d[13] = ac_left; d[14] = ac_right;
+            d[19] = gamma2; d[20] = c1; d[21] = c2; d[22] = c3; d[23] = rdense; d[24] = sparse; d[25] = observed;
+            d[26] = guiding; d[27] = rew; d[28] = gamma1;
+          }
+        }
+      }
+      // tail of post_physics_step (:701-710) on the possibly reset state
+      S.vfwd = forward_projection(S.q, S.v);
+      // ---- per-wave record of the reset event (extras["episode"], episode statistics) ----
+      if (__ballot(do_reset) != 0ull) wave_record(B, wave, lane, rc, S.sim_steps, true);
+    }
+  }
+  if (valid) {
+    store_lane(K, B, tid, wl, S);
+    if (reward_sum != nullptr && wl == 0) reward_sum[arena] = rsum;
+  }
+}
+
+// ------------------------------------------------------------------ post_reset --------
+// KAMMA.py:366-414: zero the task buffers, reset_idx(all arenas).
+__global__ __launch_bounds__(kBlock) void reset_kernel(DevConsts K, DevBuffers B, int N) {
+  const int tid = blockIdx.x * kBlock + threadIdx.x;
+  const int lane = threadIdx.x & 63;
+  const int wave = tid >> 6;
+  const int wl = tid & 3;
+  const int arena = tid >> 2;
+  const bool valid = arena < N;
+  const int la = valid ? arena : N - 1;
+  const int64_t gid = K.arena_offset + la;
+  Lane S;
+  for (int k = 0; k < 3; ++k) { S.p[k] = 0.0f; S.v[k] = 0.0f; S.w[k] = 0.0f; }
+  for (int k = 0; k < 4; ++k) { S.q[k] = 0.0f; S.cmd[k] = 0.0f; }
+  S.vfwd = S.prev_lin = S.prev_ang = 0.0f;
+  S.ep_buf = S.sim_steps = S.ep_count = 0;
+  S.jv = S.ln = S.l1 = S.l2 = S.wt = S.sa = S.sb = S.sc = 0.0f;
+  S.mu = 0.0f; S.n[0] = S.n[1] = 0.0f; S.n[2] = 1.0f;
+  // gamma_assist1/2 hold their constructor values here (KAMMA.py:192-193: ones)
+  const float g1 = K.gamma1_mode == OIS_GAMMA_CONST ? K.gamma1_const : 1.0f;
+  const float g2 = K.gamma2_mode == OIS_GAMMA_CONST ? K.gamma2_const : 1.0f;
+  ResetContrib rc;
+  reset_arena(K, wl, gid, g1, g2, S, rc);
+  if (!valid) rc = contrib_identity(wl);
+  if (lane < 4) {  // clear the finished-episode accumulators of this wave
+    float* Acc = B.stat_acc + (size_t)wave * 8;
+    Acc[lane] = 0.0f;
+    Acc[4 + lane] = -__builtin_inff();
+  }
+  wave_record(B, wave, lane, rc, 0, false);
+  if (valid) {
+    // params are owned by ois_create / ois_randomize_params: keep them
+    B.pose[tid] = sel4(wl, S.p[0], S.p[1], S.p[2], S.vfwd);
+    B.quat[tid] = sel4(wl, S.q[0], S.q[1], S.q[2], S.q[3]);
+    B.linvel[tid] = sel4(wl, S.v[0], S.v[1], S.v[2], S.prev_lin);
+    B.angvel[tid] = sel4(wl, S.w[0], S.w[1], S.w[2], S.prev_ang);
+    B.commands[tid] = sel4(wl, S.cmd[0], S.cmd[1], S.cmd[2], S.cmd[3]);
+    B.counters[tid] = (wl & 2) ? ((wl & 1) ? 0 : S.ep_count) : ((wl & 1) ? S.sim_steps : S.ep_buf);
+    B.wheel_vel[tid] = S.jv;
+    B.lam_n[tid] = 0.0f; B.lam_l[tid] = 0.0f; B.lam_t[tid] = 0.0f;
+    B.sums_a[tid] = 0.0f; B.sums_b[tid] = 0.0f; B.sums_c[tid] = 0.0f;
+    B.wheel_torqs[tid] = 0.0f;
+    B.obs[(size_t)arena * 6 + wl] = 0.0f;
+    if (wl < 2) B.obs[(size_t)arena * 6 + 4 + wl] = 0.0f;
+    if (wl == 0) { B.rew[arena] = 0.0f; B.done[arena] = 0; B.timeout[arena] = 0; }
+  }
+  if (tid < OIS_ENV0_DIAG_LEN) { B.env0_diag[tid] = 0.0f; B.episode_info[tid] = 0.0f; }
+}
+
+__global__ void init_params_kernel(DevBuffers B, int N, float mu) {
+  const int tid = blockIdx.x * blockDim.x + threadIdx.x;
+  if (tid < N * 4) B.params[tid] = (tid & 3) == 0 ? mu : ((tid & 3) == 3 ? 1.0f : 0.0f);
+}
+
+// per-arena domain randomisation (BASELINE.json config 4)
+__global__ void randomize_params_kernel(DevConsts K, DevBuffers B, int N, float mu_lo, float mu_hi,
+                                        const float* __restrict__ slopes, int n_slopes) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= N) return;
+  float u[4];
+  draw4(K, K.arena_offset + i, 0u, PURPOSE_PARAMS, u);
+  float nx = 0.0f, ny = 0.0f, nz = 1.0f;
+  if (n_slopes > 0) {
+    int idx = (int)(u[1] * (float)n_slopes);
+    if (idx >= n_slopes) idx = n_slopes - 1;
+    const float sl = slopes[idx];
+    float s, c;
+    sincos_det(3.14159274101257324f * u[2], s, c);
+    const float inv = 1.0f / sqrtf(__builtin_fmaf(sl, sl, 1.0f));
+    nx = -(sl * c) * inv; ny = -(sl * s) * inv; nz = inv;
+  }
+  float* p = B.params + (size_t)i * 4;
+  p[0] = rand_float(mu_lo, mu_hi, u[0]); p[1] = nx; p[2] = ny; p[3] = nz;
+}
+
+// extras["episode"] (KAMMA.py:480-488): deterministic in-order sum of the per-wave records
+// of the most recent reset event. One block of 64 threads; thread t owns record slot t.
+__global__ __launch_bounds__(64) void episode_info_kernel(DevConsts K, DevBuffers B, int nwaves) {
+  __shared__ float acc[32];
+  const int t = threadIdx.x;
+  int smax = -1;
+  for (int w = 0; w < nwaves; ++w) smax = max(smax, B.stamps[w]);
+  if (t < 32) {
+    float a = 0.0f;
+    bool first = true;
+    for (int w = 0; w < nwaves; ++w) {
+      if (B.stamps[w] != smax) continue;
+      const float x = B.partials[(size_t)w * 32 + t];
+      if (t == 24 || t == 25) { if (first) a = x; }  // gamma1 / gamma2 (identical in every arena)
+      else a += x;
+      first = false;
+    }
+    acc[t] = a;
+  }
+  __syncthreads();
+  if (t == 0) {
+    float* I = B.episode_info;
+    for (int k = 0; k < OIS_EPISODE_INFO_LEN; ++k) I[k] = 0.0f;
+    const float cnt = acc[0], L = K.episode_length_s;
+    I[OIS_EI_COUNT] = cnt;
+    for (int k = 0; k < 4; ++k) {
+      I[OIS_EI_R1 + k] = (acc[4 + k] / cnt) / L;              // :482-484
+      I[OIS_EI_SPARSE + k] = (acc[8 + k] / cnt) / L;
+      I[OIS_EI_R1_OVER_FINAL + k] = (acc[12 + k] / cnt) / L;
+    }
+    for (int k = 0; k < 3; ++k) {
+      I[OIS_EI_SPARSE_OVER_FINAL + k] = (acc[16 + k] / cnt) / L;
+      I[OIS_EI_SMOOTHNESS + k] = (acc[20 + k] / cnt) / L;
+    }
+    I[OIS_EI_GAMMA1] = acc[24];       // :486
+    I[OIS_EI_GAMMA2] = acc[25];       // :487
+    I[OIS_EI_TERRAIN_LEVEL] = 0.0f;   // :488 (terrain_levels are zeros, :223)
+    I[OIS_EI_STEP] = (float)smax;
+  }
+}
+
+// finished-episode statistics: in-order reduction of the per-wave accumulators
+__global__ __launch_bounds__(64) void stats_kernel(DevBuffers B, int nwaves, float* out8, int reset_after) {
+  const int t = threadIdx.x;
+  if (t >= 8) return;
+  float a = t < 4 ? 0.0f : -__builtin_inff();
+  for (int w = 0; w < nwaves; ++w) {
+    float* p = B.stat_acc + (size_t)w * 8 + t;
+    const float x = *p;
+    a = t < 4 ? a + x : fmaxf(a, x);
+    if (reset_after) *p = t < 4 ? 0.0f : -__builtin_inff();
+  }
+  out8[t] = a;
+}
+
+// ------------------------------------------------------------------ host side ---------
+thread_local char g_err[512] = "";
+int fail(int code, const char* fmt, const char* detail = "") {
+  snprintf(g_err, sizeof g_err, fmt, detail);
+  return code;
+}
+#define HIP_TRY(expr)                                                            \
+  do {                                                                           \
+    hipError_t e_ = (expr);                                                      \
+    if (e_ != hipSuccess) {                                                      \
+      snprintf(g_err, sizeof g_err, "%s failed: %s", #expr, hipGetErrorString(e_)); \
+      return OIS_EHIP;                                                           \
+    }                                                                            \
+  } while (0)
+
+size_t align256(size_t x) { return (x + 255) & ~(size_t)255; }
+
+struct Layout {
+  size_t off[OIS_BUF_COUNT_];
+  size_t bytes[OIS_BUF_COUNT_];
+  size_t partials, stamps, stat_acc, stat_out, total;
+  int nwaves;
+};
+
+Layout make_layout(int N) {
+  Layout L;
+  std::memset(&L, 0, sizeof L);
+  const size_t f4 = (size_t)N * 4 * sizeof(float);
+  size_t o = 0;
+  auto put = [&](int id, size_t b) { L.off[id] = o; L.bytes[id] = b; o = align256(o + b); };
+  // persistent state first (ois_save_state copies [0, total))
+  put(OIS_BUF_POSE, f4); put(OIS_BUF_QUAT, f4); put(OIS_BUF_LINVEL, f4); put(OIS_BUF_ANGVEL, f4);
+  put(OIS_BUF_WHEEL_VEL, f4); put(OIS_BUF_COMMANDS, f4); put(OIS_BUF_COUNTERS, f4);
+  put(OIS_BUF_SUMS_A, f4); put(OIS_BUF_SUMS_B, f4); put(OIS_BUF_SUMS_C, f4); put(OIS_BUF_PARAMS, f4);
+  put(OIS_BUF_LAMBDA_N, f4); put(OIS_BUF_LAMBDA_L, f4); put(OIS_BUF_LAMBDA_T, f4);
+  put(OIS_BUF_WHEEL_TORQS, f4);
+  put(OIS_BUF_OBS, (size_t)N * 6 * sizeof(float));
+  put(OIS_BUF_REW, (size_t)N * sizeof(float));
+  put(OIS_BUF_DONE, (size_t)N);
+  put(OIS_BUF_TIMEOUT, (size_t)N);
+  put(OIS_BUF_EPISODE_INFO, OIS_EPISODE_INFO_LEN * sizeof(float));
+  put(OIS_BUF_ENV0_DIAG, OIS_ENV0_DIAG_LEN * sizeof(float));
+  L.nwaves = (N * 4 + 63) / 64;
+  L.partials = o; o = align256(o + (size_t)L.nwaves * 32 * sizeof(float));
+  L.stamps = o; o = align256(o + (size_t)L.nwaves * sizeof(int32_t));
+  L.stat_acc = o; o = align256(o + (size_t)L.nwaves * 8 * sizeof(float));
+  L.stat_out = o; o = align256(o + 32 * sizeof(float));  // 8 stats out / 16-entry slope table scratch
+  L.total = o;
+  return L;
+}
+
+int validate(const ois_config* c) {
+  if (!c) return fail(OIS_EINVAL, "null config");
+  if (c->struct_bytes != sizeof(ois_config)) return fail(OIS_EINVAL, "ois_config.struct_bytes does not match this library");
+  if (c->num_envs <= 0 || c->num_envs > (1 << 27)) return fail(OIS_EINVAL, "num_envs out of range");
+  if (c->action_dim != 4 && c->action_dim != 2 && c->action_dim != 1) return fail(OIS_EINVAL, "action_dim must be 4, 2 or 1");
+  if (c->solver_iterations < 1 || c->solver_iterations > 16) return fail(OIS_EINVAL, "solver_iterations out of range");
+  if (c->decimation < 0 || c->extra_substeps < 0 || c->decimation + c->extra_substeps < 1 || c->decimation + c->extra_substeps > 1000)
+    return fail(OIS_EINVAL, "decimation + extra_substeps out of range");
+  if (!(c->sim_dt > 0.0f) || !(c->policy_dt > 0.0f)) return fail(OIS_EINVAL, "time steps must be positive");
+  if (!(c->body_mass > 0.0f) || !(c->wheel_spin_inertia > 0.0f) || !(c->body_inertia[0] > 0.0f) ||
+      !(c->body_inertia[1] > 0.0f) || !(c->body_inertia[2] > 0.0f) || !(c->wheel_radius > 0.0f))
+    return fail(OIS_EINVAL, "mass / inertia / radius must be positive");
+  if (c->mix_mode != OIS_MIX_SWITCH && c->mix_mode != OIS_MIX_BLEND) return fail(OIS_EINVAL, "bad mix_mode");
+  if (c->cmd_sampler == OIS_CMD_GRID) return fail(OIS_EINVAL, "cmd_sampler GRID (KAMMA_curr2) is not implemented yet");
+  if (c->cmd_sampler < 0 || c->cmd_sampler > OIS_CMD_EVAL) return fail(OIS_EINVAL, "bad cmd_sampler");
+  if (!(c->max_sim_steps > 0.0f)) return fail(OIS_EINVAL, "max_sim_steps must be positive");
+  return OIS_OK;
+}
+
+// same derivation, same float operations as the oracle's derive() (docs/SPEC.md §3.0)
+void derive(const ois_config* c, DevConsts* K) {
+  std::memset(K, 0, sizeof *K);
+  K->dt = c->sim_dt;
+  K->inv_dt = 1.0f / c->sim_dt;
+  K->gdt = c->gravity * c->sim_dt;
+  K->half_dt = 0.5f * c->sim_dt;
+  K->im4 = 4.0f / c->body_mass;
+  K->J4x = 4.0f / c->body_inertia[0];
+  K->J4y = 4.0f / c->body_inertia[1];
+  K->J4z = 4.0f / c->body_inertia[2];
+  K->dt_over_Is = c->sim_dt / c->wheel_spin_inertia;
+  K->dt_over_Iy = c->sim_dt / c->body_inertia[1];
+  K->rw = c->wheel_radius;
+  K->rw_over_Is = c->wheel_radius / c->wheel_spin_inertia;
+  K->rw2_over_Is = (c->wheel_radius * c->wheel_radius) / c->wheel_spin_inertia;
+  K->beta_inv_dt = c->baumgarte * K->inv_dt;
+  K->vdep = c->max_depenetration_velocity;
+  K->maxw = c->max_angular_velocity;
+  K->maxw2 = c->max_angular_velocity * c->max_angular_velocity;
+  K->damping = c->wheel_damping;
+  K->wx = c->wheel_pos[0];
+  K->wy = c->wheel_pos[1];
+  K->cz = c->wheel_pos[2] - c->com_height;
+  K->com_height = c->com_height;
+  K->iters = c->solver_iterations;
+  K->nsub = c->decimation + c->extra_substeps;
+  K->Kp = c->Kp; K->Kp_omega = c->Kp_omega; K->vehicle_mass = c->vehicle_mass; K->vehicle_inertia = c->vehicle_inertia;
+  K->policy_dt = c->policy_dt; K->action_scale = c->action_scale; K->torque_clip = c->torque_clip;
+  K->w1 = c->w1; K->w2 = c->w2; K->w3 = c->w3; K->sparse_bonus = c->sparse_bonus; K->sparse_threshold = c->sparse_threshold;
+  K->terminal_reward = c->terminal_reward; K->max_sim_steps = c->max_sim_steps;
+  K->gamma1_const = c->gamma1_const; K->gamma2_const = c->gamma2_const; K->bounds = c->bounds; K->clip_obs = c->clip_obs;
+  K->episode_length_s = c->episode_length_s; K->eval_ramp_steps = c->eval_ramp_steps;
+  K->cmd_x_lo = c->cmd_x_lo; K->cmd_x_hi = c->cmd_x_hi; K->cmd_y_lo = c->cmd_y_lo; K->cmd_y_hi = c->cmd_y_hi;
+  K->cmd_yaw_lo = c->cmd_yaw_lo; K->cmd_yaw_hi = c->cmd_yaw_hi; K->spawn_xy_range = c->spawn_xy_range;
+  for (int k = 0; k < 3; ++k) { K->init_pos[k] = c->init_pos[k]; K->init_lin_vel[k] = c->init_lin_vel[k]; K->init_ang_vel[k] = c->init_ang_vel[k]; }
+  for (int k = 0; k < 4; ++k) { K->init_quat[k] = c->init_quat[k]; K->init_dof_vel[k] = c->init_dof_vel[k]; }
+  K->action_dim = c->action_dim; K->mix_mode = c->mix_mode; K->gamma1_mode = c->gamma1_mode; K->gamma2_mode = c->gamma2_mode;
+  K->guiding_mode = c->guiding_mode; K->cmd_sampler = c->cmd_sampler; K->eval_sums = c->eval_sums;
+  K->max_episode_length = c->max_episode_length;
+  K->seed_lo = (uint32_t)(c->seed & 0xffffffffu);
+  K->seed_hi = (uint32_t)(c->seed >> 32);
+  K->arena_offset = c->arena_offset;
+}
+
+}  // namespace
+
+struct ois_env {
+  ois_config cfg;
+  DevConsts K;
+  DevBuffers B;
+  Layout L;
+  char* ws;
+  int N, device, grid;
+  uint64_t seed;  // seed of the last ois_reset (RNG key of the episode stream)
+  bool reset_done;
+  double steps_done;
+};
+
+extern "C" {
+
+int ois_abi_version(void) { return OIS_ABI_VERSION; }
+const char* ois_last_error(void) { return g_err; }
+
+int ois_config_default(ois_config* c) {
+  if (!c) return fail(OIS_EINVAL, "null config");
+  std::memset(c, 0, sizeof *c);
+  c->struct_bytes = sizeof(ois_config);
+  c->num_envs = 1;  // every reference script forces numEnvs = 1 (train_kamma_4d_nofifo_random_RLIL.py:79)
+  c->arena_offset = 0;
+  c->seed = 42;  // KAMMA.py:35
+  c->action_dim = 4; c->mix_mode = OIS_MIX_SWITCH;
+  c->gamma1_mode = c->gamma2_mode = OIS_GAMMA_SCHEDULE;
+  c->gamma1_const = c->gamma2_const = 1.0f;
+  c->guiding_mode = OIS_GUIDE_EXECUTED; c->cmd_sampler = OIS_CMD_RAND;
+  c->max_sim_steps = 500000.0f;  // KAMMA_medium.py:179
+  c->eval_sums = 0;
+  c->sim_dt = 0.01f; c->decimation = 10; c->extra_substeps = 10;
+  c->policy_dt = (float)(10 * 0.01);
+  c->max_episode_length = (int)(10.0 / (10 * 0.01) + 0.5);
+  c->episode_length_s = 10.0f;
+  c->Kp = 0.035f;  // train_kamma_4d_nofifo_random_RLIL.py:63 (--stiffness)
+  c->Kp_omega = 0.665f; c->vehicle_mass = 25.0f; c->vehicle_inertia = 1.05f;
+  c->action_scale = 3.0f; c->torque_clip = 4.0f;
+  c->w1 = -25.0f; c->w2 = -0.02f; c->w3 = -0.09f; c->sparse_bonus = 0.2f; c->sparse_threshold = 0.01f;
+  c->terminal_reward = 0.0f;
+  c->cmd_x_lo = 1.0f; c->cmd_x_hi = 2.0f;  // --linear_x [1,2]
+  c->cmd_y_lo = -0.5f; c->cmd_y_hi = 0.5f; c->cmd_yaw_lo = 1.0f; c->cmd_yaw_hi = 1.1f;
+  c->init_pos[0] = 0.0f; c->init_pos[1] = 0.0f; c->init_pos[2] = 0.1f;
+  c->init_quat[0] = 1.0f;
+  c->spawn_xy_range = 0.5f; c->bounds = 50.0f; c->clip_obs = 1000.0f; c->eval_ramp_steps = 50000.0f;
+  // composite body of src/my_assets/urdf/origin_sym.urdf (see options_in_simulation_amd/config.py)
+  const double mc = 21.0, mw = 1.0, wx = 0.205, wy = 0.25, wz = 0.056, iw = 0.01;
+  const double m = mc + 4.0 * mw, com = 4.0 * mw * wz / m, dz = wz - com;
+  c->gravity = 9.81f;
+  c->body_mass = (float)m;
+  c->body_inertia[0] = (float)(0.4 + mc * com * com + 4.0 * (mw * (wy * wy + dz * dz) + iw));
+  c->body_inertia[1] = (float)(0.77 + mc * com * com + 4.0 * (mw * (wx * wx + dz * dz)));
+  c->body_inertia[2] = (float)(1.01 + 4.0 * (mw * (wx * wx + wy * wy) + iw));
+  c->com_height = (float)com;
+  c->wheel_pos[0] = (float)wx; c->wheel_pos[1] = (float)wy; c->wheel_pos[2] = (float)wz;
+  c->wheel_radius = 0.1175f; c->wheel_spin_inertia = 0.01f;
+  c->wheel_damping = 0.125f;  // calibrated, not parity
+  c->friction = 0.85f; c->baumgarte = 0.2f; c->max_depenetration_velocity = 100.0f;
+  c->max_angular_velocity = 64.0f; c->solver_iterations = 4;
+  return OIS_OK;
+}
+
+size_t ois_workspace_bytes(const ois_config* cfg) {
+  if (validate(cfg) != OIS_OK) return 0;
+  return make_layout(cfg->num_envs).total;
+}
+
+int ois_create(const ois_config* cfg, int device, void* workspace_device, size_t workspace_bytes, ois_env** out) {
+  if (!out) return fail(OIS_EINVAL, "null out pointer");
+  *out = nullptr;
+  int rc = validate(cfg);
+  if (rc != OIS_OK) return rc;
+  if (!workspace_device) return fail(OIS_EINVAL, "null workspace");
+  if (((uintptr_t)workspace_device & 255u) != 0) return fail(OIS_EINVAL, "workspace must be 256-byte aligned");
+  Layout L = make_layout(cfg->num_envs);
+  if (workspace_bytes < L.total) return fail(OIS_ENOMEM, "workspace smaller than ois_workspace_bytes()");
+  int ndev = 0;
+  HIP_TRY(hipGetDeviceCount(&ndev));
+  if (device < 0 || device >= ndev) return fail(OIS_EINVAL, "device ordinal out of range");
+  HIP_TRY(hipSetDevice(device));
+  ois_env* e = new (std::nothrow) ois_env;
+  if (!e) return fail(OIS_ENOMEM, "host allocation failed");
+  e->cfg = *cfg;
+  derive(cfg, &e->K);
+  e->L = L;
+  e->ws = (char*)workspace_device;
+  e->N = cfg->num_envs;
+  e->device = device;
+  e->grid = (e->N * 4 + kBlock - 1) / kBlock;
+  e->seed = cfg->seed;
+  e->reset_done = false;
+  e->steps_done = 0.0;
+  char* w = e->ws;
+  DevBuffers& B = e->B;
+  B.pose = (float*)(w + L.off[OIS_BUF_POSE]); B.quat = (float*)(w + L.off[OIS_BUF_QUAT]);
+  B.linvel = (float*)(w + L.off[OIS_BUF_LINVEL]); B.angvel = (float*)(w + L.off[OIS_BUF_ANGVEL]);
+  B.wheel_vel = (float*)(w + L.off[OIS_BUF_WHEEL_VEL]); B.commands = (float*)(w + L.off[OIS_BUF_COMMANDS]);
+  B.counters = (int32_t*)(w + L.off[OIS_BUF_COUNTERS]);
+  B.sums_a = (float*)(w + L.off[OIS_BUF_SUMS_A]); B.sums_b = (float*)(w + L.off[OIS_BUF_SUMS_B]);
+  B.sums_c = (float*)(w + L.off[OIS_BUF_SUMS_C]); B.params = (float*)(w + L.off[OIS_BUF_PARAMS]);
+  B.lam_n = (float*)(w + L.off[OIS_BUF_LAMBDA_N]); B.lam_l = (float*)(w + L.off[OIS_BUF_LAMBDA_L]);
+  B.lam_t = (float*)(w + L.off[OIS_BUF_LAMBDA_T]); B.wheel_torqs = (float*)(w + L.off[OIS_BUF_WHEEL_TORQS]);
+  B.obs = (float*)(w + L.off[OIS_BUF_OBS]); B.rew = (float*)(w + L.off[OIS_BUF_REW]);
+  B.done = (uint8_t*)(w + L.off[OIS_BUF_DONE]); B.timeout = (uint8_t*)(w + L.off[OIS_BUF_TIMEOUT]);
+  B.episode_info = (float*)(w + L.off[OIS_BUF_EPISODE_INFO]); B.env0_diag = (float*)(w + L.off[OIS_BUF_ENV0_DIAG]);
+  B.partials = (float*)(w + L.partials); B.stamps = (int32_t*)(w + L.stamps); B.stat_acc = (float*)(w + L.stat_acc);
+  // default per-arena parameters: mu = cfg.friction, flat plane n = +z
+  hipError_t he = hipMemsetAsync(e->ws, 0, L.total, nullptr);
+  if (he == hipSuccess) {
+    hipLaunchKernelGGL(init_params_kernel, dim3((e->N * 4 + 255) / 256), dim3(256), 0, nullptr, e->B, e->N, cfg->friction);
+    he = hipGetLastError();
+  }
+  if (he == hipSuccess) he = hipStreamSynchronize(nullptr);
+  if (he != hipSuccess) {
+    snprintf(g_err, sizeof g_err, "workspace initialisation failed: %s", hipGetErrorString(he));
+    delete e;
+    return OIS_EHIP;
+  }
+  *out = e;
+  return OIS_OK;
+}
+
+void ois_destroy(ois_env* env) { delete env; }
+
+int ois_reset(ois_env* e, uint64_t seed, void* stream) {
+  if (!e) return fail(OIS_EINVAL, "null env");
+  HIP_TRY(hipSetDevice(e->device));
+  e->seed = seed;
+  e->K.seed_lo = (uint32_t)(seed & 0xffffffffu);
+  e->K.seed_hi = (uint32_t)(seed >> 32);
+  hipLaunchKernelGGL(reset_kernel, dim3(e->grid), dim3(kBlock), 0, (hipStream_t)stream, e->K, e->B, e->N);
+  HIP_TRY(hipGetLastError());
+  e->reset_done = true;
+  e->steps_done = 0.0;
+  return OIS_OK;
+}
+
+static int launch_steps(ois_env* e, int k, int policy, const float* actions, float* reward_sum, void* stream) {
+  HIP_TRY(hipSetDevice(e->device));
+  hipLaunchKernelGGL(step_kernel, dim3(e->grid), dim3(kBlock), 0, (hipStream_t)stream, e->K, e->B, actions, reward_sum,
+                     e->N, k, policy);
+  HIP_TRY(hipGetLastError());
+  e->steps_done += (double)e->N * (double)k;
+  return OIS_OK;
+}
+
+int ois_step(ois_env* e, const float* actions_device, void* stream) {
+  if (!e) return fail(OIS_EINVAL, "null env");
+  if (!actions_device) return fail(OIS_EINVAL, "null actions");
+  if (!e->reset_done) return fail(OIS_ESTATE, "ois_step called before ois_reset");
+  return launch_steps(e, 1, OIS_POLICY_EXTERNAL, actions_device, nullptr, stream);
+}
+
+int ois_rollout(ois_env* e, int k, int policy, const float* actions_device, float* reward_sum_device, void* stream) {
+  if (!e) return fail(OIS_EINVAL, "null env");
+  if (k < 1 || k > (1 << 20)) return fail(OIS_EINVAL, "k out of range");
+  if (policy < OIS_POLICY_ZERO || policy > OIS_POLICY_EXTERNAL) return fail(OIS_EINVAL, "unknown policy");
+  if (policy == OIS_POLICY_EXTERNAL && !actions_device) return fail(OIS_EINVAL, "EXTERNAL policy needs actions");
+  if (!e->reset_done) return fail(OIS_ESTATE, "ois_rollout called before ois_reset");
+  return launch_steps(e, k, policy, actions_device, reward_sum_device, stream);
+}
+
+int ois_buffer(ois_env* e, int id, void** ptr_device, size_t* bytes) {
+  if (!e || !ptr_device || !bytes) return fail(OIS_EINVAL, "null argument");
+  if (id < 0 || id >= OIS_BUF_COUNT_) return fail(OIS_EINVAL, "unknown buffer id");
+  *ptr_device = e->ws + e->L.off[id];
+  *bytes = e->L.bytes[id];
+  return OIS_OK;
+}
+
+int ois_randomize_params(ois_env* e, float mu_lo, float mu_hi, const float* slopes_host, int n_slopes, void* stream) {
+  if (!e) return fail(OIS_EINVAL, "null env");
+  if (n_slopes < 0 || n_slopes > 16 || (n_slopes > 0 && !slopes_host)) return fail(OIS_EINVAL, "bad slopes (0..16 values)");
+  HIP_TRY(hipSetDevice(e->device));
+  float* tbl = (float*)(e->ws + e->L.stat_out);  // scratch shared with ois_stats_fetch
+  if (n_slopes > 0) HIP_TRY(hipMemcpyAsync(tbl, slopes_host, (size_t)n_slopes * sizeof(float), hipMemcpyHostToDevice, (hipStream_t)stream));
+  DevConsts K = e->K;  // keyed by the CONFIG seed: arena parameters do not change with ois_reset(seed)
+  K.seed_lo = (uint32_t)(e->cfg.seed & 0xffffffffu);
+  K.seed_hi = (uint32_t)(e->cfg.seed >> 32);
+  hipLaunchKernelGGL(randomize_params_kernel, dim3((e->N + 255) / 256), dim3(256), 0, (hipStream_t)stream, K, e->B, e->N,
+                     mu_lo, mu_hi, tbl, n_slopes);
+  HIP_TRY(hipGetLastError());
+  if (n_slopes > 0) HIP_TRY(hipStreamSynchronize((hipStream_t)stream));  // slopes_host may be freed by the caller
+  return OIS_OK;
+}
+
+int ois_episode_info(ois_env* e, void* stream) {
+  if (!e) return fail(OIS_EINVAL, "null env");
+  if (!e->reset_done) return fail(OIS_ESTATE, "ois_episode_info called before ois_reset");
+  HIP_TRY(hipSetDevice(e->device));
+  hipLaunchKernelGGL(episode_info_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, e->K, e->B, e->L.nwaves);
+  HIP_TRY(hipGetLastError());
+  return OIS_OK;
+}
+
+int ois_stats_fetch(ois_env* e, ois_stats* out, int reset_after, void* stream) {
+  if (!e || !out) return fail(OIS_EINVAL, "null argument");
+  if (!e->reset_done) return fail(OIS_ESTATE, "ois_stats_fetch called before ois_reset");
+  HIP_TRY(hipSetDevice(e->device));
+  float* d = (float*)(e->ws + e->L.stat_out);
+  hipLaunchKernelGGL(stats_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, e->B, e->L.nwaves, d, reset_after);
+  HIP_TRY(hipGetLastError());
+  float h[8];
+  HIP_TRY(hipMemcpyAsync(h, d, sizeof h, hipMemcpyDeviceToHost, (hipStream_t)stream));
+  HIP_TRY(hipStreamSynchronize((hipStream_t)stream));
+  out->episodes = h[0]; out->return_sqsum = h[1]; out->length_sum = h[2]; out->return_sum = h[3];
+  out->return_min = -(double)h[6]; out->return_max = h[7];
+  out->steps = e->steps_done; out->reserved = 0.0;
+  if (reset_after) e->steps_done = 0.0;
+  return OIS_OK;
+}
+
+int ois_env0_diag(ois_env* e, float* host_out, void* stream) {
+  if (!e || !host_out) return fail(OIS_EINVAL, "null argument");
+  HIP_TRY(hipSetDevice(e->device));
+  HIP_TRY(hipMemcpyAsync(host_out, e->B.env0_diag, OIS_ENV0_DIAG_LEN * sizeof(float), hipMemcpyDeviceToHost, (hipStream_t)stream));
+  HIP_TRY(hipStreamSynchronize((hipStream_t)stream));
+  return OIS_OK;
+}
+
+struct StateHeader {
+  uint32_t magic, abi;
+  int32_t num_envs;
+  int32_t reset_done;
+  uint64_t seed;
+  double steps_done;
+  uint64_t payload;
+};
+
+size_t ois_state_bytes(const ois_env* e) { return e ? sizeof(StateHeader) + e->L.total : 0; }
+
+int ois_save_state(ois_env* e, void* host_blob, size_t bytes, void* stream) {
+  if (!e || !host_blob) return fail(OIS_EINVAL, "null argument");
+  if (bytes < ois_state_bytes(e)) return fail(OIS_ENOMEM, "blob smaller than ois_state_bytes()");
+  HIP_TRY(hipSetDevice(e->device));
+  StateHeader h = {0x3053494fu /* "OIS0" */, OIS_ABI_VERSION, e->N, e->reset_done ? 1 : 0, e->seed, e->steps_done, e->L.total};
+  std::memcpy(host_blob, &h, sizeof h);
+  HIP_TRY(hipMemcpyAsync((char*)host_blob + sizeof h, e->ws, e->L.total, hipMemcpyDeviceToHost, (hipStream_t)stream));
+  HIP_TRY(hipStreamSynchronize((hipStream_t)stream));
+  return OIS_OK;
+}
+
+int ois_load_state(ois_env* e, const void* host_blob, size_t bytes, void* stream) {
+  if (!e || !host_blob) return fail(OIS_EINVAL, "null argument");
+  if (bytes < sizeof(StateHeader)) return fail(OIS_EINVAL, "blob too small");
+  StateHeader h;
+  std::memcpy(&h, host_blob, sizeof h);
+  if (h.magic != 0x3053494fu || h.abi != OIS_ABI_VERSION) return fail(OIS_EINVAL, "not an ois state blob of this ABI");
+  if (h.num_envs != e->N || h.payload != e->L.total || bytes < sizeof h + h.payload) return fail(OIS_EINVAL, "state blob does not match this environment");
+  HIP_TRY(hipSetDevice(e->device));
+  HIP_TRY(hipMemcpyAsync(e->ws, (const char*)host_blob + sizeof h, e->L.total, hipMemcpyHostToDevice, (hipStream_t)stream));
+  HIP_TRY(hipStreamSynchronize((hipStream_t)stream));
+  e->reset_done = h.reset_done != 0;
+  e->seed = h.seed;
+  e->K.seed_lo = (uint32_t)(h.seed & 0xffffffffu);
+  e->K.seed_hi = (uint32_t)(h.seed >> 32);
+  e->steps_done = h.steps_done;
+  return OIS_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,401 @@
+"""Host-side mirror of the reference's environment interface for the skid-steer hot path.
+
+Three layers, bottom up:
+
+* :class:`NativeEnv` — thin owner of one ``ois_env`` handle (C ABI, include/ois.h): a torch
+  uint8 workspace on the GPU, typed zero-copy tensor views of every buffer, and one method
+  per entry point. PyTorch is used for device memory and streams only.
+* :class:`TorqueDistributionTask` — the attributes trainers reach for *through* the wrapper
+  (``env.task.observed_components / wheel_torqs / action_scale``: src/my_trainers/
+  base_KA_DDPG.py:184-212) plus the task tensors of KAMMA.py (``commands``, ``base_pos`` ...).
+  Constructor signature as the reference's: ``(name, sim_config, env, offset=None)``
+  (KAMMA.py:149).
+* :class:`VecEnv` — what ``wrap_env(env, "omniverse-isaacgym")`` hands the trainer
+  (skrl, third-party): ``reset() -> (obs, info)``, ``step(a) -> (obs, rew[N,1],
+  terminated[N,1], truncated[N,1], info)``, ``num_envs``, ``num_agents``, ``device``,
+  ``observation_space``, ``action_space``, ``render()``, ``close()``
+  (call sites base_KA_DDPG.py:167-182, 216, 75; train_kamma_4d_nofifo_random_RLIL.py:101-130).
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Any, Dict, Optional, Tuple
+
+import numpy as np
+import torch
+
+from . import _abi, _native
+from .config import VARIANTS, build_config, default_task_cfg
+from .spaces import Box
+
+_DTYPES = {
+    _abi.BUF_OBS: (torch.float32, 6), _abi.BUF_REW: (torch.float32, None), _abi.BUF_DONE: (torch.bool, None),
+    _abi.BUF_TIMEOUT: (torch.bool, None), _abi.BUF_WHEEL_TORQS: (torch.float32, 4),
+    _abi.BUF_POSE: (torch.float32, 4), _abi.BUF_QUAT: (torch.float32, 4), _abi.BUF_LINVEL: (torch.float32, 4),
+    _abi.BUF_ANGVEL: (torch.float32, 4), _abi.BUF_WHEEL_VEL: (torch.float32, 4),
+    _abi.BUF_COMMANDS: (torch.float32, 4), _abi.BUF_COUNTERS: (torch.int32, 4),
+    _abi.BUF_SUMS_A: (torch.float32, 4), _abi.BUF_SUMS_B: (torch.float32, 4), _abi.BUF_SUMS_C: (torch.float32, 4),
+    _abi.BUF_PARAMS: (torch.float32, 4), _abi.BUF_EPISODE_INFO: (torch.float32, None),
+    _abi.BUF_ENV0_DIAG: (torch.float32, None), _abi.BUF_LAMBDA_N: (torch.float32, 4),
+    _abi.BUF_LAMBDA_L: (torch.float32, 4), _abi.BUF_LAMBDA_T: (torch.float32, 4),
+}
+
+
+def _stream_ptr(device: torch.device) -> int:
+    return torch.cuda.current_stream(device).cuda_stream
+
+
+class NativeEnv:
+    """One ``ois_env``: N arenas resident on one GPU."""
+
+    def __init__(self, cfg: _abi.OisConfig, device: "torch.device | str | int" = "cuda:0"):
+        self.L = _native.load()  # raises NativeLibraryError if the HIP library is missing
+        if not torch.cuda.is_available():
+            raise RuntimeError("options_in_simulation_amd needs a ROCm GPU (torch.cuda.is_available() is False); "
+                               "there is no CPU fallback")
+        self.device = torch.device(device if not isinstance(device, int) else f"cuda:{device}")
+        if self.device.type != "cuda":
+            raise ValueError(f"device must be a cuda (ROCm) device, got {self.device}")
+        self.cfg = cfg
+        self.N, self.A = int(cfg.num_envs), int(cfg.action_dim)
+        nbytes = self.L.ois_workspace_bytes(C.byref(cfg))
+        if nbytes == 0:
+            raise ValueError(f"invalid ois_config: {self.L.ois_last_error().decode()}")
+        index = self.device.index if self.device.index is not None else torch.cuda.current_device()
+        self.device = torch.device("cuda", index)
+        self.workspace = torch.empty(nbytes, dtype=torch.uint8, device=self.device)
+        assert self.workspace.data_ptr() % 256 == 0
+        torch.cuda.synchronize(self.device)
+        h = C.c_void_p()
+        _native.check(self.L.ois_create(C.byref(cfg), index, C.c_void_p(self.workspace.data_ptr()), nbytes, C.byref(h)))
+        self.h = h
+        self._views: Dict[int, torch.Tensor] = {}
+        base = self.workspace.data_ptr()
+        for bid, (dt, cols) in _DTYPES.items():
+            p, n = C.c_void_p(), C.c_size_t()
+            _native.check(self.L.ois_buffer(self.h, bid, C.byref(p), C.byref(n)))
+            raw = self.workspace[p.value - base: p.value - base + n.value]
+            t = raw.view(dt)
+            self._views[bid] = t.view(-1, cols) if cols else t
+        self.policy_steps = 0
+
+    # ---- lifetime ----
+    def close(self):
+        if getattr(self, "h", None):
+            torch.cuda.synchronize(self.device)
+            self.L.ois_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:  # noqa: BLE001
+            pass
+
+    # ---- buffers ----
+    def buffer(self, bid: int) -> torch.Tensor:
+        """zero-copy tensor view of a library buffer (ids: _abi.BUF_*)."""
+        return self._views[bid]
+
+    # ---- entry points ----
+    def reset(self, seed: Optional[int] = None):
+        seed = int(self.cfg.seed if seed is None else seed) & 0xFFFFFFFFFFFFFFFF
+        _native.check(self.L.ois_reset(self.h, seed, _stream_ptr(self.device)))
+        self.policy_steps = 0
+
+    def _check_actions(self, actions: torch.Tensor, k: Optional[int] = None) -> torch.Tensor:
+        shape = (self.N, self.A) if k is None else (k, self.N, self.A)
+        if not isinstance(actions, torch.Tensor):
+            raise TypeError("actions must be a torch.Tensor")
+        if actions.device != self.device:
+            actions = actions.to(self.device)
+        if actions.dtype != torch.float32:
+            actions = actions.float()
+        if tuple(actions.shape) != shape:
+            if actions.numel() != int(np.prod(shape)):
+                raise ValueError(f"actions must have shape {shape}, got {tuple(actions.shape)}")
+            actions = actions.reshape(shape)
+        return actions.contiguous()
+
+    def step(self, actions: torch.Tensor):
+        a = self._check_actions(actions)
+        _native.check(self.L.ois_step(self.h, C.c_void_p(a.data_ptr()), _stream_ptr(self.device)))
+        self.policy_steps += 1
+        self._last_actions = a  # keep alive until the stream has consumed it
+
+    def rollout(self, k: int, policy: int, actions: Optional[torch.Tensor] = None,
+                reward_sum: Optional[torch.Tensor] = None):
+        a_ptr = None
+        if policy == _abi.POLICY_EXTERNAL:
+            if actions is None:
+                raise ValueError("POLICY_EXTERNAL needs actions [k, N, A]")
+            a = self._check_actions(actions, k)
+            self._last_actions = a
+            a_ptr = C.c_void_p(a.data_ptr())
+        r_ptr = None
+        if reward_sum is not None:
+            if reward_sum.dtype != torch.float32 or reward_sum.numel() != self.N or reward_sum.device != self.device \
+                    or not reward_sum.is_contiguous():
+                raise ValueError("reward_sum must be a contiguous float32 [N] tensor on the env device")
+            r_ptr = C.c_void_p(reward_sum.data_ptr())
+        _native.check(self.L.ois_rollout(self.h, int(k), int(policy), a_ptr, r_ptr, _stream_ptr(self.device)))
+        self.policy_steps += int(k)
+
+    def randomize_params(self, mu_lo: float, mu_hi: float, slopes=()):
+        s = np.ascontiguousarray(slopes, dtype=np.float32)
+        ptr = s.ctypes.data_as(C.POINTER(C.c_float)) if s.size else None
+        _native.check(self.L.ois_randomize_params(self.h, mu_lo, mu_hi, ptr, int(s.size), _stream_ptr(self.device)))
+
+    def episode_info(self) -> torch.Tensor:
+        """launch the finalisation kernel; returns the device vector (no host sync)."""
+        _native.check(self.L.ois_episode_info(self.h, _stream_ptr(self.device)))
+        return self._views[_abi.BUF_EPISODE_INFO]
+
+    def stats(self, reset_after: bool = False) -> _abi.OisStats:
+        st = _abi.OisStats()
+        _native.check(self.L.ois_stats_fetch(self.h, C.byref(st), int(reset_after), _stream_ptr(self.device)))
+        return st
+
+    def env0_diag(self) -> np.ndarray:
+        out = np.zeros(_abi.ENV0_DIAG_LEN, np.float32)
+        _native.check(self.L.ois_env0_diag(self.h, out.ctypes.data_as(C.POINTER(C.c_float)), _stream_ptr(self.device)))
+        return out
+
+    def save_state(self) -> bytes:
+        n = self.L.ois_state_bytes(self.h)
+        buf = (C.c_uint8 * n)()
+        _native.check(self.L.ois_save_state(self.h, C.cast(buf, C.c_void_p), n, _stream_ptr(self.device)))
+        return bytes(buf)
+
+    def load_state(self, blob: bytes):
+        buf = (C.c_uint8 * len(blob)).from_buffer_copy(blob)
+        _native.check(self.L.ois_load_state(self.h, C.cast(buf, C.c_void_p), len(blob), _stream_ptr(self.device)))
+
+
+class _LazyEpisodeInfo(dict):
+    """``extras["episode"]`` (KAMMA.py:480-488): a dict of 0-dim tensors, produced on first
+    access so that a step costs no extra launch when nobody looks."""
+
+    def __init__(self, native: NativeEnv, eval_keys: bool):
+        super().__init__()
+        self._native, self._eval, self._done = native, eval_keys, False
+
+    def _materialize(self):
+        if self._done:
+            return
+        self._done = True
+        vec = self._native.episode_info().clone()
+        for slot, key in _abi.EPISODE_INFO_KEYS.items():
+            dict.__setitem__(self, key, vec[slot])
+        for key in _abi.EPISODE_INFO_ZERO_KEYS:
+            dict.__setitem__(self, key, vec[31])  # never written by the reference: 0
+        if self._eval:
+            for slot, key in _abi.EPISODE_INFO_EVAL_KEYS.items():
+                dict.__setitem__(self, key, vec[slot])
+
+    def __getitem__(self, k): self._materialize(); return dict.__getitem__(self, k)
+    def __iter__(self): self._materialize(); return dict.__iter__(self)
+    def __len__(self): self._materialize(); return dict.__len__(self)
+    def __contains__(self, k): self._materialize(); return dict.__contains__(self, k)
+    def keys(self): self._materialize(); return dict.keys(self)
+    def values(self): self._materialize(); return dict.values(self)
+    def items(self): self._materialize(); return dict.items(self)
+    def get(self, k, d=None): self._materialize(); return dict.get(self, k, d)
+    def __repr__(self): self._materialize(); return dict.__repr__(self)
+
+
+class _SimConfigLike:
+    """stand-in for OmniIsaacGymEnvs' SimConfig: exposes .config / .task_config (KAMMA.py:231-234)"""
+
+    def __init__(self, config: Dict[str, Any]):
+        self.config = config
+        self.task_config = config["task"] if "task" in config else config
+
+
+class TorqueDistributionTask:
+    """The task object trainers reach through ``env.task`` (KAMMA.py:148)."""
+
+    def __init__(self, name: str = "TorqueDistributionTask", sim_config: Any = None, env: Any = None,
+                 offset=None, *, variant: str = "KAMMA_medium", device: "torch.device | str" = "cuda:0",
+                 num_envs: Optional[int] = None, arena_offset: int = 0, seed: Optional[int] = None,
+                 **config_overrides):
+        if sim_config is None:
+            sim_config = _SimConfigLike(default_task_cfg())
+        elif isinstance(sim_config, dict):
+            sim_config = _SimConfigLike(sim_config)
+        self.name = name
+        self.variant = variant
+        self._sim_config = sim_config
+        self._cfg = sim_config.config                # KAMMA.py:233
+        self._task_cfg = sim_config.task_config      # KAMMA.py:234
+        self.cfg_native = build_config(self._cfg, variant=variant, num_envs=num_envs, arena_offset=arena_offset,
+                                       seed=seed, **config_overrides)
+        self.native = NativeEnv(self.cfg_native, device)
+        self.device = self.native.device
+        self.rl_device = self.device
+        c = self.cfg_native
+        self._num_envs = c.num_envs
+        self._num_observations = 6                   # KAMMA.py:156
+        self._num_actions = c.action_dim             # KAMMA.py:157; KA_DDPG_2D.py:157; KA_DDPG_1D.py:157
+        self.observation_space = Box(-1.0, 1.0, (self._num_observations,), np.float32)    # KAMMA.py:158-163
+        self.action_space = Box(VARIANTS[variant]["action_low"], 1.0, (self._num_actions,), np.float32)  # :164-169
+        self.action_scale = float(c.action_scale)    # KAMMA.py:238
+        self.vehicle_mass, self.vehicle_inertia = float(c.vehicle_mass), float(c.vehicle_inertia)
+        self.max_sim_steps = float(c.max_sim_steps)
+        self.dt = float(c.policy_dt)
+        self.max_episode_length = int(c.max_episode_length)
+        self.max_episode_length_s = float(c.episode_length_s)
+        self.Kp = float(c.Kp)
+        self.clip_obs = float(c.clip_obs)
+        self.extras: Dict[str, Any] = {}
+        self._diag_step = -1
+        self._diag_cache: Dict[str, float] = {}
+        n = self.native
+        # tensors of the task (views of the library's buffers; rl_task.py:145-154, KAMMA.py:378-410)
+        self.obs_buf = n.buffer(_abi.BUF_OBS)
+        self.rew_buf = n.buffer(_abi.BUF_REW)
+        self.reset_buf = n.buffer(_abi.BUF_DONE)
+        self.timeout_buf = n.buffer(_abi.BUF_TIMEOUT)
+        self.wheel_torqs = n.buffer(_abi.BUF_WHEEL_TORQS)
+        self.commands = n.buffer(_abi.BUF_COMMANDS)
+        self.base_quat = n.buffer(_abi.BUF_QUAT)
+        self.dof_vel = n.buffer(_abi.BUF_WHEEL_VEL)
+        self._pose, self._linvel, self._angvel = n.buffer(_abi.BUF_POSE), n.buffer(_abi.BUF_LINVEL), n.buffer(_abi.BUF_ANGVEL)
+        self._counters = n.buffer(_abi.BUF_COUNTERS)
+
+    # ---- sizes ----
+    @property
+    def num_envs(self): return self._num_envs
+    @property
+    def num_observations(self): return self._num_observations
+    @property
+    def num_actions(self): return self._num_actions
+
+    # ---- state tensors (KAMMA.py:587-593) ----
+    @property
+    def base_pos(self) -> torch.Tensor:
+        """COM position (the base-link origin is com_height below it along body z)."""
+        return self._pose[:, :3]
+    @property
+    def v_forward_projected(self): return self._pose[:, 3]
+    @property
+    def base_velocities(self) -> torch.Tensor:
+        return torch.cat([self._linvel[:, :3], self._angvel[:, :3]], dim=1)
+    @property
+    def previous_linear_velocity(self): return self._linvel[:, 3]
+    @property
+    def previous_angular_velocity(self): return self._angvel[:, 3]
+    @property
+    def episode_buf(self): return self._counters[:, 0]
+    @property
+    def progress_buf(self): return self._counters[:, 0]
+    @property
+    def sim_steps(self): return self._counters[:, 1]
+    @property
+    def episode_count(self): return self._counters[:, 2]
+    @property
+    def episode_sums(self) -> Dict[str, torch.Tensor]:
+        a, b = self.native.buffer(_abi.BUF_SUMS_A), self.native.buffer(_abi.BUF_SUMS_B)
+        names = ["r1: Tracking error reward (squared errors)", "r2: Convergence reward (squared accelerations)",
+                 "r3: Torque penalty (sum of squared torques)", "Dense reward", "Sparse reward", "Guiding reward",
+                 "Observed reward", "Final reward"]
+        cols = [a[:, 0], a[:, 1], a[:, 2], a[:, 3], b[:, 0], b[:, 1], b[:, 2], b[:, 3]]
+        return dict(zip(names, cols))
+
+    # ---- env-0 diagnostics (KAMMA.py:840-867), read lazily: one 128-byte D2H copy per step ----
+    @property
+    def observed_components(self) -> Dict[str, float]:
+        if self._diag_step != self.native.policy_steps:
+            d = self.native.env0_diag().astype(np.float64)
+            g2, rew = d[19], d[27]
+
+            def perc(x, scale):
+                with np.errstate(divide="ignore", invalid="ignore"):
+                    return float(np.float64(100.0) * scale * x / rew)
+            self._diag_cache = {
+                "env0_desired_v": d[0], "env0_current_v": d[1], "env0_desired_omega": d[2],
+                "env0_current_omega": d[3], "env0_v_delta": d[4], "env0_omega_delta": d[5],
+                "env0_linear_acc": d[6], "env0_angular_acc": d[7], "env0_episode_count": int(d[8]),
+                "env0_torque_apl_fl": d[9], "env0_torque_apl_rl": d[10], "env0_torque_apl_fr": d[11],
+                "env0_torque_apl_rr": d[12], "env0_exp_left": d[13], "env0_exp_right": d[14],
+                "env0_policy_torque_fl": d[15], "env0_policy_torque_rl": d[16],
+                "env0_policy_torque_fr": d[17], "env0_policy_torque_rr": d[18],
+                "env0_perc_r1": perc(d[20], 1 - g2), "env0_perc_r2": perc(d[21], 1 - g2),
+                "env0_perc_r3": perc(d[22], 1 - g2), "env0_perc_dense": perc(d[23], 1 - g2),
+                "env0_perc_sparse": perc(d[24], 1 - g2), "env0_perc_observed": perc(d[25], 1 - g2),
+                "env0_perc_guiding": perc(d[26], g2),
+            }
+            self._diag_cache = {k: (v if isinstance(v, int) else float(v)) for k, v in self._diag_cache.items()}
+            self._diag_step = self.native.policy_steps
+        return self._diag_cache
+
+    # ---- reference call sequence ----
+    def post_reset(self, seed: Optional[int] = None):
+        """KAMMA.py:366-414"""
+        self.native.reset(seed)
+        self.extras = {"episode": _LazyEpisodeInfo(self.native, bool(self.cfg_native.eval_sums))}
+
+    def step(self, actions: torch.Tensor):
+        """pre_physics_step + substeps + post_physics_step (KAMMA.py:596-727) in one launch"""
+        self.native.step(actions)
+        self.extras = {"episode": _LazyEpisodeInfo(self.native, bool(self.cfg_native.eval_sums))}
+        return self.obs_buf, self.rew_buf, self.reset_buf, self.extras
+
+    def close(self):
+        self.native.close()
+
+
+class VecEnv:
+    """Drop-in for ``wrap_env(get_env_instance(...), "omniverse-isaacgym")`` on this path."""
+
+    def __init__(self, task_cfg: Optional[Dict[str, Any]] = None, num_envs: Optional[int] = None,
+                 device: "torch.device | str" = "cuda:0", variant: str = "KAMMA_medium",
+                 seed: Optional[int] = None, arena_offset: int = 0, copy_outputs: bool = True,
+                 task: Optional[TorqueDistributionTask] = None, **config_overrides):
+        if task is None:
+            task = TorqueDistributionTask("TorqueDistributionTask", task_cfg, None, variant=variant, device=device,
+                                          num_envs=num_envs, arena_offset=arena_offset, seed=seed, **config_overrides)
+        self.task = self._task = task
+        self.device = task.device
+        self.num_envs = task.num_envs
+        self.num_agents = 1
+        self.observation_space = task.observation_space
+        self.action_space = task.action_space
+        self.state_space = None
+        self.copy_outputs = copy_outputs
+        self._reset_once = True
+        self._obs: Optional[torch.Tensor] = None
+        self._truncated = torch.zeros((self.num_envs, 1), dtype=torch.bool, device=self.device)
+
+    def set_task(self, task, *_, **__):  # reference call order compatibility (train_*.py:97)
+        self.__init__(task=task, copy_outputs=self.copy_outputs)
+
+    def _out(self, t: torch.Tensor) -> torch.Tensor:
+        return t.clone() if self.copy_outputs else t
+
+    def reset(self, seed: Optional[int] = None) -> Tuple[torch.Tensor, Dict[str, Any]]:
+        """First call: post_reset (reset_idx of every arena) + one zero-action step, as the
+        third-party VecEnv.reset does; later calls return the cached observation (skrl's
+        wrapper only resets once — arenas auto-reset inside step(), KAMMA.py:691-693)."""
+        if self._reset_once or seed is not None:
+            self.task.post_reset(seed)
+            zero = torch.zeros((self.num_envs, self.task.num_actions), dtype=torch.float32, device=self.device)
+            obs, _, _, _ = self.task.step(zero)
+            self._obs = self._out(obs)
+            self._reset_once = False
+        return self._obs, {}
+
+    def step(self, actions: torch.Tensor):
+        if self._reset_once:
+            raise RuntimeError("step() called before reset()")
+        obs, rew, done, extras = self.task.step(actions)
+        self._obs = self._out(obs)
+        terminated = self._out(done).view(-1, 1)
+        truncated = self._truncated if not self.copy_outputs else torch.zeros_like(terminated)
+        return self._obs, self._out(rew).view(-1, 1), terminated, truncated, dict(extras)
+
+    def render(self, *_, **__):
+        return None
+
+    def close(self):
+        self.task.close()

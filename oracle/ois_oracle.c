@@ -1,0 +1,1037 @@
+/*
+ * ois_oracle.c — CPU ORACLE (test infrastructure, NOT product code). See ois_oracle.h for
+ * the parity status. Scalar float32, one arena at a time, operation order fixed by
+ * docs/SPEC.md: every fused multiply-add is an explicit fmaf() and the file is compiled
+ * with -ffp-contract=off, so the HIP kernel (which spells the same fmaf()s) can be
+ * compared bit for bit.
+ *
+ * Reference citations are to /root/reference/src/my_envs/KAMMA.py unless another file is
+ * named.
+ */
+#include "ois_oracle.h"
+
+#include <math.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
+#ifdef _OPENMP
+#include <omp.h>
+#endif
+
+static __thread char g_err[256];
+const char* orc_last_error(void) { return g_err; }
+static int fail(int code, const char* msg) {
+  snprintf(g_err, sizeof g_err, "%s", msg);
+  return code;
+}
+
+/* ------------------------------------------------------------------ RNG -------------- */
+/* Philox4x32-10, Salmon, Moraes, Dror, Shaw: "Parallel random numbers: as easy as 1, 2, 3"
+ * (SC'11); constants as in Random123 philox.h. */
+void orc_philox4x32_10(const uint32_t ctr[4], const uint32_t key[2], uint32_t out[4]) {
+  uint32_t c0 = ctr[0], c1 = ctr[1], c2 = ctr[2], c3 = ctr[3];
+  uint32_t k0 = key[0], k1 = key[1];
+  for (int r = 0; r < 10; ++r) {
+    uint64_t p0 = (uint64_t)0xD2511F53u * c0;
+    uint64_t p1 = (uint64_t)0xCD9E8D57u * c2;
+    uint32_t n0 = (uint32_t)(p1 >> 32) ^ c1 ^ k0;
+    uint32_t n1 = (uint32_t)p1;
+    uint32_t n2 = (uint32_t)(p0 >> 32) ^ c3 ^ k1;
+    uint32_t n3 = (uint32_t)p0;
+    c0 = n0; c1 = n1; c2 = n2; c3 = n3;
+    k0 += 0x9E3779B9u;
+    k1 += 0xBB67AE85u;
+  }
+  out[0] = c0; out[1] = c1; out[2] = c2; out[3] = c3;
+}
+
+/* 24 random bits -> [0,1), exact in float32 */
+float orc_u01(uint32_t x) { return (float)(x >> 8) * 5.9604644775390625e-08f; }
+
+enum { PURPOSE_MASK = 0, PURPOSE_RESET_A = 1, PURPOSE_RESET_B = 2, PURPOSE_ACTION = 3, PURPOSE_PARAMS = 4 };
+
+static void draw4(uint64_t seed, int64_t arena, uint32_t step, uint32_t purpose, float u[4]) {
+  uint32_t ctr[4] = {(uint32_t)((uint64_t)arena & 0xffffffffu), (uint32_t)((uint64_t)arena >> 32), step, purpose};
+  uint32_t key[2] = {(uint32_t)(seed & 0xffffffffu), (uint32_t)(seed >> 32)};
+  uint32_t o[4];
+  orc_philox4x32_10(ctr, key, o);
+  for (int i = 0; i < 4; ++i) u[i] = orc_u01(o[i]);
+}
+
+/* ------------------------------------------------------------------ trig ------------- */
+/* Deterministic sin/cos for x in [0, pi] built from mul/add/fma only (so the GPU can repeat
+ * it bit for bit): Cody-Waite reduction by pi/2, cephes single-precision minimax kernels. */
+void orc_sincos(float x, float* s, float* c) {
+  int k = (int)(x * 0.636619772367581343f + 0.5f);
+  float kf = (float)k;
+  float r = fmaf(-kf, 1.57079637050628662109375f, x);
+  r = fmaf(-kf, -4.37113900018624283e-8f, r);
+  float z = r * r;
+  float ps = fmaf(z, -1.9515295891e-4f, 8.3321608736e-3f);
+  ps = fmaf(z, ps, -1.6666654611e-1f);
+  float sn = fmaf(r * z, ps, r);
+  float pc = fmaf(z, 2.443315711809948e-5f, -1.388731625493765e-3f);
+  pc = fmaf(z, pc, 4.166664568298827e-2f);
+  float cs = fmaf(z * z, pc, fmaf(-0.5f, z, 1.0f));
+  switch (k & 3) {
+    case 0: *s = sn; *c = cs; break;
+    case 1: *s = cs; *c = -sn; break;
+    case 2: *s = -sn; *c = -cs; break;
+    default: *s = -cs; *c = sn; break;
+  }
+}
+
+/* ------------------------------------------------------------------ quaternions ------ */
+/* omni.isaac.core.utils.torch.rotations (third-party, not in the reference tree; formulas
+ * restated from the published isaacgym torch_utils of the same name), wxyz convention.
+ * call sites KAMMA.py:434 (quat_mul), :701, :707, :749 (quat_apply). */
+void orc_quat_apply(const float q[4], const float v[3], float out[3]) {
+  /* t = 2 * cross(xyz, v); out = v + w * t + cross(xyz, t) */
+  float x = q[1], y = q[2], z = q[3], w = q[0];
+  float tx = (y * v[2] - z * v[1]) * 2.0f;
+  float ty = (z * v[0] - x * v[2]) * 2.0f;
+  float tz = (x * v[1] - y * v[0]) * 2.0f;
+  out[0] = (v[0] + w * tx) + (y * tz - z * ty);
+  out[1] = (v[1] + w * ty) + (z * tx - x * tz);
+  out[2] = (v[2] + w * tz) + (x * ty - y * tx);
+}
+
+void orc_quat_mul(const float a[4], const float b[4], float out[4]) {
+  float w1 = a[0], x1 = a[1], y1 = a[2], z1 = a[3];
+  float w2 = b[0], x2 = b[1], y2 = b[2], z2 = b[3];
+  float ww = (z1 + x1) * (x2 + y2);
+  float yy = (w1 - y1) * (w2 + z2);
+  float zz = (w1 + y1) * (w2 - z2);
+  float xx = ww + yy + zz;
+  float qq = 0.5f * (xx + (z1 - x1) * (x2 - y2));
+  out[0] = qq - ww + (z1 - y1) * (y2 - z2);
+  out[1] = qq - xx + (x1 + w1) * (x2 + w2);
+  out[2] = qq - yy + (w1 - x1) * (y2 + z2);
+  out[3] = qq - zz + (z1 + y1) * (w2 - x2);
+}
+
+/* ------------------------------------------------------------------ a2 .. a11 -------- */
+/* a2: KAMMA.py:604-624. dt is the POLICY dt 0.1 (self.dt, KAMMA.py:260). */
+static inline void criteria1(float cmd_x, float cmd_yaw, float v_fwd_prev, float omega_z, float Kp,
+                             float Kp_omega, float mass, float inertia, float dt, float* v_delta,
+                             float* omega_delta, float* ac_left, float* ac_right) {
+  float vd = cmd_x - v_fwd_prev;  /* :609 */
+  float od = cmd_yaw - omega_z;   /* :610 */
+  float lin = Kp * (mass * (vd / dt));            /* :617 first term  */
+  float ang = Kp_omega * (inertia * (od / dt));   /* :617 second term */
+  *v_delta = vd;
+  *omega_delta = od;
+  *ac_left = lin - ang;   /* :617 */
+  *ac_right = lin + ang;  /* :619 */
+}
+
+void orc_criteria(int n, const float* cmd_x, const float* cmd_yaw, const float* v_fwd_prev,
+                  const float* omega_z, float Kp, float Kp_omega, float mass, float inertia,
+                  float dt, float* v_delta, float* omega_delta, float* ac_left, float* ac_right) {
+  for (int i = 0; i < n; ++i)
+    criteria1(cmd_x[i], cmd_yaw[i], v_fwd_prev[i], omega_z[i], Kp, Kp_omega, mass, inertia, dt,
+              &v_delta[i], &omega_delta[i], &ac_left[i], &ac_right[i]);
+}
+
+/* a3: KAMMA.py:627-628 */
+static inline float gamma1f(int32_t sim_steps, float max_sim_steps) {
+  float g = 1.0f - ((float)sim_steps / max_sim_steps);
+  return g < 0.0f ? 0.0f : g; /* torch.clamp(min=0.0) */
+}
+void orc_gamma(int n, const int32_t* sim_steps, float max_sim_steps, float* gamma) {
+  for (int i = 0; i < n; ++i) gamma[i] = gamma1f(sim_steps[i], max_sim_steps);
+}
+
+static inline float clipf(float x, float lo, float hi) { return fminf(fmaxf(x, lo), hi); }
+
+/* a4 + a5(clip) + guiding reward for one arena.
+ *   switch: KAMMA.py:632-636, clip :649, guiding :656
+ *   blend : KA_DDPG_4D.py:627-631, guiding on the UNCLIPPED policy torque :637 */
+static inline void mix1(int mix_mode, int guiding_mode, const float a[4], float ac_left,
+                        float ac_right, float gamma1, float rand01, float action_scale, float clip,
+                        float torques[4], float wheel_torqs[4], float* guiding) {
+  float crit[4] = {ac_left, ac_left, ac_right, ac_right}; /* :624 order fl, rl, fr, rr */
+  float d2[4];
+  for (int j = 0; j < 4; ++j) {
+    float pol = a[j] * action_scale;
+    float t;
+    if (mix_mode == OIS_MIX_SWITCH) {
+      float mask = rand01 < gamma1 ? 1.0f : 0.0f;      /* :634 */
+      t = mask * crit[j] + (1.0f - mask) * pol;          /* :635 */
+    } else {
+      t = ((1.0f - gamma1) * a[j]) * action_scale + gamma1 * crit[j]; /* KA_DDPG_4D.py:631 */
+    }
+    torques[j] = t;
+    wheel_torqs[j] = clipf(t, -clip, clip); /* :649 */
+    float d = (guiding_mode == OIS_GUIDE_EXECUTED ? wheel_torqs[j] : pol) - crit[j];
+    d2[j] = d * d;
+  }
+  /* torch.norm over the 4 wheels; summation order fixed by SPEC: (0+1)+(2+3) */
+  *guiding = -sqrtf((d2[0] + d2[1]) + (d2[2] + d2[3]));
+}
+
+void orc_mix(int n, int mix_mode, int guiding_mode, const float* actions4, const float* ac_left,
+             const float* ac_right, const float* gamma1, const float* rand01, float action_scale,
+             float clip, float* torques4, float* wheel_torqs4, float* guiding) {
+  for (int i = 0; i < n; ++i)
+    mix1(mix_mode, guiding_mode, &actions4[4 * i], ac_left[i], ac_right[i], gamma1[i],
+         rand01 ? rand01[i] : 0.0f, action_scale, clip, &torques4[4 * i], &wheel_torqs4[4 * i],
+         &guiding[i]);
+}
+
+/* a7: KAMMA.py:736-764 (env_origins are zero, :224) */
+static inline void is_done1(int32_t episode_buf, int max_episode_length, const float q[4],
+                            const float pos[3], float bounds, uint8_t* reset, uint8_t* timeout) {
+  uint8_t to = episode_buf >= max_episode_length - 1; /* :740-744 */
+  const float gvec[3] = {0.0f, 0.0f, -1.0f};          /* :382-384 get_axis_params(-1, 2) */
+  float pg[3];
+  orc_quat_apply(q, gvec, pg);                         /* :749 */
+  uint8_t fallen = pg[2] > 0.0f;                       /* :753 */
+  uint8_t oob = (pos[0] < -bounds) | (pos[0] > bounds) | (pos[1] < -bounds) | (pos[1] > bounds); /* :758-759 */
+  *timeout = to;
+  *reset = (uint8_t)(fallen | to | oob);
+}
+
+void orc_is_done(int n, const int32_t* episode_buf, int max_episode_length, const float* quat4,
+                 const float* pos3, float bounds, uint8_t* reset, uint8_t* timeout) {
+  for (int i = 0; i < n; ++i)
+    is_done1(episode_buf[i], max_episode_length, &quat4[4 * i], &pos3[3 * i], bounds, &reset[i], &timeout[i]);
+}
+
+typedef struct {
+  float lin_acc, ang_acc, rew;
+  float comp1, comp2, comp3, rdense, rsparse, robs;
+} metrics_out;
+
+/* a8: KAMMA.py:767-822 for one arena */
+static inline void metrics1(float v_fwd_prev, float omega_z, float* prev_lin, float* prev_ang,
+                            float v_delta, float omega_delta, const float wt[4], float guiding,
+                            float gamma2, uint8_t reset, uint8_t timeout, float dt, float w1,
+                            float w2, float w3, float sparse_bonus, float sparse_thr,
+                            float terminal_reward, float sums[8], metrics_out* o) {
+  float lin_acc = (v_fwd_prev - *prev_lin) / dt;   /* :770 */
+  float ang_acc = (omega_z - *prev_ang) / dt;      /* :771 */
+  *prev_lin = v_fwd_prev;                          /* :774 */
+  *prev_ang = omega_z;                             /* :775 */
+  float r1 = v_delta * v_delta + 5.0f * (omega_delta * omega_delta);        /* :779 */
+  float r2 = lin_acc * lin_acc + ang_acc * ang_acc;                          /* :781 */
+  float r3 = (wt[0] * wt[0] + wt[1] * wt[1]) + (wt[2] * wt[2] + wt[3] * wt[3]); /* :783, order by SPEC */
+  float c1 = w1 * r1, c2 = w2 * r2, c3 = w3 * r3;
+  float rdense = (c1 + c2) + c3;                                             /* :786 */
+  float sparse = (fabsf(v_delta) < sparse_thr && fabsf(omega_delta) < sparse_thr) ? sparse_bonus : 0.0f; /* :789-794 */
+  float observed = rdense + sparse;                                          /* :795 */
+  float rew = (1.0f - gamma2) * observed + gamma2 * guiding;                 /* :798 */
+  /* :801  rew += terminalReward * reset_buf * ~timeout_buf ; timeout_buf is an int64
+   * tensor, so ~ is the bitwise not: ~0 = -1, ~1 = -2 (reference quirk, kept). */
+  rew += (terminal_reward * (float)reset) * (float)(~(int)timeout);
+  sums[0] += c1;       /* :803 */
+  sums[1] += c2;       /* :804 */
+  sums[2] += c3;       /* :805 */
+  sums[3] += rdense;   /* :806 */
+  sums[4] += sparse;   /* :807 */
+  sums[5] += guiding;  /* :808 */
+  sums[6] += observed; /* :809 */
+  sums[7] += rew;      /* :810 */
+  o->lin_acc = lin_acc; o->ang_acc = ang_acc; o->rew = rew;
+  o->comp1 = c1; o->comp2 = c2; o->comp3 = c3; o->rdense = rdense; o->rsparse = sparse; o->robs = observed;
+}
+
+void orc_metrics(int n, const float* v_fwd_prev, const float* omega_z, float* prev_lin,
+                 float* prev_ang, const float* v_delta, const float* omega_delta,
+                 const float* wheel_torqs4, const float* guiding, const float* gamma2,
+                 const uint8_t* reset, const uint8_t* timeout, float dt, float w1, float w2,
+                 float w3, float sparse_bonus, float sparse_thr, float terminal_reward,
+                 float* lin_acc, float* ang_acc, float* rew, float* sums8) {
+  for (int i = 0; i < n; ++i) {
+    metrics_out o;
+    metrics1(v_fwd_prev[i], omega_z[i], &prev_lin[i], &prev_ang[i], v_delta[i], omega_delta[i],
+             &wheel_torqs4[4 * i], guiding[i], gamma2[i], reset[i], timeout[i], dt, w1, w2, w3,
+             sparse_bonus, sparse_thr, terminal_reward, &sums8[8 * i], &o);
+    lin_acc[i] = o.lin_acc; ang_acc[i] = o.ang_acc; rew[i] = o.rew;
+  }
+}
+
+/* a11: KAMMA.py:701-710 (only v_forward_projected is ever read back, :607, :770) */
+static inline float forward_projection1(const float q[4], const float v[3]) {
+  const float fvec[3] = {1.0f, 0.0f, 0.0f};
+  float f[3];
+  orc_quat_apply(q, fvec, f);                                        /* :701 */
+  float nrm = sqrtf((f[0] * f[0] + f[1] * f[1]) + f[2] * f[2]);      /* :704 torch.norm */
+  float fx = f[0] / nrm, fy = f[1] / nrm, fz = f[2] / nrm;
+  return (v[0] * fx + v[1] * fy) + v[2] * fz;                        /* :710 torch.sum */
+}
+void orc_forward_projection(int n, const float* quat4, const float* linvel3, float* v_fwd) {
+  for (int i = 0; i < n; ++i) v_fwd[i] = forward_projection1(&quat4[4 * i], &linvel3[3 * i]);
+}
+
+/* torch_rand_float(lower, upper, ...) = (upper - lower) * rand + lower
+ * (omni.isaac.core.utils.torch.maths, third-party; call sites :424-456, :571-572) */
+static inline float rand_float(float lo, float hi, float u) { return (hi - lo) * u + lo; }
+
+/* a9 pose + command part, KAMMA.py:422-460 and 490-496 / 569-575 */
+void orc_reset_draws(const ois_config* cfg, const float u[8], float pos3[3], float quat4[4],
+                     float commands4[4]) {
+  float r = cfg->spawn_xy_range;
+  pos3[0] = cfg->init_pos[0] + rand_float(-r, r, u[0]); /* :422-424 */
+  pos3[1] = cfg->init_pos[1] + rand_float(-r, r, u[1]);
+  pos3[2] = cfg->init_pos[2];
+  float ang = rand_float(0.0f, 6.28318530717958647692f, u[2]); /* :426 (2*pi as float32) */
+  float s, c;
+  orc_sincos(ang / 2.0f, &s, &c);                        /* :428, :431 */
+  float qz[4] = {c, 0.0f, 0.0f, s};
+  orc_quat_mul(qz, cfg->init_quat, quat4);               /* :434 */
+  float cx = rand_float(cfg->cmd_x_lo, cfg->cmd_x_hi, u[3]);       /* :448 */
+  float cy = rand_float(cfg->cmd_y_lo, cfg->cmd_y_hi, u[4]);       /* :451 */
+  float ch = rand_float(cfg->cmd_yaw_lo, cfg->cmd_yaw_hi, u[5]);   /* :454 */
+  float keep = sqrtf(cx * cx + cy * cy) > 0.25f ? 1.0f : 0.0f;     /* :458 */
+  commands4[0] = cx * keep;
+  commands4[1] = cy * keep;
+  commands4[2] = 0.0f * keep; /* commands[:,2] is still 0 here (zero-initialised :378) */
+  commands4[3] = ch * keep;
+  /* sample_velocity_command, randsampling branch :569-575 (u[7] is the discarded omega draw) */
+  float x_vel = rand_float(cfg->cmd_x_lo, cfg->cmd_x_hi, u[6]);    /* :571 */
+  commands4[0] = x_vel > 0.0f ? x_vel : 0.0f;                      /* :575 max(x_vel, 0.0), :495 */
+  commands4[2] = 0.0f;                                             /* :574, :496 */
+}
+
+/* ------------------------------------------------------------------ physics ---------- */
+typedef struct {
+  float dt, inv_dt, gdt, half_dt;
+  float im4;         /* 4 / body_mass (mass-splitting factor 4 = contacts per chassis) */
+  float J4[3];       /* 4 / body_inertia */
+  float dt_over_Is, dt_over_Iy, rw, rw_over_Is, rw2_over_Is;
+  float beta_inv_dt, vdep, maxw, maxw2, damping;
+  float cx[4], cy[4], cz; /* wheel centres relative to the composite COM, order fl, rl, fr, rr */
+  int iters;
+} derived;
+
+static void derive(const ois_config* c, derived* D) {
+  D->dt = c->sim_dt;
+  D->inv_dt = 1.0f / c->sim_dt;
+  D->gdt = c->gravity * c->sim_dt;
+  D->half_dt = 0.5f * c->sim_dt;
+  D->im4 = 4.0f / c->body_mass;
+  for (int k = 0; k < 3; ++k) D->J4[k] = 4.0f / c->body_inertia[k];
+  D->dt_over_Is = c->sim_dt / c->wheel_spin_inertia;
+  D->dt_over_Iy = c->sim_dt / c->body_inertia[1];
+  D->rw = c->wheel_radius;
+  D->rw_over_Is = c->wheel_radius / c->wheel_spin_inertia;
+  D->rw2_over_Is = (c->wheel_radius * c->wheel_radius) / c->wheel_spin_inertia;
+  D->beta_inv_dt = c->baumgarte * D->inv_dt;
+  D->vdep = c->max_depenetration_velocity;
+  D->maxw = c->max_angular_velocity;
+  D->maxw2 = c->max_angular_velocity * c->max_angular_velocity;
+  D->damping = c->wheel_damping;
+  /* env order fl, rl, fr, rr (KAMMA.py:157, 623); URDF: left = +y, front = +x (urdf:112-142) */
+  const float sx[4] = {1.0f, -1.0f, 1.0f, -1.0f};
+  const float sy[4] = {1.0f, 1.0f, -1.0f, -1.0f};
+  for (int w = 0; w < 4; ++w) {
+    D->cx[w] = sx[w] * c->wheel_pos[0];
+    D->cy[w] = sy[w] * c->wheel_pos[1];
+  }
+  D->cz = c->wheel_pos[2] - c->com_height;
+  D->iters = c->solver_iterations;
+}
+
+static inline void rotmat(const float q[4], float R[9]) {
+  float qw = q[0], qx = q[1], qy = q[2], qz = q[3];
+  float x2 = qx + qx, y2 = qy + qy, z2 = qz + qz;
+  float xx = qx * x2, yy = qy * y2, zz = qz * z2;
+  float xy = qx * y2, xz = qx * z2, yz = qy * z2;
+  float wx = qw * x2, wy = qw * y2, wz = qw * z2;
+  R[0] = 1.0f - (yy + zz); R[1] = xy - wz;          R[2] = xz + wy;
+  R[3] = xy + wz;          R[4] = 1.0f - (xx + zz); R[5] = yz - wx;
+  R[6] = xz - wy;          R[7] = yz + wx;          R[8] = 1.0f - (xx + yy);
+}
+/* out = R^T a */
+static inline void rotT(const float R[9], const float a[3], float o[3]) {
+  o[0] = fmaf(R[6], a[2], fmaf(R[3], a[1], R[0] * a[0]));
+  o[1] = fmaf(R[7], a[2], fmaf(R[4], a[1], R[1] * a[0]));
+  o[2] = fmaf(R[8], a[2], fmaf(R[5], a[1], R[2] * a[0]));
+}
+/* out = R a */
+static inline void rot(const float R[9], const float a[3], float o[3]) {
+  o[0] = fmaf(R[2], a[2], fmaf(R[1], a[1], R[0] * a[0]));
+  o[1] = fmaf(R[5], a[2], fmaf(R[4], a[1], R[3] * a[0]));
+  o[2] = fmaf(R[8], a[2], fmaf(R[7], a[1], R[6] * a[0]));
+}
+
+/* One physics substep (docs/SPEC.md §3). spin[] = absolute wheel spin about the body y
+ * axis (joint velocity + chassis w_y). Mass-splitting Jacobi across the 4 wheel contacts,
+ * Gauss-Seidel across the 3 rows (normal, longitudinal, lateral) of each contact. */
+static void substep(const derived* D, float mu, const float n[3], const float tau[4], float p[3],
+                    float q[4], float v[3], float w[3], float spin[4], float ln[4], float l1[4],
+                    float l2[4]) {
+  float R[9];
+  rotmat(q, R);
+  float vb[3], wb[3], nb[3];
+  rotT(R, v, vb);
+  rotT(R, w, wb);
+  rotT(R, n, nb);
+  /* gravity (world -z) in the body frame */
+  vb[0] = fmaf(-D->gdt, R[6], vb[0]);
+  vb[1] = fmaf(-D->gdt, R[7], vb[1]);
+  vb[2] = fmaf(-D->gdt, R[8], vb[2]);
+  /* wheel drive + viscous joint damping, reaction on the chassis */
+  float T[4];
+  for (int k = 0; k < 4; ++k) {
+    float jv = spin[k] - wb[1];
+    T[k] = fmaf(-D->damping, jv, tau[k]);
+    spin[k] = fmaf(D->dt_over_Is, T[k], spin[k]);
+  }
+  float Tsum = (T[0] + T[1]) + (T[2] + T[3]);
+  wb[1] = fmaf(-D->dt_over_Iy, Tsum, wb[1]);
+
+  /* contact frame shared by the four wheels (common axle direction = body y) */
+  float s2 = fmaf(nb[2], nb[2], nb[0] * nb[0]);
+  s2 = fmaxf(s2, 1e-12f);
+  float inv_s = 1.0f / sqrtf(s2);
+  float dx = -(nb[0] * inv_s), dz = -(nb[2] * inv_s);
+  float t1x = -dz, t1z = dx;
+  float t2x = nb[1] * t1z;
+  float t2y = fmaf(nb[2], t1x, -(nb[0] * t1z));
+  float t2z = -(nb[1] * t1x);
+  float np = fmaf(n[2], p[2], fmaf(n[1], p[1], n[0] * p[0]));
+
+  float b[4], an[4][3], a1[4][3], a2[4][3], Jan[4][3], Ja1[4][3], Ja2[4][3], mn[4], m1[4], m2[4];
+  for (int k = 0; k < 4; ++k) {
+    float cx = D->cx[k], cy = D->cy[k], cz = D->cz;
+    float rx = fmaf(D->rw, dx, cx), ry = cy, rz = fmaf(D->rw, dz, cz);
+    float gap = np + fmaf(nb[2], rz, fmaf(nb[1], ry, nb[0] * rx));
+    b[k] = gap >= 0.0f ? -(gap * D->inv_dt) : fminf(-(gap * D->beta_inv_dt), D->vdep);
+    an[k][0] = fmaf(ry, nb[2], -(rz * nb[1]));
+    an[k][1] = fmaf(rz, nb[0], -(rx * nb[2]));
+    an[k][2] = fmaf(rx, nb[1], -(ry * nb[0]));
+    a1[k][0] = cy * t1z;
+    a1[k][1] = fmaf(cz, t1x, -(cx * t1z));
+    a1[k][2] = -(cy * t1x);
+    a2[k][0] = fmaf(ry, t2z, -(rz * t2y));
+    a2[k][1] = fmaf(rz, t2x, -(rx * t2z));
+    a2[k][2] = fmaf(rx, t2y, -(ry * t2x));
+    for (int j = 0; j < 3; ++j) {
+      Jan[k][j] = D->J4[j] * an[k][j];
+      Ja1[k][j] = D->J4[j] * a1[k][j];
+      Ja2[k][j] = D->J4[j] * a2[k][j];
+    }
+    float kn = fmaf(an[k][2], Jan[k][2], fmaf(an[k][1], Jan[k][1], fmaf(an[k][0], Jan[k][0], D->im4)));
+    float k1 = fmaf(a1[k][2], Ja1[k][2], fmaf(a1[k][1], Ja1[k][1], fmaf(a1[k][0], Ja1[k][0], D->im4))) + D->rw2_over_Is;
+    float k2 = fmaf(a2[k][2], Ja2[k][2], fmaf(a2[k][1], Ja2[k][1], fmaf(a2[k][0], Ja2[k][0], D->im4)));
+    mn[k] = 1.0f / kn;
+    m1[k] = 1.0f / k1;
+    m2[k] = 1.0f / k2;
+  }
+  float vnx = D->im4 * nb[0], vny = D->im4 * nb[1], vnz = D->im4 * nb[2];
+  float v1x = D->im4 * t1x, v1z = D->im4 * t1z;
+  float v2x = D->im4 * t2x, v2y = D->im4 * t2y, v2z = D->im4 * t2z;
+
+  /* warm start: re-apply the impulses accumulated in the previous substep (they persist
+   * across policy steps in OIS_BUF_LAMBDA_*), as one more mass-split averaging pass */
+  {
+    float vl[4][3], wl[4][3];
+    for (int k = 0; k < 4; ++k) {
+      vl[k][0] = fmaf(l2[k], v2x, fmaf(l1[k], v1x, fmaf(ln[k], vnx, vb[0])));
+      vl[k][1] = fmaf(l2[k], v2y, fmaf(ln[k], vny, vb[1]));
+      vl[k][2] = fmaf(l2[k], v2z, fmaf(l1[k], v1z, fmaf(ln[k], vnz, vb[2])));
+      for (int j = 0; j < 3; ++j) wl[k][j] = fmaf(l2[k], Ja2[k][j], fmaf(l1[k], Ja1[k][j], fmaf(ln[k], Jan[k][j], wb[j])));
+      spin[k] = fmaf(-D->rw_over_Is, l1[k], spin[k]);
+    }
+    for (int j = 0; j < 3; ++j) {
+      vb[j] = 0.25f * ((vl[0][j] + vl[1][j]) + (vl[2][j] + vl[3][j]));
+      wb[j] = 0.25f * ((wl[0][j] + wl[1][j]) + (wl[2][j] + wl[3][j]));
+    }
+  }
+  for (int it = 0; it < D->iters; ++it) {
+    float vl[4][3], wl[4][3];
+    for (int k = 0; k < 4; ++k) {
+      float vx = vb[0], vy = vb[1], vz = vb[2], ox = wb[0], oy = wb[1], oz = wb[2];
+      /* normal row */
+      float u = fmaf(an[k][2], oz, fmaf(an[k][1], oy, fmaf(an[k][0], ox, fmaf(nb[2], vz, fmaf(nb[1], vy, nb[0] * vx)))));
+      float dl = (b[k] - u) * mn[k];
+      float nw = fmaxf(ln[k] + dl, 0.0f);
+      dl = nw - ln[k];
+      ln[k] = nw;
+      vx = fmaf(dl, vnx, vx); vy = fmaf(dl, vny, vy); vz = fmaf(dl, vnz, vz);
+      ox = fmaf(dl, Jan[k][0], ox); oy = fmaf(dl, Jan[k][1], oy); oz = fmaf(dl, Jan[k][2], oz);
+      float lim = mu * ln[k];
+      /* longitudinal row (couples the wheel spin) */
+      u = fmaf(-D->rw, spin[k], fmaf(a1[k][2], oz, fmaf(a1[k][1], oy, fmaf(a1[k][0], ox, fmaf(t1z, vz, t1x * vx)))));
+      dl = -(u * m1[k]);
+      nw = fminf(fmaxf(l1[k] + dl, -lim), lim);
+      dl = nw - l1[k];
+      l1[k] = nw;
+      vx = fmaf(dl, v1x, vx); vz = fmaf(dl, v1z, vz);
+      ox = fmaf(dl, Ja1[k][0], ox); oy = fmaf(dl, Ja1[k][1], oy); oz = fmaf(dl, Ja1[k][2], oz);
+      spin[k] = fmaf(-D->rw_over_Is, dl, spin[k]);
+      /* lateral row */
+      u = fmaf(a2[k][2], oz, fmaf(a2[k][1], oy, fmaf(a2[k][0], ox, fmaf(t2z, vz, fmaf(t2y, vy, t2x * vx)))));
+      dl = -(u * m2[k]);
+      nw = fminf(fmaxf(l2[k] + dl, -lim), lim);
+      dl = nw - l2[k];
+      l2[k] = nw;
+      vx = fmaf(dl, v2x, vx); vy = fmaf(dl, v2y, vy); vz = fmaf(dl, v2z, vz);
+      ox = fmaf(dl, Ja2[k][0], ox); oy = fmaf(dl, Ja2[k][1], oy); oz = fmaf(dl, Ja2[k][2], oz);
+      vl[k][0] = vx; vl[k][1] = vy; vl[k][2] = vz;
+      wl[k][0] = ox; wl[k][1] = oy; wl[k][2] = oz;
+    }
+    for (int j = 0; j < 3; ++j) {
+      vb[j] = 0.25f * ((vl[0][j] + vl[1][j]) + (vl[2][j] + vl[3][j]));
+      wb[j] = 0.25f * ((wl[0][j] + wl[1][j]) + (wl[2][j] + wl[3][j]));
+    }
+  }
+  /* back to the world frame, velocity caps (origin_v18.py:65-70), integrate */
+  rot(R, vb, v);
+  rot(R, wb, w);
+  float w2 = fmaf(w[2], w[2], fmaf(w[1], w[1], w[0] * w[0]));
+  if (w2 > D->maxw2) {
+    float sc = D->maxw / sqrtf(w2);
+    w[0] *= sc; w[1] *= sc; w[2] *= sc;
+  }
+  for (int k = 0; k < 4; ++k) spin[k] = fminf(fmaxf(spin[k], -D->maxw), D->maxw);
+  p[0] = fmaf(D->dt, v[0], p[0]);
+  p[1] = fmaf(D->dt, v[1], p[1]);
+  p[2] = fmaf(D->dt, v[2], p[2]);
+  float qw = q[0], qx = q[1], qy = q[2], qz = q[3], h = D->half_dt;
+  float nqw = fmaf(-h, fmaf(w[2], qz, fmaf(w[1], qy, w[0] * qx)), qw);
+  float nqx = fmaf(h, fmaf(-w[2], qy, fmaf(w[1], qz, w[0] * qw)), qx);
+  float nqy = fmaf(h, fmaf(-w[0], qz, fmaf(w[2], qx, w[1] * qw)), qy);
+  float nqz = fmaf(h, fmaf(-w[1], qx, fmaf(w[0], qy, w[2] * qw)), qz);
+  float nn = fmaf(nqz, nqz, fmaf(nqy, nqy, fmaf(nqx, nqx, nqw * nqw)));
+  float inv = 1.0f / sqrtf(nn);
+  q[0] = nqw * inv; q[1] = nqx * inv; q[2] = nqy * inv; q[3] = nqz * inv;
+}
+
+void orc_substep(const ois_config* cfg, float mu, const float n_world[3], const float tau[4],
+                 float p[3], float q[4], float v[3], float w[3], float spin[4], float lam_n[4],
+                 float lam_l[4], float lam_t[4]) {
+  derived D;
+  derive(cfg, &D);
+  substep(&D, mu, n_world, tau, p, q, v, w, spin, lam_n, lam_l, lam_t);
+}
+
+/* ------------------------------------------------------------------ environment ------ */
+#define GROUP 16          /* arenas per reduction group (= one wave64 of the HIP kernel) */
+#define PART_STRIDE 32    /* floats per group partial record */
+/* partial-record slots: 0..15 as OIS_EI_COUNT..OBSERVED_OVER_FINAL (sums over reset arenas),
+ * 16 gamma1, 17 gamma2, 20..22 eval sums, 24 return^2 sum, 25 return min, 26 return max, 27 length sum */
+enum { P_G1 = 16, P_G2 = 17, P_SM = 20, P_TE = 21, P_DV = 22, P_RET2 = 24, P_RMIN = 25, P_RMAX = 26, P_LEN = 27 };
+enum { ST_COUNT = 0, ST_RET = 1, ST_RET2 = 2, ST_RMIN = 3, ST_RMAX = 4, ST_LEN = 5, ST_STRIDE = 8 };
+
+struct orc_env {
+  ois_config cfg;
+  derived D;
+  int N, G;
+  int threads;
+  int reset_done;
+  uint64_t seed;
+  double steps_done;
+  /* buffers, same ids/shapes as the product */
+  float *obs, *rew, *wheel_torqs, *pose, *quat, *linvel, *angvel, *wheel_vel, *commands, *sums_a, *sums_b, *sums_c, *params;
+  float *lam_n, *lam_l, *lam_t; /* contact impulse cache (warm start), [N,4] each */
+  uint8_t *done, *timeout;
+  int32_t* counters;
+  float episode_info[OIS_EPISODE_INFO_LEN];
+  float env0_diag[OIS_ENV0_DIAG_LEN];
+  float* partials;  /* [G][PART_STRIDE] */
+  int32_t* stamps;  /* [G] */
+  float* stat_acc;  /* [G][ST_STRIDE] */
+};
+
+static void* zalloc(size_t n) { return calloc(n ? n : 1, 1); }
+
+int orc_create(const ois_config* cfg, orc_env** out) {
+  if (!cfg || !out) return fail(OIS_EINVAL, "null argument");
+  if (cfg->struct_bytes != sizeof(ois_config)) return fail(OIS_EINVAL, "ois_config.struct_bytes mismatch");
+  if (cfg->num_envs <= 0) return fail(OIS_EINVAL, "num_envs must be > 0");
+  if (cfg->action_dim != 4 && cfg->action_dim != 2 && cfg->action_dim != 1) return fail(OIS_EINVAL, "action_dim must be 4, 2 or 1");
+  if (cfg->solver_iterations < 1 || cfg->solver_iterations > 16) return fail(OIS_EINVAL, "solver_iterations out of range");
+  orc_env* e = (orc_env*)zalloc(sizeof *e);
+  if (!e) return fail(OIS_ENOMEM, "host alloc");
+  e->cfg = *cfg;
+  derive(cfg, &e->D);
+  int N = e->N = cfg->num_envs;
+  int G = e->G = (N + GROUP - 1) / GROUP;
+  e->threads = 1;
+  size_t f4 = (size_t)N * 4 * sizeof(float);
+  e->obs = zalloc((size_t)N * 6 * sizeof(float));
+  e->rew = zalloc((size_t)N * sizeof(float));
+  e->wheel_torqs = zalloc(f4); e->pose = zalloc(f4); e->quat = zalloc(f4); e->linvel = zalloc(f4);
+  e->angvel = zalloc(f4); e->wheel_vel = zalloc(f4); e->commands = zalloc(f4);
+  e->sums_a = zalloc(f4); e->sums_b = zalloc(f4); e->sums_c = zalloc(f4); e->params = zalloc(f4);
+  e->lam_n = zalloc(f4); e->lam_l = zalloc(f4); e->lam_t = zalloc(f4);
+  e->done = zalloc((size_t)N); e->timeout = zalloc((size_t)N);
+  e->counters = zalloc((size_t)N * 4 * sizeof(int32_t));
+  e->partials = zalloc((size_t)G * PART_STRIDE * sizeof(float));
+  e->stamps = zalloc((size_t)G * sizeof(int32_t));
+  e->stat_acc = zalloc((size_t)G * ST_STRIDE * sizeof(float));
+  for (int i = 0; i < N; ++i) {
+    e->params[4 * i + 0] = cfg->friction;
+    e->params[4 * i + 1] = 0.0f; e->params[4 * i + 2] = 0.0f; e->params[4 * i + 3] = 1.0f;
+  }
+  *out = e;
+  return OIS_OK;
+}
+
+void orc_destroy(orc_env* e) {
+  if (!e) return;
+  free(e->obs); free(e->rew); free(e->wheel_torqs); free(e->pose); free(e->quat); free(e->linvel);
+  free(e->angvel); free(e->wheel_vel); free(e->commands); free(e->sums_a); free(e->sums_b); free(e->sums_c);
+  free(e->params); free(e->lam_n); free(e->lam_l); free(e->lam_t); free(e->done); free(e->timeout); free(e->counters); free(e->partials); free(e->stamps);
+  free(e->stat_acc); free(e);
+}
+
+int orc_set_threads(orc_env* e, int threads) {
+  if (!e || threads < 1) return fail(OIS_EINVAL, "threads must be >= 1");
+#ifndef _OPENMP
+  if (threads != 1) return fail(OIS_EINVAL, "oracle built without OpenMP");
+#endif
+  e->threads = threads;
+  return OIS_OK;
+}
+
+int orc_buffer(orc_env* e, int id, void** ptr, size_t* bytes) {
+  if (!e || !ptr || !bytes) return fail(OIS_EINVAL, "null argument");
+  size_t N = (size_t)e->N, f4 = N * 4 * sizeof(float);
+  switch (id) {
+    case OIS_BUF_OBS: *ptr = e->obs; *bytes = N * 6 * sizeof(float); break;
+    case OIS_BUF_REW: *ptr = e->rew; *bytes = N * sizeof(float); break;
+    case OIS_BUF_DONE: *ptr = e->done; *bytes = N; break;
+    case OIS_BUF_TIMEOUT: *ptr = e->timeout; *bytes = N; break;
+    case OIS_BUF_WHEEL_TORQS: *ptr = e->wheel_torqs; *bytes = f4; break;
+    case OIS_BUF_POSE: *ptr = e->pose; *bytes = f4; break;
+    case OIS_BUF_QUAT: *ptr = e->quat; *bytes = f4; break;
+    case OIS_BUF_LINVEL: *ptr = e->linvel; *bytes = f4; break;
+    case OIS_BUF_ANGVEL: *ptr = e->angvel; *bytes = f4; break;
+    case OIS_BUF_WHEEL_VEL: *ptr = e->wheel_vel; *bytes = f4; break;
+    case OIS_BUF_COMMANDS: *ptr = e->commands; *bytes = f4; break;
+    case OIS_BUF_COUNTERS: *ptr = e->counters; *bytes = N * 4 * sizeof(int32_t); break;
+    case OIS_BUF_SUMS_A: *ptr = e->sums_a; *bytes = f4; break;
+    case OIS_BUF_SUMS_B: *ptr = e->sums_b; *bytes = f4; break;
+    case OIS_BUF_SUMS_C: *ptr = e->sums_c; *bytes = f4; break;
+    case OIS_BUF_PARAMS: *ptr = e->params; *bytes = f4; break;
+    case OIS_BUF_LAMBDA_N: *ptr = e->lam_n; *bytes = f4; break;
+    case OIS_BUF_LAMBDA_L: *ptr = e->lam_l; *bytes = f4; break;
+    case OIS_BUF_LAMBDA_T: *ptr = e->lam_t; *bytes = f4; break;
+    case OIS_BUF_EPISODE_INFO: *ptr = e->episode_info; *bytes = sizeof e->episode_info; break;
+    case OIS_BUF_ENV0_DIAG: *ptr = e->env0_diag; *bytes = sizeof e->env0_diag; break;
+    default: return fail(OIS_EINVAL, "unknown buffer id");
+  }
+  return OIS_OK;
+}
+
+/* per-arena values contributed to the group partial record when the arena resets */
+typedef struct {
+  float v[16];  /* slots 0..15 */
+  float sm, te, dv;
+  float ret, len;
+} reset_contrib;
+
+/* reset_idx for ONE arena (KAMMA.py:417-498). Fills the contribution to extras, rewrites
+ * pose / velocities / commands / counters / sums. step_ctr = sim_steps value used as RNG
+ * counter. gamma2 = current reward assist (:467-476). */
+static void reset_arena(orc_env* e, int i, uint32_t step_ctr, float gamma2, reset_contrib* rc) {
+  const ois_config* c = &e->cfg;
+  float* sa = &e->sums_a[4 * i];
+  float* sb = &e->sums_b[4 * i];
+  float* sc = &e->sums_c[4 * i];
+  int32_t* cnt = &e->counters[4 * i];
+  float S[8] = {sa[0], sa[1], sa[2], sa[3], sb[0], sb[1], sb[2], sb[3]};
+  float Sf = S[7];
+  float hg = 100.0f * (1.0f - gamma2); /* hundred * (one - gamma2) :470 */
+  float gg = 100.0f * gamma2;          /* hundred * gamma2         :475 */
+  float L = c->episode_length_s;
+  rc->v[OIS_EI_COUNT] = 1.0f;
+  for (int k = 0; k < 8; ++k) rc->v[OIS_EI_R1 + k] = S[k];
+  rc->v[OIS_EI_R1_OVER_FINAL] = L * ((hg * S[0]) / Sf);       /* :470 */
+  rc->v[OIS_EI_R2_OVER_FINAL] = L * ((hg * S[1]) / Sf);       /* :471 */
+  rc->v[OIS_EI_R3_OVER_FINAL] = L * ((hg * S[2]) / Sf);       /* :472 */
+  rc->v[OIS_EI_DENSE_OVER_FINAL] = L * ((hg * S[3]) / Sf);    /* :473 */
+  rc->v[OIS_EI_SPARSE_OVER_FINAL] = L * ((hg * S[4]) / Sf);   /* :474 */
+  rc->v[OIS_EI_GUIDING_OVER_FINAL] = L * ((gg * S[5]) / Sf);  /* :475 */
+  rc->v[OIS_EI_OBSERVED_OVER_FINAL] = L * ((hg * S[6]) / Sf); /* :476 */
+  rc->sm = sc[0]; rc->te = sc[1]; rc->dv = sc[2];
+  rc->ret = Sf;
+  rc->len = (float)cnt[0];
+  /* :485 zero the sums of the reset arena */
+  for (int k = 0; k < 4; ++k) { sa[k] = 0.0f; sb[k] = 0.0f; }
+  sc[0] = sc[1] = sc[2] = 0.0f;
+  sc[3] = 0.0f; /* old_torques scratch (KAMMA_eval.py:470) — per-arena here, see SPEC */
+
+  float u[8];
+  int64_t gid = c->arena_offset + i;
+  draw4(e->seed, gid, step_ctr, PURPOSE_RESET_A, &u[0]);
+  draw4(e->seed, gid, step_ctr, PURPOSE_RESET_B, &u[4]);
+  float pos[3], q[4], cmd[4];
+  orc_reset_draws(c, u, pos, q, cmd);
+  if (c->cmd_sampler == OIS_CMD_BOX) {
+    /* KAMMA_curr1.py:577-598 */
+    float progress = fminf(1.0f, (float)cnt[1] / c->max_sim_steps);
+    float factor = 0.1f + (1.0f - 0.1f) * progress;
+    float xc = (c->cmd_x_lo + c->cmd_x_hi) / 2.0f;
+    float xmin = xc - (xc - c->cmd_x_lo) * factor;
+    float xmax = xc + (c->cmd_x_hi - xc) * factor;
+    float xv = rand_float(xmin, xmax, u[6]);
+    cmd[0] = xv > 0.0f ? xv : 0.0f;
+  } else if (c->cmd_sampler == OIS_CMD_EVAL) {
+    /* KAMMA_eval.py:545-550 */
+    float progress = fminf(fmaxf((float)cnt[1] / c->eval_ramp_steps, 0.0f), 1.0f);
+    float xv = 1.0f + progress * (2.0f - 1.0f);
+    cmd[0] = xv > 0.0f ? xv : 0.0f;
+  }
+  /* pose: the reference sets the base-link pose (:441-443); the state stores the COM */
+  float* P = &e->pose[4 * i];
+  float R[9];
+  rotmat(q, R);
+  P[0] = fmaf(R[2], c->com_height, pos[0]);
+  P[1] = fmaf(R[5], c->com_height, pos[1]);
+  P[2] = fmaf(R[8], c->com_height, pos[2]);
+  memcpy(&e->quat[4 * i], q, sizeof q);
+  for (int k = 0; k < 3; ++k) {
+    e->linvel[4 * i + k] = c->init_lin_vel[k]; /* :435 */
+    e->angvel[4 * i + k] = c->init_ang_vel[k];
+  }
+  for (int k = 0; k < 4; ++k) e->wheel_vel[4 * i + k] = c->init_dof_vel[k]; /* :438, :446 */
+  for (int k = 0; k < 4; ++k) e->lam_n[4 * i + k] = e->lam_l[4 * i + k] = e->lam_t[4 * i + k] = 0.0f; /* teleport: drop the contact cache */
+  memcpy(&e->commands[4 * i], cmd, sizeof cmd);
+  cnt[0] = 0;   /* :462 */
+  cnt[2] += 1;  /* :463 */
+}
+
+/* pairwise tree over the GROUP arenas of a group; absent arenas contribute `ident` */
+static float tree16(const float* x, int n, float ident, int op) {
+  float t[GROUP];
+  for (int i = 0; i < GROUP; ++i) t[i] = i < n ? x[i] : ident;
+  for (int s = 1; s < GROUP; s <<= 1)
+    for (int i = 0; i < GROUP; i += 2 * s) {
+      float a = t[i], b = t[i + s];
+      t[i] = op == 0 ? a + b : (op == 1 ? fminf(a, b) : fmaxf(a, b));
+    }
+  return t[0];
+}
+
+static void group_reduce(orc_env* e, int g, const uint8_t* rs, const reset_contrib* rc, int32_t stamp,
+                         float gamma1, float gamma2, int count_stats) {
+  int base = g * GROUP;
+  int n = e->N - base < GROUP ? e->N - base : GROUP;
+  int any = 0;
+  for (int i = 0; i < n; ++i) any |= rs[base + i];
+  if (!any) return;
+  float* P = &e->partials[(size_t)g * PART_STRIDE];
+  float x[GROUP];
+  for (int k = 0; k < 16; ++k) {
+    for (int i = 0; i < n; ++i) x[i] = rs[base + i] ? rc[base + i].v[k] : 0.0f;
+    P[k] = tree16(x, n, 0.0f, 0);
+  }
+  P[P_G1] = gamma1; P[P_G2] = gamma2;
+  for (int i = 0; i < n; ++i) x[i] = rs[base + i] ? rc[base + i].sm : 0.0f;
+  P[P_SM] = tree16(x, n, 0.0f, 0);
+  for (int i = 0; i < n; ++i) x[i] = rs[base + i] ? rc[base + i].te : 0.0f;
+  P[P_TE] = tree16(x, n, 0.0f, 0);
+  for (int i = 0; i < n; ++i) x[i] = rs[base + i] ? rc[base + i].dv : 0.0f;
+  P[P_DV] = tree16(x, n, 0.0f, 0);
+  for (int i = 0; i < n; ++i) x[i] = rs[base + i] ? rc[base + i].ret * rc[base + i].ret : 0.0f;
+  P[P_RET2] = tree16(x, n, 0.0f, 0);
+  for (int i = 0; i < n; ++i) x[i] = rs[base + i] ? rc[base + i].ret : INFINITY;
+  P[P_RMIN] = tree16(x, n, INFINITY, 1);
+  for (int i = 0; i < n; ++i) x[i] = rs[base + i] ? rc[base + i].ret : -INFINITY;
+  P[P_RMAX] = tree16(x, n, -INFINITY, 2);
+  for (int i = 0; i < n; ++i) x[i] = rs[base + i] ? rc[base + i].len : 0.0f;
+  P[P_LEN] = tree16(x, n, 0.0f, 0);
+  e->stamps[g] = stamp;
+  if (count_stats) {
+    float* A = &e->stat_acc[(size_t)g * ST_STRIDE];
+    A[ST_COUNT] += P[OIS_EI_COUNT];
+    A[ST_RET] += P[OIS_EI_FINAL];
+    A[ST_RET2] += P[P_RET2];
+    A[ST_RMIN] = fminf(A[ST_RMIN], P[P_RMIN]);
+    A[ST_RMAX] = fmaxf(A[ST_RMAX], P[P_RMAX]);
+    A[ST_LEN] += P[P_LEN];
+  }
+}
+
+static void stats_clear(orc_env* e) {
+  for (int g = 0; g < e->G; ++g) {
+    float* A = &e->stat_acc[(size_t)g * ST_STRIDE];
+    memset(A, 0, ST_STRIDE * sizeof(float));
+    A[ST_RMIN] = INFINITY;
+    A[ST_RMAX] = -INFINITY;
+  }
+  e->steps_done = 0.0;
+}
+
+/* post_reset (KAMMA.py:366-414): zero task buffers, reset_idx(all) */
+int orc_reset(orc_env* e, uint64_t seed) {
+  if (!e) return fail(OIS_EINVAL, "null env");
+  int N = e->N;
+  e->seed = seed;
+  size_t f4 = (size_t)N * 4 * sizeof(float);
+  memset(e->obs, 0, (size_t)N * 6 * sizeof(float)); memset(e->rew, 0, (size_t)N * sizeof(float));
+  memset(e->wheel_torqs, 0, f4); memset(e->pose, 0, f4); memset(e->quat, 0, f4); memset(e->linvel, 0, f4);
+  memset(e->angvel, 0, f4); memset(e->wheel_vel, 0, f4); memset(e->commands, 0, f4);
+  memset(e->sums_a, 0, f4); memset(e->sums_b, 0, f4); memset(e->sums_c, 0, f4);
+  memset(e->lam_n, 0, f4); memset(e->lam_l, 0, f4); memset(e->lam_t, 0, f4);
+  memset(e->done, 0, (size_t)N); memset(e->timeout, 0, (size_t)N);
+  memset(e->counters, 0, (size_t)N * 4 * sizeof(int32_t));
+  memset(e->partials, 0, (size_t)e->G * PART_STRIDE * sizeof(float));
+  memset(e->episode_info, 0, sizeof e->episode_info);
+  memset(e->env0_diag, 0, sizeof e->env0_diag);
+  stats_clear(e);
+  reset_contrib* rc = (reset_contrib*)zalloc((size_t)N * sizeof *rc);
+  uint8_t* rs = (uint8_t*)malloc((size_t)N);
+  if (!rc || !rs) { free(rc); free(rs); return fail(OIS_ENOMEM, "host alloc"); }
+  memset(rs, 1, (size_t)N);
+  /* gamma_assist1/2 are their constructor values here: ones (KAMMA.py:192-193), or the
+   * configured constants for the constant-gamma variants */
+  float g1 = e->cfg.gamma1_mode == OIS_GAMMA_CONST ? e->cfg.gamma1_const : 1.0f;
+  float g2 = e->cfg.gamma2_mode == OIS_GAMMA_CONST ? e->cfg.gamma2_const : 1.0f;
+  for (int i = 0; i < N; ++i) reset_arena(e, i, 0u, g2, &rc[i]);
+  for (int g = 0; g < e->G; ++g) group_reduce(e, g, rs, rc, 0, g1, g2, 0);
+  free(rc); free(rs);
+  e->reset_done = 1;
+  return OIS_OK;
+}
+
+/* one policy step of arena i: pre_physics_step + substeps + post_physics_step.
+ * Returns reward. rs/rc: reset flag and contribution (for the group reduction). */
+static float step_arena(orc_env* e, int i, const float* act /*[A]*/, uint8_t* rs, reset_contrib* rc, float* g1_out, float* g2_out) {
+  const ois_config* c = &e->cfg;
+  const derived* D = &e->D;
+  float* P = &e->pose[4 * i];
+  float* Q = &e->quat[4 * i];
+  float* V = &e->linvel[4 * i];
+  float* W = &e->angvel[4 * i];
+  float* JV = &e->wheel_vel[4 * i];
+  float* CMD = &e->commands[4 * i];
+  int32_t* cnt = &e->counters[4 * i];
+  float* sa = &e->sums_a[4 * i];
+  float* sb = &e->sums_b[4 * i];
+  float* sc = &e->sums_c[4 * i];
+  const float* prm = &e->params[4 * i];
+  int64_t gid = c->arena_offset + i;
+
+  /* ---- pre_physics_step (KAMMA.py:596-656) ---- */
+  float a4[4];
+  if (c->action_dim == 4) { a4[0] = act[0]; a4[1] = act[1]; a4[2] = act[2]; a4[3] = act[3]; }
+  else if (c->action_dim == 2) { a4[0] = a4[1] = act[0]; a4[2] = a4[3] = act[1]; } /* KA_DDPG_2D.py:623-624 */
+  else { a4[0] = a4[1] = a4[2] = a4[3] = act[0]; }                                  /* KA_DDPG_1D.py:600-603 */
+  float desired_v = CMD[0], desired_omega = CMD[2];
+  float current_v = P[3];      /* v_forward_projected of the previous step :607 */
+  float current_omega = W[2];  /* base_velocities[:,5] :608 */
+  float v_delta, omega_delta, ac_left, ac_right;
+  criteria1(desired_v, desired_omega, current_v, current_omega, c->Kp, c->Kp_omega, c->vehicle_mass,
+            c->vehicle_inertia, c->policy_dt, &v_delta, &omega_delta, &ac_left, &ac_right);
+  float gsched = gamma1f(cnt[1], c->max_sim_steps);
+  float gamma1 = c->gamma1_mode == OIS_GAMMA_CONST ? c->gamma1_const : gsched;
+  float gamma2 = c->gamma2_mode == OIS_GAMMA_CONST ? c->gamma2_const : gsched;
+  float rnd = 0.0f;
+  if (c->mix_mode == OIS_MIX_SWITCH) {
+    float u[4];
+    draw4(e->seed, gid, (uint32_t)cnt[1], PURPOSE_MASK, u); /* torch.rand(num_envs,1) :633 */
+    rnd = u[0];
+  }
+  float torques[4], wt[4], guiding;
+  mix1(c->mix_mode, c->guiding_mode, a4, ac_left, ac_right, gamma1, rnd, c->action_scale, c->torque_clip,
+       torques, wt, &guiding);
+  if (c->eval_sums) {
+    /* KAMMA_eval.py:677-685. old_torques = the previous step's clipped torques, which
+     * still sit in the wheel_torqs buffer; sums_c[3] != 0 marks them valid (the reference
+     * zeroes old_torques in reset_idx, KAMMA_eval.py:470 — for ALL arenas at once, which
+     * only ever ran with numEnvs = 1; here the zeroing is per arena, docs/SPEC.md §2.9) */
+    const float* old = &e->wheel_torqs[4 * i];
+    float o0 = sc[3] != 0.0f ? old[0] : 0.0f, o1 = sc[3] != 0.0f ? old[1] : 0.0f;
+    float o2 = sc[3] != 0.0f ? old[2] : 0.0f, o3 = sc[3] != 0.0f ? old[3] : 0.0f;
+    float d0 = o0 - wt[0], d1 = o1 - wt[1], d2 = o2 - wt[2], d3 = o3 - wt[3];
+    sc[0] += ((d0 * d0 + d1 * d1) + (d2 * d2 + d3 * d3)) / 10.0f;
+    sc[2] += desired_v / 10.0f;
+    sc[3] = 1.0f; /* old_torques valid */
+  }
+  for (int k = 0; k < 4; ++k) e->wheel_torqs[4 * i + k] = wt[k];
+
+  /* ---- physics: decimation substeps (:646-653) + controlFrequencyInv substeps (:43) ---- */
+  float p[3] = {P[0], P[1], P[2]}, q[4] = {Q[0], Q[1], Q[2], Q[3]};
+  float v[3] = {V[0], V[1], V[2]}, w[3] = {W[0], W[1], W[2]};
+  float n[3] = {prm[1], prm[2], prm[3]};
+  float mu = prm[0];
+  float R[9], wb[3], spin[4];
+  rotmat(q, R);
+  rotT(R, w, wb);
+  for (int k = 0; k < 4; ++k) spin[k] = JV[k] + wb[1];
+  int nsub = c->decimation + c->extra_substeps;
+  float* LN = &e->lam_n[4 * i];
+  float* LL = &e->lam_l[4 * i];
+  float* LT = &e->lam_t[4 * i];
+  for (int s = 0; s < nsub; ++s) substep(D, mu, n, wt, p, q, v, w, spin, LN, LL, LT);
+  rotmat(q, R);
+  rotT(R, w, wb);
+  float jv[4];
+  for (int k = 0; k < 4; ++k) jv[k] = spin[k] - wb[1];
+
+  /* ---- post_physics_step (:674-727) ---- */
+  cnt[0] += 1; /* episode_buf :675 */
+  cnt[1] += 1; /* sim_steps   :676 */
+  /* base-link position for the bounds check */
+  float plink[3] = {fmaf(-R[2], c->com_height, p[0]), fmaf(-R[5], c->com_height, p[1]), fmaf(-R[8], c->com_height, p[2])};
+  uint8_t reset, timeout;
+  is_done1(cnt[0], c->max_episode_length, q, plink, c->bounds, &reset, &timeout); /* :687 */
+  float S[8] = {sa[0], sa[1], sa[2], sa[3], sb[0], sb[1], sb[2], sb[3]};
+  float prev_lin = V[3], prev_ang = W[3];
+  metrics_out mo;
+  metrics1(current_v, w[2], &prev_lin, &prev_ang, v_delta, omega_delta, wt, guiding, gamma2, reset, timeout,
+           c->policy_dt, c->w1, c->w2, c->w3, c->sparse_bonus, c->sparse_threshold, c->terminal_reward, S, &mo); /* :689 */
+  for (int k = 0; k < 4; ++k) { sa[k] = S[k]; sb[k] = S[4 + k]; }
+  if (c->eval_sums) sc[1] += fabsf(v_delta) / 10.0f; /* KAMMA_eval.py:840 */
+  /* write back the post-physics state (reset_arena overwrites it if the arena resets) */
+  P[0] = p[0]; P[1] = p[1]; P[2] = p[2];
+  Q[0] = q[0]; Q[1] = q[1]; Q[2] = q[2]; Q[3] = q[3];
+  V[0] = v[0]; V[1] = v[1]; V[2] = v[2]; V[3] = prev_lin;
+  W[0] = w[0]; W[1] = w[1]; W[2] = w[2]; W[3] = prev_ang;
+  for (int k = 0; k < 4; ++k) JV[k] = jv[k];
+  rs[i] = reset;
+  if (reset) reset_arena(e, i, (uint32_t)cnt[1], gamma2, &rc[i]); /* :691-693 */
+  /* get_observations (:825-833): desired_* are views of commands -> post-reset values */
+  float o[6] = {CMD[0], CMD[2], v_delta, omega_delta, mo.lin_acc, mo.ang_acc};
+  for (int k = 0; k < 6; ++k) e->obs[6 * i + k] = clipf(o[k], -c->clip_obs, c->clip_obs); /* rl_task.py:99 clamp in the VecEnv */
+  e->rew[i] = mo.rew;
+  e->done[i] = reset;
+  e->timeout[i] = timeout;
+  /* tail of post_physics_step (:701-710) on the (possibly reset) state */
+  P[3] = forward_projection1(Q, V);
+  if (i == 0) {
+    float* d = e->env0_diag; /* KAMMA.py:840-867 ingredients */
+    d[0] = CMD[0]; d[1] = current_v; d[2] = CMD[2]; d[3] = current_omega; d[4] = v_delta; d[5] = omega_delta;
+    d[6] = mo.lin_acc; d[7] = mo.ang_acc; d[8] = (float)cnt[2];
+    for (int k = 0; k < 4; ++k) { d[9 + k] = torques[k]; d[15 + k] = c->action_scale * a4[k]; }
+    d[13] = ac_left; d[14] = ac_right;
+    d[19] = gamma2; d[20] = mo.comp1; d[21] = mo.comp2; d[22] = mo.comp3; d[23] = mo.rdense; d[24] = mo.rsparse;
+    d[25] = mo.robs; d[26] = guiding; d[27] = mo.rew; d[28] = gamma1;
+  }
+  *g1_out = gamma1; *g2_out = gamma2;
+  return mo.rew;
+}
+
+static int step_all(orc_env* e, int policy, const float* actions, float* reward_sum, reset_contrib* rc, uint8_t* rs) {
+  const int N = e->N, A = e->cfg.action_dim, G = e->G;
+  int32_t stamp = e->counters[1] + 1; /* sim_steps after this step (identical for all arenas) */
+#ifdef _OPENMP
+#pragma omp parallel for schedule(static) num_threads(e->threads)
+#endif
+  for (int g = 0; g < G; ++g) {
+    int base = g * GROUP;
+    int n = N - base < GROUP ? N - base : GROUP;
+    float lg1 = 0.0f, lg2 = 0.0f;
+    for (int j = 0; j < n; ++j) {
+      int i = base + j;
+      float a[4] = {0, 0, 0, 0};
+      if (policy == OIS_POLICY_EXTERNAL) {
+        for (int k = 0; k < A; ++k) a[k] = actions[(size_t)i * A + k];
+      } else if (policy == OIS_POLICY_RANDOM) {
+        float u[4];
+        draw4(e->seed, e->cfg.arena_offset + i, (uint32_t)e->counters[4 * i + 1], PURPOSE_ACTION, u);
+        for (int k = 0; k < A; ++k) a[k] = u[k];
+      }
+      float r = step_arena(e, i, a, rs, rc, &lg1, &lg2);
+      if (reward_sum) reward_sum[i] += r;
+    }
+    group_reduce(e, g, rs, rc, stamp, lg1, lg2, 1);
+  }
+  e->steps_done += (double)N;
+  return OIS_OK;
+}
+
+int orc_step(orc_env* e, const float* actions) {
+  if (!e || !actions) return fail(OIS_EINVAL, "null argument");
+  if (!e->reset_done) return fail(OIS_ESTATE, "orc_step before orc_reset");
+  reset_contrib* rc = (reset_contrib*)malloc((size_t)e->N * sizeof *rc);
+  uint8_t* rs = (uint8_t*)calloc((size_t)e->N, 1);
+  if (!rc || !rs) { free(rc); free(rs); return fail(OIS_ENOMEM, "host alloc"); }
+  int r = step_all(e, OIS_POLICY_EXTERNAL, actions, NULL, rc, rs);
+  free(rc); free(rs);
+  return r;
+}
+
+int orc_rollout(orc_env* e, int k, int policy, const float* actions, float* reward_sum) {
+  if (!e || k < 1) return fail(OIS_EINVAL, "bad argument");
+  if (policy == OIS_POLICY_EXTERNAL && !actions) return fail(OIS_EINVAL, "EXTERNAL policy needs actions");
+  if (policy < 0 || policy > 2) return fail(OIS_EINVAL, "unknown policy");
+  if (!e->reset_done) return fail(OIS_ESTATE, "orc_rollout before orc_reset");
+  reset_contrib* rc = (reset_contrib*)malloc((size_t)e->N * sizeof *rc);
+  uint8_t* rs = (uint8_t*)calloc((size_t)e->N, 1);
+  if (!rc || !rs) { free(rc); free(rs); return fail(OIS_ENOMEM, "host alloc"); }
+  if (reward_sum) memset(reward_sum, 0, (size_t)e->N * sizeof(float));
+  for (int s = 0; s < k; ++s) {
+    const float* a = policy == OIS_POLICY_EXTERNAL ? actions + (size_t)s * e->N * e->cfg.action_dim : NULL;
+    memset(rs, 0, (size_t)e->N);
+    step_all(e, policy, a, reward_sum, rc, rs);
+  }
+  free(rc); free(rs);
+  return OIS_OK;
+}
+
+/* extras["episode"] (KAMMA.py:480-488) from the most recent reset event */
+int orc_episode_info(orc_env* e) {
+  if (!e) return fail(OIS_EINVAL, "null env");
+  int32_t smax = -1;
+  for (int g = 0; g < e->G; ++g) smax = e->stamps[g] > smax ? e->stamps[g] : smax;
+  float acc[PART_STRIDE];
+  memset(acc, 0, sizeof acc);
+  int first = 1;
+  for (int g = 0; g < e->G; ++g) {
+    if (e->stamps[g] != smax) continue;
+    const float* P = &e->partials[(size_t)g * PART_STRIDE];
+    for (int k = 0; k < 16; ++k) acc[k] += P[k];
+    acc[P_SM] += P[P_SM]; acc[P_TE] += P[P_TE]; acc[P_DV] += P[P_DV];
+    if (first) { acc[P_G1] = P[P_G1]; acc[P_G2] = P[P_G2]; first = 0; }
+  }
+  float* I = e->episode_info;
+  memset(I, 0, sizeof e->episode_info);
+  float cntf = acc[OIS_EI_COUNT];
+  I[OIS_EI_COUNT] = cntf;
+  float L = e->cfg.episode_length_s;
+  for (int k = OIS_EI_R1; k <= OIS_EI_OBSERVED_OVER_FINAL; ++k) I[k] = (acc[k] / cntf) / L; /* :482-484 */
+  I[OIS_EI_GAMMA1] = acc[P_G1];   /* :486 mean of N identical values */
+  I[OIS_EI_GAMMA2] = acc[P_G2];   /* :487 */
+  I[OIS_EI_TERRAIN_LEVEL] = 0.0f; /* :488 terrain_levels are zeros (:223) */
+  I[OIS_EI_STEP] = (float)smax;
+  I[OIS_EI_SMOOTHNESS] = (acc[P_SM] / cntf) / L;
+  I[OIS_EI_TRACKING_ERROR] = (acc[P_TE] / cntf) / L;
+  I[OIS_EI_DESIRED_VELOCITY] = (acc[P_DV] / cntf) / L;
+  return OIS_OK;
+}
+
+int orc_stats_fetch(orc_env* e, ois_stats* out, int reset_after) {
+  if (!e || !out) return fail(OIS_EINVAL, "null argument");
+  float cnt = 0, ret = 0, ret2 = 0, len = 0, mn = INFINITY, mx = -INFINITY;
+  for (int g = 0; g < e->G; ++g) {
+    const float* A = &e->stat_acc[(size_t)g * ST_STRIDE];
+    cnt += A[ST_COUNT]; ret += A[ST_RET]; ret2 += A[ST_RET2]; len += A[ST_LEN];
+    mn = fminf(mn, A[ST_RMIN]); mx = fmaxf(mx, A[ST_RMAX]);
+  }
+  out->episodes = cnt; out->return_sum = ret; out->return_sqsum = ret2; out->return_min = mn;
+  out->return_max = mx; out->length_sum = len; out->steps = e->steps_done; out->reserved = 0.0;
+  if (reset_after) stats_clear(e);
+  return OIS_OK;
+}
+
+/* per-arena domain randomisation (BASELINE.json config 4) */
+int orc_randomize_params(orc_env* e, float mu_lo, float mu_hi, const float* slopes, int n_slopes) {
+  if (!e) return fail(OIS_EINVAL, "null env");
+  if (n_slopes < 0 || (n_slopes > 0 && !slopes)) return fail(OIS_EINVAL, "bad slopes");
+  for (int i = 0; i < e->N; ++i) {
+    float u[4];
+    draw4(e->cfg.seed, e->cfg.arena_offset + i, 0u, PURPOSE_PARAMS, u);
+    float* prm = &e->params[4 * i];
+    prm[0] = rand_float(mu_lo, mu_hi, u[0]);
+    float nx = 0.0f, ny = 0.0f, nz = 1.0f;
+    if (n_slopes > 0) {
+      int idx = (int)(u[1] * (float)n_slopes);
+      if (idx >= n_slopes) idx = n_slopes - 1;
+      float sl = slopes[idx];
+      float s, c;
+      orc_sincos(3.14159274101257324f * u[2], &s, &c); /* heading in [0, pi); sign of the slope covers the rest */
+      float inv = 1.0f / sqrtf(fmaf(sl, sl, 1.0f));
+      nx = -(sl * c) * inv; ny = -(sl * s) * inv; nz = inv;
+    }
+    prm[1] = nx; prm[2] = ny; prm[3] = nz;
+  }
+  return OIS_OK;
+}

@@ -1,0 +1,106 @@
+/*
+ * ois_oracle.h — CPU ORACLE (test infrastructure, NOT product code).
+ *
+ * A scalar, one-arena-at-a-time float32 restatement of the hot path of
+ * meesjansen/Options_In_Simulation (src/my_envs/KAMMA.py and variants) plus the
+ * build-defined rigid-body model of docs/SPEC.md §3. Only tests/, bench.py's
+ * cpu_baseline leg and __graft_entry__.smoke() may load this library; the product
+ * (options_in_simulation_amd/) never does.
+ *
+ * PARITY STATUS
+ *   - reference-followed math (controller, gamma, mixing, clip, termination, reward,
+ *     reset, observation, projections): pinned against tests/golden/refmath_*.npz, which
+ *     are produced by tests/golden/make_golden.py — a torch-CPU transcription of the
+ *     cited KAMMA.py lines written in this repo (the reference module itself cannot be
+ *     imported: it needs Isaac Sim / gym / pxr, plain ModuleNotFoundError).
+ *   - physics (PhysX 5 inside Isaac Sim 4.0.0, not in /root/reference, no golden vectors
+ *     anywhere in the reference): PARITY UNPINNED. The model is defined by docs/SPEC.md §3;
+ *     parity is oracle <-> HIP kernel only.
+ *   - RNG: Philox4x32-10 (Salmon et al., SC'11; Random123 v1.14 known-answer vectors are
+ *     checked in tests/test_oracle_rng.py). The reference uses torch's global generator,
+ *     which cannot be reproduced counter-for-counter; draw ORDER follows KAMMA.py.
+ *
+ * The config struct is the product ABI's (include/ois.h) so that one dict drives both.
+ */
+#ifndef OIS_ORACLE_H_
+#define OIS_ORACLE_H_
+
+#include <stddef.h>
+#include <stdint.h>
+
+#include "../include/ois.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct orc_env orc_env;
+
+/* ---- environment-level API (mirrors ois_* but on host memory) ---- */
+int orc_create(const ois_config* cfg, orc_env** out);
+void orc_destroy(orc_env* env);
+int orc_reset(orc_env* env, uint64_t seed);
+/* actions: float [N, action_dim] host */
+int orc_step(orc_env* env, const float* actions);
+/* policy: OIS_POLICY_*; actions [k,N,A] for EXTERNAL; reward_sum [N] optional */
+int orc_rollout(orc_env* env, int k, int policy, const float* actions, float* reward_sum);
+int orc_randomize_params(orc_env* env, float mu_lo, float mu_hi, const float* slopes, int n_slopes);
+/* number of OpenMP threads used by orc_step/orc_rollout (1 = scalar). */
+int orc_set_threads(orc_env* env, int threads);
+
+/* host pointer to a buffer with the SAME id / shape / dtype as ois_buffer() */
+int orc_buffer(orc_env* env, int id, void** ptr, size_t* bytes);
+int orc_episode_info(orc_env* env);               /* fills OIS_BUF_EPISODE_INFO */
+int orc_stats_fetch(orc_env* env, ois_stats* out, int reset_after);
+const char* orc_last_error(void);
+
+/* ---- unit-level API: the reference-followed formulas, one call per SURVEY §8a row,
+ *      array-in / array-out so the golden fixtures can be replayed ---- */
+
+/* a2: criteria controller, KAMMA.py:604-624 */
+void orc_criteria(int n, const float* cmd_x, const float* cmd_yaw, const float* v_fwd_prev,
+                  const float* omega_z, float Kp, float Kp_omega, float mass, float inertia,
+                  float dt, float* v_delta, float* omega_delta, float* ac_left, float* ac_right);
+/* a3: gamma schedule, KAMMA.py:627-628 */
+void orc_gamma(int n, const int32_t* sim_steps, float max_sim_steps, float* gamma);
+/* a4: stochastic switch KAMMA.py:632-636 (rand given) / blend KA_DDPG_4D.py:627-631;
+ *     a5 clip KAMMA.py:649; guiding reward KAMMA.py:656 / KA_DDPG_4D.py:637 */
+void orc_mix(int n, int mix_mode, int guiding_mode, const float* actions4, const float* ac_left,
+             const float* ac_right, const float* gamma1, const float* rand01, float action_scale,
+             float clip, float* torques4, float* wheel_torqs4, float* guiding);
+/* a7: is_done, KAMMA.py:736-764 */
+void orc_is_done(int n, const int32_t* episode_buf, int max_episode_length, const float* quat4,
+                 const float* pos3, float bounds, uint8_t* reset, uint8_t* timeout);
+/* a8: calculate_metrics, KAMMA.py:767-822. sums8 is updated in place, prev_lin/prev_ang too */
+void orc_metrics(int n, const float* v_fwd_prev, const float* omega_z, float* prev_lin,
+                 float* prev_ang, const float* v_delta, const float* omega_delta,
+                 const float* wheel_torqs4, const float* guiding, const float* gamma2,
+                 const uint8_t* reset, const uint8_t* timeout, float dt, float w1, float w2,
+                 float w3, float sparse_bonus, float sparse_thr, float terminal_reward,
+                 float* lin_acc, float* ang_acc, float* rew, float* sums8);
+/* a11: forward-velocity projection, KAMMA.py:701-710 */
+void orc_forward_projection(int n, const float* quat4, const float* linvel3, float* v_fwd);
+/* quat helpers as used by the reference (omni.isaac.core.utils.torch.rotations, wxyz) */
+void orc_quat_apply(const float q[4], const float v[3], float out[3]);
+void orc_quat_mul(const float a[4], const float b[4], float out[4]);
+/* a9: the pose/command part of reset_idx for one arena given its 8 uniform draws
+ *     (order: pos x, pos y, yaw, cmd x, cmd y, cmd heading, x re-draw, discarded omega) */
+void orc_reset_draws(const ois_config* cfg, const float u[8], float pos3[3], float quat4[4],
+                     float commands4[4]);
+
+/* RNG + deterministic trig */
+void orc_philox4x32_10(const uint32_t ctr[4], const uint32_t key[2], uint32_t out[4]);
+float orc_u01(uint32_t x);
+void orc_sincos(float x, float* s, float* c);
+
+/* one physics substep for one arena (docs/SPEC.md §3); exposed for physics unit tests.
+ * state: p[3], q[4], v[3], w[3] (world), spin[4] (absolute wheel spin about body y),
+ * lam_*[4]: accumulated normal / longitudinal / lateral contact impulses (warm start) */
+void orc_substep(const ois_config* cfg, float mu, const float n_world[3], const float tau[4],
+                 float p[3], float q[4], float v[3], float w[3], float spin[4], float lam_n[4],
+                 float lam_l[4], float lam_t[4]);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,161 @@
+"""HIP kernel vs CPU oracle through the C ABI, same seeded inputs (-m gpu).
+
+Tolerance: BASELINE.json north_star asks 1e-5 relative for floats and bit-exact masks /
+counters. The kernel and the oracle spell the same float32 operation order (explicit fma,
+-ffp-contract=off), so most checks here are in fact exact; where a test says rtol it is the
+north_star's 1e-5.
+"""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+torch = pytest.importorskip("torch")
+
+from options_in_simulation_amd import _abi, build_config  # noqa: E402
+
+STATE_BUFS = [_abi.BUF_POSE, _abi.BUF_QUAT, _abi.BUF_LINVEL, _abi.BUF_ANGVEL, _abi.BUF_WHEEL_VEL,
+              _abi.BUF_COMMANDS, _abi.BUF_SUMS_A, _abi.BUF_SUMS_B, _abi.BUF_LAMBDA_N, _abi.BUF_LAMBDA_L,
+              _abi.BUF_LAMBDA_T, _abi.BUF_WHEEL_TORQS, _abi.BUF_OBS, _abi.BUF_REW]
+EXACT_BUFS = [_abi.BUF_COUNTERS, _abi.BUF_DONE, _abi.BUF_TIMEOUT]
+RTOL, ATOL = 1e-5, 1e-6
+
+
+def make_pair(**kw):
+    from options_in_simulation_amd.vecenv import NativeEnv
+    from oracle.binding import OracleEnv
+    cfg = build_config(**kw)
+    return cfg, NativeEnv(cfg, "cuda:0"), OracleEnv(cfg)
+
+
+def compare(dev, orc, where="", exact_float=False):
+    torch.cuda.synchronize()
+    for bid in EXACT_BUFS:
+        got = dev.buffer(bid).cpu().numpy()
+        if got.dtype == np.bool_:
+            got = got.astype(np.uint8)
+        assert np.array_equal(got, orc.buffer(bid)), f"{where}: buffer {bid} differs (must be bit-exact)"
+    worst = 0.0
+    for bid in STATE_BUFS:
+        got, ref = dev.buffer(bid).cpu().numpy(), orc.buffer(bid)
+        if exact_float:
+            assert np.array_equal(got, ref, equal_nan=True), f"{where}: buffer {bid} not bit-identical"
+        np.testing.assert_allclose(got, ref, rtol=RTOL, atol=ATOL, err_msg=f"{where}: buffer {bid}")
+        worst = max(worst, float(np.max(np.abs(got - ref))) if got.size else 0.0)
+    return worst
+
+
+@pytest.mark.parametrize("variant", ["KAMMA_medium", "KA_DDPG_4D", "KA_DDPG_2D", "KA_DDPG_1D", "KAMMA_eval",
+                                     "KAMMA_curr1", "KAMMA_g1d_g21"])
+def test_step_parity_variants(variant):
+    N = 200  # not a multiple of 16: ragged last wave
+    cfg, dev, orc = make_pair(variant=variant, num_envs=N, seed=11, max_sim_steps=60.0)
+    dev.reset(11); orc.reset(11)
+    compare(dev, orc, f"{variant} after reset", exact_float=True)
+    rng = np.random.default_rng(0)
+    lo = -1.0 if variant.startswith("KA_DDPG") else 0.0
+    for t in range(12):
+        a = rng.uniform(lo, 1.0, size=(N, cfg.action_dim)).astype(np.float32)
+        dev.step(torch.from_numpy(a).cuda()); orc.step(a)
+        compare(dev, orc, f"{variant} step {t}", exact_float=True)
+
+
+def test_long_rollout_with_resets_and_extras():
+    """250 steps: two timeouts (99-step episodes), extras['episode'] and episode statistics."""
+    N = 333
+    cfg, dev, orc = make_pair(variant="KAMMA_medium", num_envs=N, seed=3, max_sim_steps=300.0)
+    dev.reset(3); orc.reset(3)
+    rng = np.random.default_rng(5)
+    for t in range(250):
+        a = rng.uniform(0, 1, size=(N, 4)).astype(np.float32)
+        dev.step(torch.from_numpy(a).cuda()); orc.step(a)
+        if t % 50 == 49 or t in (98, 99, 197, 198):
+            compare(dev, orc, f"step {t}", exact_float=True)
+            ei = dev.episode_info().cpu().numpy()
+            np.testing.assert_allclose(ei, orc.episode_info(), rtol=RTOL, atol=ATOL, equal_nan=True)
+    sd, so = dev.stats(), orc.stats()
+    for f in ("episodes", "return_sum", "return_sqsum", "return_min", "return_max", "length_sum", "steps"):
+        assert getattr(sd, f) == pytest.approx(getattr(so, f), rel=RTOL), f
+    assert sd.episodes == 2 * N
+
+
+def test_fused_rollout_equals_single_steps_and_oracle():
+    N, K = 512, 40
+    cfg, dev, orc = make_pair(variant="KAMMA_eval", num_envs=N, seed=9)
+    dev.reset(9); orc.reset(9)
+    rs = torch.zeros(N, device="cuda")
+    dev.rollout(K, _abi.POLICY_RANDOM, reward_sum=rs)
+    ro = orc.rollout(K, _abi.POLICY_RANDOM, want_reward_sum=True)
+    compare(dev, orc, "random-policy rollout", exact_float=True)
+    np.testing.assert_allclose(rs.cpu().numpy(), ro, rtol=RTOL, atol=ATOL)
+    acts = torch.rand((K, N, 4), generator=torch.Generator().manual_seed(1))
+    dev.rollout(K, _abi.POLICY_EXTERNAL, actions=acts.cuda())
+    for k in range(K):
+        orc.step(acts[k].numpy())
+    compare(dev, orc, "external-policy rollout vs k single steps", exact_float=True)
+    dev.rollout(3, _abi.POLICY_ZERO); orc.rollout(3, _abi.POLICY_ZERO)
+    compare(dev, orc, "zero-policy rollout", exact_float=True)
+
+
+def test_domain_randomisation_parity():
+    N = 1000
+    cfg, dev, orc = make_pair(variant="KAMMA_g11_g21", num_envs=N, seed=21)
+    slopes = [-0.3, -0.2, 0.0, 0.2, 0.3]  # origin_terrain_generator.py:92
+    dev.randomize_params(0.5, 1.0, slopes); orc.randomize_params(0.5, 1.0, slopes)
+    torch.cuda.synchronize()
+    assert np.array_equal(dev.buffer(_abi.BUF_PARAMS).cpu().numpy(), orc.buffer(_abi.BUF_PARAMS))
+    dev.reset(21); orc.reset(21)
+    z = np.zeros((N, 4), np.float32)
+    for t in range(30):
+        dev.step(torch.from_numpy(z).cuda()); orc.step(z)
+    compare(dev, orc, "sloped arenas, expert controller", exact_float=True)
+
+
+def test_sharding_invariance():
+    """arena i gets the same stream whether it lives in a 1-GPU env or in shard 1 of 2."""
+    from options_in_simulation_amd.vecenv import NativeEnv
+    N = 256
+    full = NativeEnv(build_config(variant="KAMMA_medium", num_envs=N, seed=5), "cuda:0")
+    half = NativeEnv(build_config(variant="KAMMA_medium", num_envs=N // 2, seed=5, arena_offset=N // 2), "cuda:0")
+    full.reset(5); half.reset(5)
+    a = torch.rand((N, 4), device="cuda")
+    for _ in range(5):
+        full.step(a); half.step(a[N // 2:])
+    torch.cuda.synchronize()
+    for bid in STATE_BUFS + EXACT_BUFS:
+        assert torch.equal(full.buffer(bid)[N // 2:] if full.buffer(bid).shape[0] == N else full.buffer(bid),
+                           half.buffer(bid) if half.buffer(bid).shape[0] == N // 2 else full.buffer(bid))
+
+
+def test_save_load_state_roundtrip():
+    N = 128
+    cfg, dev, orc = make_pair(variant="KAMMA_medium", num_envs=N, seed=2)
+    dev.reset(2)
+    a = torch.rand((N, 4), device="cuda")
+    for _ in range(4):
+        dev.step(a)
+    blob = dev.save_state()
+    for _ in range(6):
+        dev.step(a)
+    ref = {b: dev.buffer(b).clone() for b in STATE_BUFS + EXACT_BUFS}
+    dev.load_state(blob)
+    for _ in range(6):
+        dev.step(a)
+    torch.cuda.synchronize()
+    for b, t in ref.items():
+        assert torch.equal(dev.buffer(b), t)
+
+
+def test_error_paths():
+    from options_in_simulation_amd.vecenv import NativeEnv
+    cfg = build_config(variant="KAMMA_medium", num_envs=8)
+    env = NativeEnv(cfg, "cuda:0")
+    with pytest.raises(RuntimeError, match="before ois_reset"):
+        env.step(torch.zeros((8, 4), device="cuda"))
+    env.reset(1)
+    with pytest.raises(ValueError):
+        env.step(torch.zeros((7, 4), device="cuda"))
+    bad = build_config(variant="KAMMA_medium", num_envs=8)
+    bad.action_dim = 3
+    with pytest.raises(ValueError):
+        NativeEnv(bad, "cuda:0")
