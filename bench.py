@@ -41,12 +41,25 @@ def build_actor(torch, device):
     return net.to(device).eval()
 
 
+def usable_cores():
+    """threads the CPU baseline may use: the cgroup CPU quota when there is one, otherwise the
+    affinity mask capped at the GPU box's per-GPU CPU share (16)."""
+    n = len(os.sched_getaffinity(0))
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
+        if quota != "max":
+            n = min(n, max(1, int(int(quota) / int(period))))
+    except (OSError, ValueError):
+        pass
+    return max(1, min(n, int(os.environ.get("OIS_CPU_THREADS", "16"))))
+
+
 def cpu_baseline(n_arenas, seconds_target=12.0):
     """time the oracle on the host cores: same task, same actor-free step (random actions)."""
     import numpy as np
     from options_in_simulation_amd import _abi, build_config
     from oracle.binding import OracleEnv
-    cores = len(os.sched_getaffinity(0))
+    cores = usable_cores()
     n = min(n_arenas, 4096)
     env = OracleEnv(build_config(variant="KAMMA_medium", num_envs=n, seed=42), threads=cores)
     env.reset(42)

@@ -34,6 +34,11 @@ def load() -> C.CDLL:
     global _lib
     if _lib is not None:
         return _lib
+    # Load order matters: torch ships its own libamdhip64 (SONAME libamdhip64.so.7, found via
+    # its RPATH). Importing torch first makes the dynamic linker resolve this library's
+    # NEEDED libamdhip64.so.7 to that already-loaded runtime, so streams and device pointers
+    # handed over by PyTorch belong to the same HIP runtime instance.
+    import torch  # noqa: F401
     if not os.path.exists(LIB_PATH):
         raise NativeLibraryError(
             f"{LIB_PATH} not found. Build it with `python -c 'import __graft_entry__ as g; g.build()'` "

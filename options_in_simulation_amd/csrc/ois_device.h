@@ -1,16 +1,21 @@
 // ois_device.h — device-side building blocks of the fused skid-steer step kernel (gfx950).
 //
-// Execution shape ("quad layout"): 4 consecutive lanes = one arena, lane (tid & 3) = one
-// wheel / one ground contact, in the env's wheel order fl, rl, fr, rr (KAMMA.py:157, 623).
-// A wave64 therefore carries 16 arenas. Chassis quantities are replicated in the 4 lanes
-// of a quad; per-wheel quantities (torque, spin, contact impulses) live in their lane.
-// Cross-wheel sums are DPP quad_perm adds (no LDS, no ds_bpermute), cross-arena sums are
-// wave butterflies. Every array in HBM is [N][4] so that lane tid reads element tid:
-// each wave-level load/store instruction moves 256 contiguous bytes.
+// Execution shape: ONE ARENA PER LANE. A lane owns the chassis and all four wheel contacts of
+// its arena; the four contacts are four independent instruction streams inside the lane
+// (mass-splitting Jacobi, docs/SPEC.md §3.5), which gives the in-order SIMD the
+// instruction-level parallelism a single dependent fma chain lacks. Measured on MI355X
+// (tools/valu_rate.hip, profiles/r1_valu_rate.txt): independent v_fma_f32 issue every
+// ~1.13 ns per SIMD, a dependent chain every ~1.4-1.9 ns, a quad_perm DPP add every ~2.7 ns,
+// v_pk_fma_f32 every ~1.9 ns (no gain over two scalar fmas). An earlier layout with one wheel
+// per lane (4 lanes per arena, DPP quad sums) replicated the chassis math four times and paid
+// 62 DPP adds per substep: 88 us per 65 536-arena step against this layout's.
+//
+// Memory: every state array in HBM is [N][4] floats, so a lane reads its arena's row with one
+// 16-byte global_load_dwordx4 and a wave-level instruction moves 1 KiB of contiguous bytes.
 //
 // Floating point: float32, operation order fixed by docs/SPEC.md; every fused multiply-add
-// is an explicit __builtin_fmaf and the file is compiled with -ffp-contract=off, so results
-// are bit-identical to the CPU oracle's.
+// is an explicit __builtin_fmaf and the file is compiled with -ffp-contract=off
+// -fno-slp-vectorize, so results are bit-identical to the CPU oracle's.
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
@@ -20,6 +25,8 @@
 namespace ois {
 
 #define OIS_DEV __device__ __forceinline__
+
+constexpr int kGroup = 16;  // arenas per reduction group of the reset-event records (SPEC §2.10)
 
 // ---------------------------------------------------------------- kernel constants ----
 struct DevConsts {
@@ -41,43 +48,19 @@ struct DevConsts {
 
 // device pointers of one environment ([N][4] unless noted)
 struct DevBuffers {
-  float *pose, *quat, *linvel, *angvel, *wheel_vel, *commands, *sums_a, *sums_b, *sums_c, *params,
+  float4 *pose, *quat, *linvel, *angvel, *wheel_vel, *commands, *sums_a, *sums_b, *sums_c, *params,
       *lam_n, *lam_l, *lam_t, *wheel_torqs;
-  int32_t* counters;
+  int4* counters;
   float* obs;        // [N][6]
   float* rew;        // [N]
   uint8_t* done;     // [N]
   uint8_t* timeout;  // [N]
-  float* partials;   // [nwaves][32] per-wave reset-event records
-  int32_t* stamps;   // [nwaves]
-  float* stat_acc;   // [nwaves][8]
+  float* partials;   // [ngroups][32] per-group reset-event records
+  int32_t* stamps;   // [ngroups]
+  float* stat_acc;   // [ngroups][8]
   float* episode_info;  // [32]
   float* env0_diag;     // [32]
 };
-
-// ---------------------------------------------------------------- cross-lane ----------
-template <int CTRL>
-OIS_DEV float dpp(float x) {
-  return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x), CTRL, 0xF, 0xF, true));
-}
-template <int CTRL>
-OIS_DEV int dppi(int x) {
-  return __builtin_amdgcn_update_dpp(0, x, CTRL, 0xF, 0xF, true);
-}
-// (x0 + x1) + (x2 + x3) in every lane of the quad, bitwise identical in the 4 lanes
-OIS_DEV float quad_sum(float x) {
-  float s = x + dpp<0xB1>(x);  // quad_perm [1,0,3,2]
-  return s + dpp<0x4E>(s);     // quad_perm [2,3,0,1]
-}
-template <int K>
-OIS_DEV float quad_bcast(float x) { return dpp<K * 0x55>(x); }
-template <int K>
-OIS_DEV int quad_bcasti(int x) { return dppi<K * 0x55>(x); }
-// component `w` of (a,b,c,d)
-OIS_DEV float sel4(int w, float a, float b, float c, float d) {
-  float lo = (w & 1) ? b : a, hi = (w & 1) ? d : c;
-  return (w & 2) ? hi : lo;
-}
 
 // ---------------------------------------------------------------- RNG -----------------
 // Philox4x32-10 (Salmon et al., SC'11; Random123 constants)
@@ -156,12 +139,12 @@ OIS_DEV void rotmat(const float q[4], float R[9]) {
   R[3] = xy + wz;          R[4] = 1.0f - (xx + zz); R[5] = yz - wx;
   R[6] = xz - wy;          R[7] = yz + wx;          R[8] = 1.0f - (xx + yy);
 }
-OIS_DEV void rotT(const float R[9], const float a[3], float o[3]) {
+OIS_DEV void rotT(const float R[9], const float a[3], float o[3]) {  // o = R^T a
   o[0] = __builtin_fmaf(R[6], a[2], __builtin_fmaf(R[3], a[1], R[0] * a[0]));
   o[1] = __builtin_fmaf(R[7], a[2], __builtin_fmaf(R[4], a[1], R[1] * a[0]));
   o[2] = __builtin_fmaf(R[8], a[2], __builtin_fmaf(R[5], a[1], R[2] * a[0]));
 }
-OIS_DEV void rot(const float R[9], const float a[3], float o[3]) {
+OIS_DEV void rot(const float R[9], const float a[3], float o[3]) {  // o = R a
   o[0] = __builtin_fmaf(R[2], a[2], __builtin_fmaf(R[1], a[1], R[0] * a[0]));
   o[1] = __builtin_fmaf(R[5], a[2], __builtin_fmaf(R[4], a[1], R[3] * a[0]));
   o[2] = __builtin_fmaf(R[8], a[2], __builtin_fmaf(R[7], a[1], R[6] * a[0]));
@@ -169,9 +152,8 @@ OIS_DEV void rot(const float R[9], const float a[3], float o[3]) {
 
 OIS_DEV float clipf(float x, float lo, float hi) { return fminf(fmaxf(x, lo), hi); }
 
-// ---------------------------------------------------------------- per-lane state ------
-struct Lane {
-  // chassis (replicated across the quad)
+// ---------------------------------------------------------------- per-arena state -----
+struct Arena {
   float p[3], vfwd;      // COM position, v_forward_projected of the previous step
   float q[4];
   float v[3], prev_lin;  // world linear velocity, previous_linear_velocity[:,0]
@@ -179,134 +161,11 @@ struct Lane {
   float cmd[4];
   int ep_buf, sim_steps, ep_count;
   float mu, n[3];
-  // per wheel (this lane's wheel)
-  float jv;              // joint velocity (dof_vel)
-  float ln, l1, l2;      // cached contact impulses
-  float wt;              // clipped torque of this wheel (wheel_torqs)
-  // lane-distributed episode sums: lane k holds component k of each float4 group
-  float sa, sb, sc;
+  float jv[4];                  // wheel joint velocities (dof_vel), order fl, rl, fr, rr
+  float ln[4], l1[4], l2[4];    // cached contact impulses per wheel
+  float wt[4];                  // clipped wheel torques (wheel_torqs)
+  float sa[4], sb[4], sc[4];    // episode sums: r1 r2 r3 dense | sparse guiding observed final | eval
 };
-
-// One physics substep (docs/SPEC.md §3) for this lane's wheel. spin = absolute wheel spin.
-OIS_DEV void substep(const DevConsts& K, int wl, float cx, float cy, Lane& S, float& spin) {
-  float R[9];
-  rotmat(S.q, R);
-  float vb[3], wb[3], nb[3];
-  rotT(R, S.v, vb);
-  rotT(R, S.w, wb);
-  rotT(R, S.n, nb);
-  vb[0] = __builtin_fmaf(-K.gdt, R[6], vb[0]);
-  vb[1] = __builtin_fmaf(-K.gdt, R[7], vb[1]);
-  vb[2] = __builtin_fmaf(-K.gdt, R[8], vb[2]);
-  // wheel drive, viscous joint damping, reaction on the chassis
-  float jv = spin - wb[1];
-  float T = __builtin_fmaf(-K.damping, jv, S.wt);
-  spin = __builtin_fmaf(K.dt_over_Is, T, spin);
-  float Tsum = quad_sum(T);
-  wb[1] = __builtin_fmaf(-K.dt_over_Iy, Tsum, wb[1]);
-  // contact frame (shared by the 4 wheels: common axle = body y)
-  float s2 = __builtin_fmaf(nb[2], nb[2], nb[0] * nb[0]);
-  s2 = fmaxf(s2, 1e-12f);
-  float inv_s = 1.0f / sqrtf(s2);
-  float dx = -(nb[0] * inv_s), dz = -(nb[2] * inv_s);
-  float t1x = -dz, t1z = dx;
-  float t2x = nb[1] * t1z;
-  float t2y = __builtin_fmaf(nb[2], t1x, -(nb[0] * t1z));
-  float t2z = -(nb[1] * t1x);
-  float np = __builtin_fmaf(S.n[2], S.p[2], __builtin_fmaf(S.n[1], S.p[1], S.n[0] * S.p[0]));
-  const float cz = K.cz;
-  float rx = __builtin_fmaf(K.rw, dx, cx), ry = cy, rz = __builtin_fmaf(K.rw, dz, cz);
-  float gap = np + __builtin_fmaf(nb[2], rz, __builtin_fmaf(nb[1], ry, nb[0] * rx));
-  float b = gap >= 0.0f ? -(gap * K.inv_dt) : fminf(-(gap * K.beta_inv_dt), K.vdep);
-  float anx = __builtin_fmaf(ry, nb[2], -(rz * nb[1]));
-  float any = __builtin_fmaf(rz, nb[0], -(rx * nb[2]));
-  float anz = __builtin_fmaf(rx, nb[1], -(ry * nb[0]));
-  float a1x = cy * t1z;
-  float a1y = __builtin_fmaf(cz, t1x, -(cx * t1z));
-  float a1z = -(cy * t1x);
-  float a2x = __builtin_fmaf(ry, t2z, -(rz * t2y));
-  float a2y = __builtin_fmaf(rz, t2x, -(rx * t2z));
-  float a2z = __builtin_fmaf(rx, t2y, -(ry * t2x));
-  float Janx = K.J4x * anx, Jany = K.J4y * any, Janz = K.J4z * anz;
-  float Ja1x = K.J4x * a1x, Ja1y = K.J4y * a1y, Ja1z = K.J4z * a1z;
-  float Ja2x = K.J4x * a2x, Ja2y = K.J4y * a2y, Ja2z = K.J4z * a2z;
-  float kn = __builtin_fmaf(anz, Janz, __builtin_fmaf(any, Jany, __builtin_fmaf(anx, Janx, K.im4)));
-  float k1 = __builtin_fmaf(a1z, Ja1z, __builtin_fmaf(a1y, Ja1y, __builtin_fmaf(a1x, Ja1x, K.im4))) + K.rw2_over_Is;
-  float k2 = __builtin_fmaf(a2z, Ja2z, __builtin_fmaf(a2y, Ja2y, __builtin_fmaf(a2x, Ja2x, K.im4)));
-  float mn = 1.0f / kn, m1 = 1.0f / k1, m2 = 1.0f / k2;
-  float vnx = K.im4 * nb[0], vny = K.im4 * nb[1], vnz = K.im4 * nb[2];
-  float v1x = K.im4 * t1x, v1z = K.im4 * t1z;
-  float v2x = K.im4 * t2x, v2y = K.im4 * t2y, v2z = K.im4 * t2z;
-  float ln = S.ln, l1 = S.l1, l2 = S.l2;
-  // warm start: one mass-split averaging pass with the cached impulses
-  {
-    float vx = __builtin_fmaf(l2, v2x, __builtin_fmaf(l1, v1x, __builtin_fmaf(ln, vnx, vb[0])));
-    float vy = __builtin_fmaf(l2, v2y, __builtin_fmaf(ln, vny, vb[1]));
-    float vz = __builtin_fmaf(l2, v2z, __builtin_fmaf(l1, v1z, __builtin_fmaf(ln, vnz, vb[2])));
-    float ox = __builtin_fmaf(l2, Ja2x, __builtin_fmaf(l1, Ja1x, __builtin_fmaf(ln, Janx, wb[0])));
-    float oy = __builtin_fmaf(l2, Ja2y, __builtin_fmaf(l1, Ja1y, __builtin_fmaf(ln, Jany, wb[1])));
-    float oz = __builtin_fmaf(l2, Ja2z, __builtin_fmaf(l1, Ja1z, __builtin_fmaf(ln, Janz, wb[2])));
-    spin = __builtin_fmaf(-K.rw_over_Is, l1, spin);
-    vb[0] = 0.25f * quad_sum(vx); vb[1] = 0.25f * quad_sum(vy); vb[2] = 0.25f * quad_sum(vz);
-    wb[0] = 0.25f * quad_sum(ox); wb[1] = 0.25f * quad_sum(oy); wb[2] = 0.25f * quad_sum(oz);
-  }
-  for (int it = 0; it < K.iters; ++it) {
-    float vx = vb[0], vy = vb[1], vz = vb[2], ox = wb[0], oy = wb[1], oz = wb[2];
-    // normal row
-    float u = __builtin_fmaf(anz, oz, __builtin_fmaf(any, oy, __builtin_fmaf(anx, ox,
-              __builtin_fmaf(nb[2], vz, __builtin_fmaf(nb[1], vy, nb[0] * vx)))));
-    float dl = (b - u) * mn;
-    float nw = fmaxf(ln + dl, 0.0f);
-    dl = nw - ln;
-    ln = nw;
-    vx = __builtin_fmaf(dl, vnx, vx); vy = __builtin_fmaf(dl, vny, vy); vz = __builtin_fmaf(dl, vnz, vz);
-    ox = __builtin_fmaf(dl, Janx, ox); oy = __builtin_fmaf(dl, Jany, oy); oz = __builtin_fmaf(dl, Janz, oz);
-    float lim = S.mu * ln;
-    // longitudinal row (couples the wheel spin)
-    u = __builtin_fmaf(-K.rw, spin, __builtin_fmaf(a1z, oz, __builtin_fmaf(a1y, oy, __builtin_fmaf(a1x, ox,
-        __builtin_fmaf(t1z, vz, t1x * vx)))));
-    dl = -(u * m1);
-    nw = fminf(fmaxf(l1 + dl, -lim), lim);
-    dl = nw - l1;
-    l1 = nw;
-    vx = __builtin_fmaf(dl, v1x, vx); vz = __builtin_fmaf(dl, v1z, vz);
-    ox = __builtin_fmaf(dl, Ja1x, ox); oy = __builtin_fmaf(dl, Ja1y, oy); oz = __builtin_fmaf(dl, Ja1z, oz);
-    spin = __builtin_fmaf(-K.rw_over_Is, dl, spin);
-    // lateral row
-    u = __builtin_fmaf(a2z, oz, __builtin_fmaf(a2y, oy, __builtin_fmaf(a2x, ox,
-        __builtin_fmaf(t2z, vz, __builtin_fmaf(t2y, vy, t2x * vx)))));
-    dl = -(u * m2);
-    nw = fminf(fmaxf(l2 + dl, -lim), lim);
-    dl = nw - l2;
-    l2 = nw;
-    vx = __builtin_fmaf(dl, v2x, vx); vy = __builtin_fmaf(dl, v2y, vy); vz = __builtin_fmaf(dl, v2z, vz);
-    ox = __builtin_fmaf(dl, Ja2x, ox); oy = __builtin_fmaf(dl, Ja2y, oy); oz = __builtin_fmaf(dl, Ja2z, oz);
-    // mass-splitting average over the 4 contacts
-    vb[0] = 0.25f * quad_sum(vx); vb[1] = 0.25f * quad_sum(vy); vb[2] = 0.25f * quad_sum(vz);
-    wb[0] = 0.25f * quad_sum(ox); wb[1] = 0.25f * quad_sum(oy); wb[2] = 0.25f * quad_sum(oz);
-  }
-  S.ln = ln; S.l1 = l1; S.l2 = l2;
-  // back to world, caps (origin_v18.py:65-70), integrate
-  rot(R, vb, S.v);
-  rot(R, wb, S.w);
-  float w2 = __builtin_fmaf(S.w[2], S.w[2], __builtin_fmaf(S.w[1], S.w[1], S.w[0] * S.w[0]));
-  if (w2 > K.maxw2) {
-    float sc = K.maxw / sqrtf(w2);
-    S.w[0] *= sc; S.w[1] *= sc; S.w[2] *= sc;
-  }
-  spin = fminf(fmaxf(spin, -K.maxw), K.maxw);
-  S.p[0] = __builtin_fmaf(K.dt, S.v[0], S.p[0]);
-  S.p[1] = __builtin_fmaf(K.dt, S.v[1], S.p[1]);
-  S.p[2] = __builtin_fmaf(K.dt, S.v[2], S.p[2]);
-  float qw = S.q[0], qx = S.q[1], qy = S.q[2], qz = S.q[3], h = K.half_dt;
-  float nqw = __builtin_fmaf(-h, __builtin_fmaf(S.w[2], qz, __builtin_fmaf(S.w[1], qy, S.w[0] * qx)), qw);
-  float nqx = __builtin_fmaf(h, __builtin_fmaf(-S.w[2], qy, __builtin_fmaf(S.w[1], qz, S.w[0] * qw)), qx);
-  float nqy = __builtin_fmaf(h, __builtin_fmaf(-S.w[0], qz, __builtin_fmaf(S.w[2], qx, S.w[1] * qw)), qy);
-  float nqz = __builtin_fmaf(h, __builtin_fmaf(-S.w[1], qx, __builtin_fmaf(S.w[0], qy, S.w[2] * qw)), qz);
-  float nn = __builtin_fmaf(nqz, nqz, __builtin_fmaf(nqy, nqy, __builtin_fmaf(nqx, nqx, nqw * nqw)));
-  float inv = 1.0f / sqrtf(nn);
-  S.q[0] = nqw * inv; S.q[1] = nqx * inv; S.q[2] = nqy * inv; S.q[3] = nqz * inv;
-}
 
 // torch_rand_float(lower, upper) = (upper - lower) * rand + lower  (KAMMA.py:424-456)
 OIS_DEV float rand_float(float lo, float hi, float u) { return (hi - lo) * u + lo; }
@@ -320,65 +179,72 @@ OIS_DEV float forward_projection(const float q[4], const float v[3]) {
   return (v[0] * fx + v[1] * fy) + v[2] * fz;
 }
 
-// What a resetting arena contributes to the per-wave reset-event record; lane k of the quad
-// holds component k of every 4-vector.
+// What a resetting arena contributes to its group's reset-event record (SPEC §2.10).
+// Record slots: 0 count, 1 return^2, 2 length, 4..7 sums r1 r2 r3 dense, 8..11 sums sparse
+// guiding observed final, 12..15 ratios r1 r2 r3 dense, 16..18 ratios sparse guiding observed,
+// 20..22 eval sums, 24 gamma1, 25 gamma2, 26 -return (max), 27 return (max)
+constexpr int kRecSum = 23;  // slots [0, 23) are summed; 24..27 are max-reduced
 struct ResetContrib {
-  float v0, v1, v2, v3, v4, v5, v6;
+  float s[kRecSum];
+  float m[4];
 };
-OIS_DEV ResetContrib contrib_identity(int wl) {
-  ResetContrib c;
-  c.v0 = c.v1 = c.v2 = c.v3 = c.v4 = c.v5 = 0.0f;
-  c.v6 = -__builtin_inff();
-  return c;
+OIS_DEV void contrib_identity(ResetContrib& c) {
+#pragma unroll
+  for (int k = 0; k < kRecSum; ++k) c.s[k] = 0.0f;
+#pragma unroll
+  for (int k = 0; k < 4; ++k) c.m[k] = -__builtin_inff();
 }
 
-// reset_idx for one arena (KAMMA.py:417-498); executed by the 4 lanes of the quad together.
-OIS_DEV void reset_arena(const DevConsts& K, int wl, int64_t gid, float gamma1, float gamma2, Lane& S,
-                         ResetContrib& rc) {
-  float Sf = quad_bcast<3>(S.sb);  // "Final reward" sum
-  float hg = 100.0f * (1.0f - gamma2);  // :470
-  float gg = 100.0f * gamma2;           // :475
-  float L = K.episode_length_s;
-  // V0 = [count, ret^2, len, 0]
-  rc.v0 = sel4(wl, 1.0f, Sf * Sf, (float)S.ep_buf, 0.0f);
-  rc.v1 = S.sa;  // r1, r2, r3, dense
-  rc.v2 = S.sb;  // sparse, guiding, observed, final
-  rc.v3 = L * ((hg * S.sa) / Sf);  // :470-473
-  float fb = (wl == 1) ? gg : hg;  // guiding uses gamma2 itself (:475)
-  float rb = L * ((fb * S.sb) / Sf);  // :474-476
-  rc.v4 = (wl == 3) ? 0.0f : rb;
-  rc.v5 = (wl == 3) ? 0.0f : S.sc;  // smoothness, tracking error, desired velocity
-  rc.v6 = sel4(wl, gamma1, gamma2, -Sf, Sf);
-  S.sa = 0.0f; S.sb = 0.0f; S.sc = 0.0f;  // :485 (sc[3] = old-torque-valid flag, cleared too)
+// reset_idx for one arena (KAMMA.py:417-498)
+OIS_DEV void reset_arena(const DevConsts& K, int64_t gid, float gamma1, float gamma2, Arena& S, ResetContrib& rc) {
+  const float Sf = S.sb[3];                   // "Final reward" sum
+  const float hg = 100.0f * (1.0f - gamma2);  // :470
+  const float gg = 100.0f * gamma2;           // :475
+  const float L = K.episode_length_s;
+  rc.s[0] = 1.0f; rc.s[1] = Sf * Sf; rc.s[2] = (float)S.ep_buf; rc.s[3] = 0.0f;
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    rc.s[4 + k] = S.sa[k];
+    rc.s[8 + k] = S.sb[k];
+    rc.s[12 + k] = L * ((hg * S.sa[k]) / Sf);  // :470-473
+  }
+  rc.s[16] = L * ((hg * S.sb[0]) / Sf);  // :474
+  rc.s[17] = L * ((gg * S.sb[1]) / Sf);  // :475 guiding uses gamma2 itself
+  rc.s[18] = L * ((hg * S.sb[2]) / Sf);  // :476
+  rc.s[19] = 0.0f;
+  rc.s[20] = S.sc[0]; rc.s[21] = S.sc[1]; rc.s[22] = S.sc[2];
+  rc.m[0] = gamma1; rc.m[1] = gamma2; rc.m[2] = -Sf; rc.m[3] = Sf;
+#pragma unroll
+  for (int k = 0; k < 4; ++k) { S.sa[k] = 0.0f; S.sb[k] = 0.0f; S.sc[k] = 0.0f; }  // :485 (sc[3]: old-torque flag)
 
   float u[8];
   draw4(K, gid, (uint32_t)S.sim_steps, PURPOSE_RESET_A, &u[0]);
   draw4(K, gid, (uint32_t)S.sim_steps, PURPOSE_RESET_B, &u[4]);
-  float r = K.spawn_xy_range;
-  float px = K.init_pos[0] + rand_float(-r, r, u[0]);  // :422-424
-  float py = K.init_pos[1] + rand_float(-r, r, u[1]);
-  float pz = K.init_pos[2];
-  float ang = rand_float(0.0f, 6.28318530717958647692f, u[2]);  // :426
+  const float r = K.spawn_xy_range;
+  const float px = K.init_pos[0] + rand_float(-r, r, u[0]);  // :422-424
+  const float py = K.init_pos[1] + rand_float(-r, r, u[1]);
+  const float pz = K.init_pos[2];
+  const float ang = rand_float(0.0f, 6.28318530717958647692f, u[2]);  // :426
   float s, c;
   sincos_det(ang / 2.0f, s, c);
-  float qz[4] = {c, 0.0f, 0.0f, s};
+  const float qz[4] = {c, 0.0f, 0.0f, s};
   quat_mul(qz, K.init_quat, S.q);  // :434
-  float cx = rand_float(K.cmd_x_lo, K.cmd_x_hi, u[3]);      // :448
-  float cy = rand_float(K.cmd_y_lo, K.cmd_y_hi, u[4]);      // :451
-  float ch = rand_float(K.cmd_yaw_lo, K.cmd_yaw_hi, u[5]);  // :454
-  float keep = sqrtf(cx * cx + cy * cy) > 0.25f ? 1.0f : 0.0f;  // :458
+  const float cx = rand_float(K.cmd_x_lo, K.cmd_x_hi, u[3]);      // :448
+  const float cy = rand_float(K.cmd_y_lo, K.cmd_y_hi, u[4]);      // :451
+  const float ch = rand_float(K.cmd_yaw_lo, K.cmd_yaw_hi, u[5]);  // :454
+  const float keep = sqrtf(cx * cx + cy * cy) > 0.25f ? 1.0f : 0.0f;  // :458
   S.cmd[1] = cy * keep;
   S.cmd[3] = ch * keep;
   float x_vel = rand_float(K.cmd_x_lo, K.cmd_x_hi, u[6]);  // :571 (u[7]: discarded omega draw :572)
   if (K.cmd_sampler == OIS_CMD_BOX) {  // KAMMA_curr1.py:577-598
-    float progress = fminf(1.0f, (float)S.sim_steps / K.max_sim_steps);
-    float factor = 0.1f + (1.0f - 0.1f) * progress;
-    float xc = (K.cmd_x_lo + K.cmd_x_hi) / 2.0f;
-    float xmin = xc - (xc - K.cmd_x_lo) * factor;
-    float xmax = xc + (K.cmd_x_hi - xc) * factor;
+    const float progress = fminf(1.0f, (float)S.sim_steps / K.max_sim_steps);
+    const float factor = 0.1f + (1.0f - 0.1f) * progress;
+    const float xc = (K.cmd_x_lo + K.cmd_x_hi) / 2.0f;
+    const float xmin = xc - (xc - K.cmd_x_lo) * factor;
+    const float xmax = xc + (K.cmd_x_hi - xc) * factor;
     x_vel = rand_float(xmin, xmax, u[6]);
   } else if (K.cmd_sampler == OIS_CMD_EVAL) {  // KAMMA_eval.py:545-550
-    float progress = fminf(fmaxf((float)S.sim_steps / K.eval_ramp_steps, 0.0f), 1.0f);
+    const float progress = fminf(fmaxf((float)S.sim_steps / K.eval_ramp_steps, 0.0f), 1.0f);
     x_vel = 1.0f + progress * (2.0f - 1.0f);
   }
   S.cmd[0] = x_vel > 0.0f ? x_vel : 0.0f;  // :575, :495
@@ -388,42 +254,47 @@ OIS_DEV void reset_arena(const DevConsts& K, int wl, int64_t gid, float gamma1, 
   S.p[0] = __builtin_fmaf(R[2], K.com_height, px);
   S.p[1] = __builtin_fmaf(R[5], K.com_height, py);
   S.p[2] = __builtin_fmaf(R[8], K.com_height, pz);
-  S.v[0] = K.init_lin_vel[0]; S.v[1] = K.init_lin_vel[1]; S.v[2] = K.init_lin_vel[2];  // :435
-  S.w[0] = K.init_ang_vel[0]; S.w[1] = K.init_ang_vel[1]; S.w[2] = K.init_ang_vel[2];
-  S.jv = sel4(wl, K.init_dof_vel[0], K.init_dof_vel[1], K.init_dof_vel[2], K.init_dof_vel[3]);  // :438
-  S.ln = 0.0f; S.l1 = 0.0f; S.l2 = 0.0f;
-  S.ep_buf = 0;    // :462
-  S.ep_count += 1; // :463
+#pragma unroll
+  for (int k = 0; k < 3; ++k) { S.v[k] = K.init_lin_vel[k]; S.w[k] = K.init_ang_vel[k]; }  // :435
+#pragma unroll
+  for (int k = 0; k < 4; ++k) { S.jv[k] = K.init_dof_vel[k]; S.ln[k] = 0.0f; S.l1[k] = 0.0f; S.l2[k] = 0.0f; }  // :438
+  S.ep_buf = 0;     // :462
+  S.ep_count += 1;  // :463
 }
 
-// Butterfly over the 16 arenas of the wave (lane bits 2..5); lane k keeps component k.
+// Pairwise butterfly over the 16 arenas (= 16 consecutive lanes) of a reduction group.
 template <int OP>
-OIS_DEV float wave_reduce16(float x) {
+OIS_DEV float group_reduce16(float x) {
 #pragma unroll
-  for (int m = 4; m < 64; m <<= 1) {
-    float y = __shfl_xor(x, m, 64);
+  for (int m = 1; m < kGroup; m <<= 1) {
+    const float y = __shfl_xor(x, m, 64);
     x = OP == 0 ? x + y : fmaxf(x, y);
   }
   return x;
 }
 
-// Per-wave record of a reset event + finished-episode accumulators. Must be called by all
-// 64 lanes of the wave. `any` = wave has at least one resetting arena.
-OIS_DEV void wave_record(const DevBuffers& B, int wave, int lane, const ResetContrib& rc, int stamp,
-                         bool count_stats) {
-  float r0 = wave_reduce16<0>(rc.v0), r1 = wave_reduce16<0>(rc.v1), r2 = wave_reduce16<0>(rc.v2);
-  float r3 = wave_reduce16<0>(rc.v3), r4 = wave_reduce16<0>(rc.v4), r5 = wave_reduce16<0>(rc.v5);
-  float r6 = wave_reduce16<1>(rc.v6);
-  if (lane < 4) {
-    float* P = B.partials + (size_t)wave * 32;
-    P[0 + lane] = r0; P[4 + lane] = r1; P[8 + lane] = r2; P[12 + lane] = r3;
-    P[16 + lane] = r4; P[20 + lane] = r5; P[24 + lane] = r6;
-    if (lane == 0) B.stamps[wave] = stamp;
+// Record of a reset event + finished-episode accumulators for the group of this lane.
+// Must be called by all 64 lanes of the wave (shuffles); only groups with a resetting arena
+// write. group = arena / 16.
+OIS_DEV void group_record(const DevBuffers& B, int group, int lane, bool group_has_reset, const ResetContrib& rc,
+                          int stamp, bool count_stats) {
+  float rs[kRecSum], rm[4];
+#pragma unroll
+  for (int k = 0; k < kRecSum; ++k) rs[k] = group_reduce16<0>(rc.s[k]);
+#pragma unroll
+  for (int k = 0; k < 4; ++k) rm[k] = group_reduce16<1>(rc.m[k]);
+  if ((lane & (kGroup - 1)) == 0 && group_has_reset) {
+    float* P = B.partials + (size_t)group * 32;
+#pragma unroll
+    for (int k = 0; k < kRecSum; ++k) P[k] = rs[k];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) P[24 + k] = rm[k];
+    B.stamps[group] = stamp;
     if (count_stats) {
-      float* A = B.stat_acc + (size_t)wave * 8;
-      // A[0..3] = count, ret^2, len, ret ; A[4..7] = -, -, max(-ret), max(ret)
-      A[lane] += (lane == 3) ? r2 : r0;
-      if (lane >= 2) A[4 + lane] = fmaxf(A[4 + lane], r6);
+      float* A = B.stat_acc + (size_t)group * 8;
+      // A[0..3] = count, ret^2, len, ret ; A[6], A[7] = max(-ret), max(ret)
+      A[0] += rs[0]; A[1] += rs[1]; A[2] += rs[2]; A[3] += rs[11];
+      A[6] = fmaxf(A[6], rm[2]); A[7] = fmaxf(A[7], rm[3]);
     }
   }
 }

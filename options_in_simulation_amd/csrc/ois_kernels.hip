@@ -3,264 +3,306 @@
 // post_physics_step (src/my_envs/KAMMA.py:596-727) with PhysX replaced by the build-defined
 // rigid-body model of docs/SPEC.md §3.
 //
-// One launch = one (or k) policy step(s) for all arenas: controller -> action mixing ->
-// torque clip -> 20 contact-solver substeps -> termination -> reward -> auto-reset ->
-// observation -> forward-speed projection, state in registers throughout.
+// One launch = one (or k) policy step(s) for all arenas, one arena per lane: controller ->
+// action mixing -> torque clip -> 20 contact-solver substeps -> termination -> reward ->
+// auto-reset -> observation -> forward-speed projection, state in registers throughout.
 #include <hip/hip_runtime.h>
 
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <new>
 
-#include "ois_device.h"
+#include "ois_physics.h"
 
 using namespace ois;
 
 namespace {
 
-constexpr int kBlock = 256;
+constexpr int kBlock = 64;  // one wave per workgroup: 65 536 arenas = 1024 workgroups = 1 per SIMD
 
 // ------------------------------------------------------------------ load / store ------
-OIS_DEV void load_lane(const DevConsts& K, const DevBuffers& B, int ld, Lane& S) {
-  float g;
-  g = B.pose[ld];
-  S.p[0] = quad_bcast<0>(g); S.p[1] = quad_bcast<1>(g); S.p[2] = quad_bcast<2>(g); S.vfwd = quad_bcast<3>(g);
-  g = B.quat[ld];
-  S.q[0] = quad_bcast<0>(g); S.q[1] = quad_bcast<1>(g); S.q[2] = quad_bcast<2>(g); S.q[3] = quad_bcast<3>(g);
-  g = B.linvel[ld];
-  S.v[0] = quad_bcast<0>(g); S.v[1] = quad_bcast<1>(g); S.v[2] = quad_bcast<2>(g); S.prev_lin = quad_bcast<3>(g);
-  g = B.angvel[ld];
-  S.w[0] = quad_bcast<0>(g); S.w[1] = quad_bcast<1>(g); S.w[2] = quad_bcast<2>(g); S.prev_ang = quad_bcast<3>(g);
-  g = B.commands[ld];
-  S.cmd[0] = quad_bcast<0>(g); S.cmd[1] = quad_bcast<1>(g); S.cmd[2] = quad_bcast<2>(g); S.cmd[3] = quad_bcast<3>(g);
-  int c = B.counters[ld];
-  S.ep_buf = quad_bcasti<0>(c); S.sim_steps = quad_bcasti<1>(c); S.ep_count = quad_bcasti<2>(c);
-  g = B.params[ld];
-  S.mu = quad_bcast<0>(g); S.n[0] = quad_bcast<1>(g); S.n[1] = quad_bcast<2>(g); S.n[2] = quad_bcast<3>(g);
-  S.jv = B.wheel_vel[ld];
-  S.ln = B.lam_n[ld]; S.l1 = B.lam_l[ld]; S.l2 = B.lam_t[ld];
-  S.sa = B.sums_a[ld]; S.sb = B.sums_b[ld];
-  S.sc = K.eval_sums ? B.sums_c[ld] : 0.0f;
-  S.wt = K.eval_sums ? B.wheel_torqs[ld] : 0.0f;
+OIS_DEV void load_arena(const DevConsts& K, const DevBuffers& B, int i, Arena& S) {
+  const float4 po = B.pose[i], qu = B.quat[i], lv = B.linvel[i], av = B.angvel[i], cm = B.commands[i];
+  const float4 pr = B.params[i], jv = B.wheel_vel[i], ln = B.lam_n[i], l1 = B.lam_l[i], l2 = B.lam_t[i];
+  const float4 sa = B.sums_a[i], sb = B.sums_b[i];
+  const int4 ct = B.counters[i];
+  S.p[0] = po.x; S.p[1] = po.y; S.p[2] = po.z; S.vfwd = po.w;
+  S.q[0] = qu.x; S.q[1] = qu.y; S.q[2] = qu.z; S.q[3] = qu.w;
+  S.v[0] = lv.x; S.v[1] = lv.y; S.v[2] = lv.z; S.prev_lin = lv.w;
+  S.w[0] = av.x; S.w[1] = av.y; S.w[2] = av.z; S.prev_ang = av.w;
+  S.cmd[0] = cm.x; S.cmd[1] = cm.y; S.cmd[2] = cm.z; S.cmd[3] = cm.w;
+  S.ep_buf = ct.x; S.sim_steps = ct.y; S.ep_count = ct.z;
+  S.mu = pr.x; S.n[0] = pr.y; S.n[1] = pr.z; S.n[2] = pr.w;
+  S.jv[0] = jv.x; S.jv[1] = jv.y; S.jv[2] = jv.z; S.jv[3] = jv.w;
+  S.ln[0] = ln.x; S.ln[1] = ln.y; S.ln[2] = ln.z; S.ln[3] = ln.w;
+  S.l1[0] = l1.x; S.l1[1] = l1.y; S.l1[2] = l1.z; S.l1[3] = l1.w;
+  S.l2[0] = l2.x; S.l2[1] = l2.y; S.l2[2] = l2.z; S.l2[3] = l2.w;
+  S.sa[0] = sa.x; S.sa[1] = sa.y; S.sa[2] = sa.z; S.sa[3] = sa.w;
+  S.sb[0] = sb.x; S.sb[1] = sb.y; S.sb[2] = sb.z; S.sb[3] = sb.w;
+  if (K.eval_sums) {
+    const float4 sc = B.sums_c[i], wt = B.wheel_torqs[i];
+    S.sc[0] = sc.x; S.sc[1] = sc.y; S.sc[2] = sc.z; S.sc[3] = sc.w;
+    S.wt[0] = wt.x; S.wt[1] = wt.y; S.wt[2] = wt.z; S.wt[3] = wt.w;
+  } else {
+    for (int k = 0; k < 4; ++k) { S.sc[k] = 0.0f; S.wt[k] = 0.0f; }
+  }
 }
 
-OIS_DEV void store_lane(const DevConsts& K, const DevBuffers& B, int tid, int wl, const Lane& S) {
-  B.pose[tid] = sel4(wl, S.p[0], S.p[1], S.p[2], S.vfwd);
-  B.quat[tid] = sel4(wl, S.q[0], S.q[1], S.q[2], S.q[3]);
-  B.linvel[tid] = sel4(wl, S.v[0], S.v[1], S.v[2], S.prev_lin);
-  B.angvel[tid] = sel4(wl, S.w[0], S.w[1], S.w[2], S.prev_ang);
-  B.commands[tid] = sel4(wl, S.cmd[0], S.cmd[1], S.cmd[2], S.cmd[3]);
-  int c = (wl & 2) ? ((wl & 1) ? 0 : S.ep_count) : ((wl & 1) ? S.sim_steps : S.ep_buf);
-  B.counters[tid] = c;
-  B.wheel_vel[tid] = S.jv;
-  B.lam_n[tid] = S.ln; B.lam_l[tid] = S.l1; B.lam_t[tid] = S.l2;
-  B.sums_a[tid] = S.sa; B.sums_b[tid] = S.sb;
-  if (K.eval_sums) B.sums_c[tid] = S.sc;
-  B.wheel_torqs[tid] = S.wt;
+OIS_DEV void store_arena(const DevConsts& K, const DevBuffers& B, int i, const Arena& S) {
+  B.pose[i] = make_float4(S.p[0], S.p[1], S.p[2], S.vfwd);
+  B.quat[i] = make_float4(S.q[0], S.q[1], S.q[2], S.q[3]);
+  B.linvel[i] = make_float4(S.v[0], S.v[1], S.v[2], S.prev_lin);
+  B.angvel[i] = make_float4(S.w[0], S.w[1], S.w[2], S.prev_ang);
+  B.commands[i] = make_float4(S.cmd[0], S.cmd[1], S.cmd[2], S.cmd[3]);
+  B.counters[i] = make_int4(S.ep_buf, S.sim_steps, S.ep_count, 0);
+  B.wheel_vel[i] = make_float4(S.jv[0], S.jv[1], S.jv[2], S.jv[3]);
+  B.lam_n[i] = make_float4(S.ln[0], S.ln[1], S.ln[2], S.ln[3]);
+  B.lam_l[i] = make_float4(S.l1[0], S.l1[1], S.l1[2], S.l1[3]);
+  B.lam_t[i] = make_float4(S.l2[0], S.l2[1], S.l2[2], S.l2[3]);
+  B.sums_a[i] = make_float4(S.sa[0], S.sa[1], S.sa[2], S.sa[3]);
+  B.sums_b[i] = make_float4(S.sb[0], S.sb[1], S.sb[2], S.sb[3]);
+  if (K.eval_sums) B.sums_c[i] = make_float4(S.sc[0], S.sc[1], S.sc[2], S.sc[3]);
+  B.wheel_torqs[i] = make_float4(S.wt[0], S.wt[1], S.wt[2], S.wt[3]);
 }
 
 // ------------------------------------------------------------------ the step kernel ---
 __global__ __launch_bounds__(kBlock) void step_kernel(DevConsts K, DevBuffers B, const float* __restrict__ actions,
                                                       float* __restrict__ reward_sum, int N, int ksteps, int policy) {
-  const int tid = blockIdx.x * kBlock + threadIdx.x;
+  const int arena = blockIdx.x * kBlock + threadIdx.x;
   const int lane = threadIdx.x & 63;
-  const int wave = tid >> 6;
-  const int wl = tid & 3;
-  const int arena = tid >> 2;
   const bool valid = arena < N;
-  const int la = valid ? arena : N - 1;
-  const int ld = la * 4 + wl;
+  const int la = valid ? arena : N - 1;  // tail lanes shadow the last arena and store nothing
   const int64_t gid = K.arena_offset + la;
-  // wheel centre of this lane relative to the COM: fl, rl, fr, rr (urdf:112-142)
-  const float cx = (wl & 1) ? -K.wx : K.wx;
-  const float cy = (wl & 2) ? -K.wy : K.wy;
   const int A = K.action_dim;
-  const int amap = A == 4 ? wl : (A == 2 ? (wl >> 1) : 0);  // KA_DDPG_2D.py:623-624, KA_DDPG_1D.py:600-603
 
-  Lane S;
-  load_lane(K, B, ld, S);
+  Arena S;
+  load_arena(K, B, la, S);
   float rsum = 0.0f;
 
   for (int s = 0; s < ksteps; ++s) {
     const bool last = s == ksteps - 1;
-    // ---- action of this lane's wheel ----
-    float a = 0.0f;
+    // ---- actions -> 4 wheels (KA_DDPG_2D.py:623-624, KA_DDPG_1D.py:600-603) ----
+    float a4[4] = {0.0f, 0.0f, 0.0f, 0.0f};
     if (policy == OIS_POLICY_EXTERNAL) {
-      a = actions[((size_t)s * N + la) * A + amap];
+      const float* ap = actions + ((size_t)s * N + la) * A;
+      if (A == 4) {
+        const float4 t = *reinterpret_cast<const float4*>(ap);
+        a4[0] = t.x; a4[1] = t.y; a4[2] = t.z; a4[3] = t.w;
+      } else if (A == 2) {
+        const float2 t = *reinterpret_cast<const float2*>(ap);
+        a4[0] = a4[1] = t.x; a4[2] = a4[3] = t.y;
+      } else {
+        a4[0] = a4[1] = a4[2] = a4[3] = ap[0];
+      }
     } else if (policy == OIS_POLICY_RANDOM) {
       float u[4];
       draw4(K, gid, (uint32_t)S.sim_steps, PURPOSE_ACTION, u);
-      a = sel4(amap, u[0], u[1], u[2], u[3]);
+      if (A == 4) { a4[0] = u[0]; a4[1] = u[1]; a4[2] = u[2]; a4[3] = u[3]; }
+      else if (A == 2) { a4[0] = a4[1] = u[0]; a4[2] = a4[3] = u[1]; }
+      else { a4[0] = a4[1] = a4[2] = a4[3] = u[0]; }
     }
     // ---- pre_physics_step (KAMMA.py:596-656) ----
-    const float current_v = S.vfwd;     // :607
-    const float current_omega = S.w[2]; // :608
+    const float current_v = S.vfwd;      // :607
+    const float current_omega = S.w[2];  // :608
     const float vd = S.cmd[0] - current_v;      // :609
     const float od = S.cmd[2] - current_omega;  // :610
-    const float lin = K.Kp * (K.vehicle_mass * (vd / K.policy_dt));           // :617
+    const float lin = K.Kp * (K.vehicle_mass * (vd / K.policy_dt));            // :617
     const float ang = K.Kp_omega * (K.vehicle_inertia * (od / K.policy_dt));
-    const float ac_left = lin - ang, ac_right = lin + ang;                    // :617, :619
-    const float crit = (wl < 2) ? ac_left : ac_right;                         // :624
-    float gs = 1.0f - ((float)S.sim_steps / K.max_sim_steps);                 // :627-628
+    const float ac_left = lin - ang, ac_right = lin + ang;                     // :617, :619
+    float gs = 1.0f - ((float)S.sim_steps / K.max_sim_steps);                  // :627-628
     gs = gs < 0.0f ? 0.0f : gs;
     const float gamma1 = K.gamma1_mode == OIS_GAMMA_CONST ? K.gamma1_const : gs;
     const float gamma2 = K.gamma2_mode == OIS_GAMMA_CONST ? K.gamma2_const : gs;
-    const float pol = a * K.action_scale;
-    float t;
+    float rnd = 0.0f;
     if (K.mix_mode == OIS_MIX_SWITCH) {
       float u[4];
       draw4(K, gid, (uint32_t)S.sim_steps, PURPOSE_MASK, u);  // torch.rand(num_envs, 1) :633
-      const float mask = u[0] < gamma1 ? 1.0f : 0.0f;         // :634
-      t = mask * crit + (1.0f - mask) * pol;                  // :635
-    } else {
-      t = ((1.0f - gamma1) * a) * K.action_scale + gamma1 * crit;  // KA_DDPG_4D.py:631
+      rnd = u[0];
     }
-    const float wt = clipf(t, -K.torque_clip, K.torque_clip);  // :649
-    const float gd = (K.guiding_mode == OIS_GUIDE_EXECUTED ? wt : pol) - crit;
-    const float guiding = -sqrtf(quad_sum(gd * gd));           // :656 / KA_DDPG_4D.py:637
+    float torq[4], wt[4], pol[4], d2[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const float crit = j < 2 ? ac_left : ac_right;  // :624 order fl, rl, fr, rr
+      pol[j] = a4[j] * K.action_scale;
+      float t;
+      if (K.mix_mode == OIS_MIX_SWITCH) {
+        const float mask = rnd < gamma1 ? 1.0f : 0.0f;  // :634
+        t = mask * crit + (1.0f - mask) * pol[j];        // :635
+      } else {
+        t = ((1.0f - gamma1) * a4[j]) * K.action_scale + gamma1 * crit;  // KA_DDPG_4D.py:631
+      }
+      torq[j] = t;
+      wt[j] = clipf(t, -K.torque_clip, K.torque_clip);  // :649
+      const float d = (K.guiding_mode == OIS_GUIDE_EXECUTED ? wt[j] : pol[j]) - crit;
+      d2[j] = d * d;
+    }
+    const float guiding = -sqrtf((d2[0] + d2[1]) + (d2[2] + d2[3]));  // :656 / KA_DDPG_4D.py:637
     if (K.eval_sums) {  // KAMMA_eval.py:677-685
-      const float flag = quad_bcast<3>(S.sc);
-      const float old = flag != 0.0f ? S.wt : 0.0f;
-      const float df = old - wt;
-      const float sm = quad_sum(df * df) / 10.0f;
-      const float dv = S.cmd[0] / 10.0f;
-      S.sc = wl == 0 ? S.sc + sm : (wl == 2 ? S.sc + dv : (wl == 3 ? 1.0f : S.sc));
+      float e2[4];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const float old = S.sc[3] != 0.0f ? S.wt[j] : 0.0f;
+        const float df = old - wt[j];
+        e2[j] = df * df;
+      }
+      S.sc[0] += ((e2[0] + e2[1]) + (e2[2] + e2[3])) / 10.0f;
+      S.sc[2] += S.cmd[0] / 10.0f;
+      S.sc[3] = 1.0f;
     }
-    S.wt = wt;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) S.wt[j] = wt[j];
 
     // ---- physics: decimation (:646-653) + controlFrequencyInv (:43) substeps ----
+    float R[9];
     {
-      float R[9], wb[3];
+      Phys X;
+      float wb[3];
       rotmat(S.q, R);
       rotT(R, S.w, wb);
-      float spin = S.jv + wb[1];
-      for (int i = 0; i < K.nsub; ++i) substep(K, wl, cx, cy, S, spin);
-      rotmat(S.q, R);
-      rotT(R, S.w, wb);
-      S.jv = spin - wb[1];
-      // base-link position for the bounds check (:758-759)
-      S.ep_buf += 1;     // :675
-      S.sim_steps += 1;  // :676
-      const float plx = __builtin_fmaf(-R[2], K.com_height, S.p[0]);
-      const float ply = __builtin_fmaf(-R[5], K.com_height, S.p[1]);
-      // ---- is_done (:736-764) ----
-      const bool timeout = S.ep_buf >= K.max_episode_length - 1;  // :740-744
-      float pg[3];
-      quat_apply(S.q, 0.0f, 0.0f, -1.0f, pg);                      // :749
-      const bool fallen = pg[2] > 0.0f;                            // :753
-      const bool oob = (plx < -K.bounds) | (plx > K.bounds) | (ply < -K.bounds) | (ply > K.bounds);
-      const bool reset = fallen | timeout | oob;
-      // ---- calculate_metrics (:767-822) ----
-      const float lin_acc = (current_v - S.prev_lin) / K.policy_dt;  // :770
-      const float ang_acc = (S.w[2] - S.prev_ang) / K.policy_dt;     // :771
-      S.prev_lin = current_v;                                        // :774
-      S.prev_ang = S.w[2];                                           // :775
-      const float r1 = vd * vd + 5.0f * (od * od);                   // :779
-      const float r2 = lin_acc * lin_acc + ang_acc * ang_acc;        // :781
-      const float r3 = quad_sum(wt * wt);                            // :783
-      const float c1 = K.w1 * r1, c2 = K.w2 * r2, c3 = K.w3 * r3;
-      const float rdense = (c1 + c2) + c3;                           // :786
-      const float sparse = (fabsf(vd) < K.sparse_threshold && fabsf(od) < K.sparse_threshold) ? K.sparse_bonus : 0.0f;
-      const float observed = rdense + sparse;                        // :795
-      float rew = (1.0f - gamma2) * observed + gamma2 * guiding;     // :798
-      rew += (K.terminal_reward * (reset ? 1.0f : 0.0f)) * (timeout ? -2.0f : -1.0f);  // :801 (~ on int64)
-      S.sa += sel4(wl, c1, c2, c3, rdense);          // :803-806
-      S.sb += sel4(wl, sparse, guiding, observed, rew);  // :807-810
-      if (K.eval_sums && wl == 1) S.sc += fabsf(vd) / 10.0f;  // KAMMA_eval.py:840
-      rsum += rew;
-      // ---- reset_idx (:417-498) ----
-      ResetContrib rc = contrib_identity(wl);
-      const bool do_reset = reset && valid;
-      if (reset) reset_arena(K, wl, gid, gamma1, gamma2, S, rc);
-      if (!valid) rc = contrib_identity(wl);
-      // ---- outputs (only the last step of a rollout is observable) ----
-      if (last && valid) {
-        // get_observations (:833); desired_* are views of commands -> post-reset values
-        const float o = sel4(wl, S.cmd[0], S.cmd[2], vd, od);
-        B.obs[(size_t)arena * 6 + wl] = clipf(o, -K.clip_obs, K.clip_obs);  // clamp: rl_task.py:99
-        if (wl < 2) B.obs[(size_t)arena * 6 + 4 + wl] = clipf(wl == 0 ? lin_acc : ang_acc, -K.clip_obs, K.clip_obs);
-        if (wl == 0) {
-          B.rew[arena] = rew;
-          B.done[arena] = reset ? 1 : 0;
-          B.timeout[arena] = timeout ? 1 : 0;
-        }
-        if (arena == 0) {  // task.observed_components ingredients (:840-867)
-          float* d = B.env0_diag;
-          d[9 + wl] = t;
-          d[15 + wl] = pol;
-          if (wl == 0) {
-            d[0] = S.cmd[0]; d[1] = current_v; d[2] = S.cmd[2]; d[3] = current_omega; d[4] = vd; d[5] = od;
-            d[6] = lin_acc; d[7] = ang_acc; d[8] = (float)S.ep_count; d[13] = ac_left; d[14] = ac_right;
-            d[19] = gamma2; d[20] = c1; d[21] = c2; d[22] = c3; d[23] = rdense; d[24] = sparse; d[25] = observed;
-            d[26] = guiding; d[27] = rew; d[28] = gamma1;
-          }
-        }
+#pragma unroll
+      for (int k = 0; k < 3; ++k) { X.p[k] = S.p[k]; X.v[k] = S.v[k]; X.wb[k] = wb[k]; X.n[k] = S.n[k]; }
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        X.q[k] = S.q[k]; X.tau[k] = wt[k]; X.spin[k] = S.jv[k] + wb[1];
+        X.ln[k] = S.ln[k]; X.l1[k] = S.l1[k]; X.l2[k] = S.l2[k];
       }
-      // tail of post_physics_step (:701-710) on the possibly reset state
-      S.vfwd = forward_projection(S.q, S.v);
-      // ---- per-wave record of the reset event (extras["episode"], episode statistics) ----
-      if (__ballot(do_reset) != 0ull) wave_record(B, wave, lane, rc, S.sim_steps, true);
+      X.mu = S.mu;
+      for (int i = 0; i < K.nsub; ++i) substep(K, X);
+      rotmat(X.q, R);
+      rot(R, X.wb, S.w);  // body -> world with the final orientation
+#pragma unroll
+      for (int k = 0; k < 3; ++k) { S.p[k] = X.p[k]; S.v[k] = X.v[k]; }
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        S.q[k] = X.q[k]; S.jv[k] = X.spin[k] - X.wb[1];
+        S.ln[k] = X.ln[k]; S.l1[k] = X.l1[k]; S.l2[k] = X.l2[k];
+      }
+    }
+
+    // ---- post_physics_step (:674-727) ----
+    S.ep_buf += 1;     // :675
+    S.sim_steps += 1;  // :676
+    // base-link position for the bounds check (:758-759)
+    const float plx = __builtin_fmaf(-R[2], K.com_height, S.p[0]);
+    const float ply = __builtin_fmaf(-R[5], K.com_height, S.p[1]);
+    // is_done (:736-764)
+    const bool timeout = S.ep_buf >= K.max_episode_length - 1;  // :740-744
+    float pg[3];
+    quat_apply(S.q, 0.0f, 0.0f, -1.0f, pg);                      // :749
+    const bool fallen = pg[2] > 0.0f;                            // :753
+    const bool oob = (plx < -K.bounds) | (plx > K.bounds) | (ply < -K.bounds) | (ply > K.bounds);
+    const bool reset = fallen | timeout | oob;
+    // calculate_metrics (:767-822)
+    const float lin_acc = (current_v - S.prev_lin) / K.policy_dt;  // :770
+    const float ang_acc = (S.w[2] - S.prev_ang) / K.policy_dt;     // :771
+    S.prev_lin = current_v;                                        // :774
+    S.prev_ang = S.w[2];                                           // :775
+    const float r1 = vd * vd + 5.0f * (od * od);                   // :779
+    const float r2 = lin_acc * lin_acc + ang_acc * ang_acc;        // :781
+    const float r3 = (wt[0] * wt[0] + wt[1] * wt[1]) + (wt[2] * wt[2] + wt[3] * wt[3]);  // :783
+    const float c1 = K.w1 * r1, c2 = K.w2 * r2, c3 = K.w3 * r3;
+    const float rdense = (c1 + c2) + c3;                           // :786
+    const float sparse = (fabsf(vd) < K.sparse_threshold && fabsf(od) < K.sparse_threshold) ? K.sparse_bonus : 0.0f;
+    const float observed = rdense + sparse;                        // :795
+    float rew = (1.0f - gamma2) * observed + gamma2 * guiding;     // :798
+    rew += (K.terminal_reward * (reset ? 1.0f : 0.0f)) * (timeout ? -2.0f : -1.0f);  // :801 (~ on an int64 tensor)
+    S.sa[0] += c1; S.sa[1] += c2; S.sa[2] += c3; S.sa[3] += rdense;               // :803-806
+    S.sb[0] += sparse; S.sb[1] += guiding; S.sb[2] += observed; S.sb[3] += rew;   // :807-810
+    if (K.eval_sums) S.sc[1] += fabsf(vd) / 10.0f;                 // KAMMA_eval.py:840
+    rsum += rew;
+    // reset_idx (:417-498)
+    ResetContrib rc;
+    contrib_identity(rc);
+    const bool do_reset = reset && valid;
+    if (reset) reset_arena(K, gid, gamma1, gamma2, S, rc);
+    if (!valid) contrib_identity(rc);
+    // outputs (only the last step of a rollout is observable)
+    if (last && valid) {
+      // get_observations (:833); desired_* are views of commands -> post-reset values; clamp: rl_task.py:99
+      float* o = B.obs + (size_t)arena * 6;
+      const float co = K.clip_obs;
+      *reinterpret_cast<float2*>(o) = make_float2(clipf(S.cmd[0], -co, co), clipf(S.cmd[2], -co, co));
+      *reinterpret_cast<float2*>(o + 2) = make_float2(clipf(vd, -co, co), clipf(od, -co, co));
+      *reinterpret_cast<float2*>(o + 4) = make_float2(clipf(lin_acc, -co, co), clipf(ang_acc, -co, co));
+      B.rew[arena] = rew;
+      B.done[arena] = reset ? 1 : 0;
+      B.timeout[arena] = timeout ? 1 : 0;
+      if (arena == 0) {  // task.observed_components ingredients (:840-867)
+        float* d = B.env0_diag;
+        d[0] = S.cmd[0]; d[1] = current_v; d[2] = S.cmd[2]; d[3] = current_omega; d[4] = vd; d[5] = od;
+        d[6] = lin_acc; d[7] = ang_acc; d[8] = (float)S.ep_count;
+        for (int j = 0; j < 4; ++j) { d[9 + j] = torq[j]; d[15 + j] = pol[j]; }
+        d[13] = ac_left; d[14] = ac_right;
+        d[19] = gamma2; d[20] = c1; d[21] = c2; d[22] = c3; d[23] = rdense; d[24] = sparse; d[25] = observed;
+        d[26] = guiding; d[27] = rew; d[28] = gamma1;
+      }
+    }
+    // tail of post_physics_step (:701-710) on the possibly reset state
+    S.vfwd = forward_projection(S.q, S.v);
+    // per-group record of the reset event (extras["episode"], episode statistics)
+    const unsigned long long m = __ballot(do_reset);
+    if (m != 0ull) {
+      const bool grp = ((m >> (lane & ~(kGroup - 1))) & 0xFFFFull) != 0ull;
+      group_record(B, arena / kGroup, lane, grp, rc, S.sim_steps, true);
     }
   }
   if (valid) {
-    store_lane(K, B, tid, wl, S);
-    if (reward_sum != nullptr && wl == 0) reward_sum[arena] = rsum;
+    store_arena(K, B, arena, S);
+    if (reward_sum != nullptr) reward_sum[arena] = rsum;
   }
 }
 
 // ------------------------------------------------------------------ post_reset --------
 // KAMMA.py:366-414: zero the task buffers, reset_idx(all arenas).
 __global__ __launch_bounds__(kBlock) void reset_kernel(DevConsts K, DevBuffers B, int N) {
-  const int tid = blockIdx.x * kBlock + threadIdx.x;
+  const int arena = blockIdx.x * kBlock + threadIdx.x;
   const int lane = threadIdx.x & 63;
-  const int wave = tid >> 6;
-  const int wl = tid & 3;
-  const int arena = tid >> 2;
   const bool valid = arena < N;
   const int la = valid ? arena : N - 1;
-  const int64_t gid = K.arena_offset + la;
-  Lane S;
-  for (int k = 0; k < 3; ++k) { S.p[k] = 0.0f; S.v[k] = 0.0f; S.w[k] = 0.0f; }
-  for (int k = 0; k < 4; ++k) { S.q[k] = 0.0f; S.cmd[k] = 0.0f; }
-  S.vfwd = S.prev_lin = S.prev_ang = 0.0f;
+  Arena S;
+  for (int k = 0; k < 3; ++k) { S.p[k] = 0.0f; S.v[k] = 0.0f; S.w[k] = 0.0f; S.n[k] = 0.0f; }
+  for (int k = 0; k < 4; ++k) {
+    S.q[k] = 0.0f; S.cmd[k] = 0.0f; S.jv[k] = 0.0f; S.ln[k] = 0.0f; S.l1[k] = 0.0f; S.l2[k] = 0.0f; S.wt[k] = 0.0f;
+    S.sa[k] = 0.0f; S.sb[k] = 0.0f; S.sc[k] = 0.0f;
+  }
+  S.vfwd = S.prev_lin = S.prev_ang = S.mu = 0.0f;
   S.ep_buf = S.sim_steps = S.ep_count = 0;
-  S.jv = S.ln = S.l1 = S.l2 = S.wt = S.sa = S.sb = S.sc = 0.0f;
-  S.mu = 0.0f; S.n[0] = S.n[1] = 0.0f; S.n[2] = 1.0f;
   // gamma_assist1/2 hold their constructor values here (KAMMA.py:192-193: ones)
   const float g1 = K.gamma1_mode == OIS_GAMMA_CONST ? K.gamma1_const : 1.0f;
   const float g2 = K.gamma2_mode == OIS_GAMMA_CONST ? K.gamma2_const : 1.0f;
   ResetContrib rc;
-  reset_arena(K, wl, gid, g1, g2, S, rc);
-  if (!valid) rc = contrib_identity(wl);
-  if (lane < 4) {  // clear the finished-episode accumulators of this wave
-    float* Acc = B.stat_acc + (size_t)wave * 8;
-    Acc[lane] = 0.0f;
-    Acc[4 + lane] = -__builtin_inff();
+  reset_arena(K, K.arena_offset + la, g1, g2, S, rc);
+  if (!valid) contrib_identity(rc);
+  if ((lane & (kGroup - 1)) == 0 && valid) {  // clear the finished-episode accumulators of this group
+    float* Acc = B.stat_acc + (size_t)(arena / kGroup) * 8;
+    for (int k = 0; k < 4; ++k) { Acc[k] = 0.0f; Acc[4 + k] = -__builtin_inff(); }
   }
-  wave_record(B, wave, lane, rc, 0, false);
+  const unsigned long long m = __ballot(valid);
+  const bool grp = ((m >> (lane & ~(kGroup - 1))) & 0xFFFFull) != 0ull;
+  group_record(B, arena / kGroup, lane, grp, rc, 0, false);
   if (valid) {
     // params are owned by ois_create / ois_randomize_params: keep them
-    B.pose[tid] = sel4(wl, S.p[0], S.p[1], S.p[2], S.vfwd);
-    B.quat[tid] = sel4(wl, S.q[0], S.q[1], S.q[2], S.q[3]);
-    B.linvel[tid] = sel4(wl, S.v[0], S.v[1], S.v[2], S.prev_lin);
-    B.angvel[tid] = sel4(wl, S.w[0], S.w[1], S.w[2], S.prev_ang);
-    B.commands[tid] = sel4(wl, S.cmd[0], S.cmd[1], S.cmd[2], S.cmd[3]);
-    B.counters[tid] = (wl & 2) ? ((wl & 1) ? 0 : S.ep_count) : ((wl & 1) ? S.sim_steps : S.ep_buf);
-    B.wheel_vel[tid] = S.jv;
-    B.lam_n[tid] = 0.0f; B.lam_l[tid] = 0.0f; B.lam_t[tid] = 0.0f;
-    B.sums_a[tid] = 0.0f; B.sums_b[tid] = 0.0f; B.sums_c[tid] = 0.0f;
-    B.wheel_torqs[tid] = 0.0f;
-    B.obs[(size_t)arena * 6 + wl] = 0.0f;
-    if (wl < 2) B.obs[(size_t)arena * 6 + 4 + wl] = 0.0f;
-    if (wl == 0) { B.rew[arena] = 0.0f; B.done[arena] = 0; B.timeout[arena] = 0; }
+    B.pose[arena] = make_float4(S.p[0], S.p[1], S.p[2], S.vfwd);
+    B.quat[arena] = make_float4(S.q[0], S.q[1], S.q[2], S.q[3]);
+    B.linvel[arena] = make_float4(S.v[0], S.v[1], S.v[2], S.prev_lin);
+    B.angvel[arena] = make_float4(S.w[0], S.w[1], S.w[2], S.prev_ang);
+    B.commands[arena] = make_float4(S.cmd[0], S.cmd[1], S.cmd[2], S.cmd[3]);
+    B.counters[arena] = make_int4(S.ep_buf, S.sim_steps, S.ep_count, 0);
+    B.wheel_vel[arena] = make_float4(S.jv[0], S.jv[1], S.jv[2], S.jv[3]);
+    const float4 z = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+    B.lam_n[arena] = z; B.lam_l[arena] = z; B.lam_t[arena] = z;
+    B.sums_a[arena] = z; B.sums_b[arena] = z; B.sums_c[arena] = z; B.wheel_torqs[arena] = z;
+    for (int k = 0; k < 6; ++k) B.obs[(size_t)arena * 6 + k] = 0.0f;
+    B.rew[arena] = 0.0f; B.done[arena] = 0; B.timeout[arena] = 0;
   }
-  if (tid < OIS_ENV0_DIAG_LEN) { B.env0_diag[tid] = 0.0f; B.episode_info[tid] = 0.0f; }
+  if (arena < OIS_ENV0_DIAG_LEN) { B.env0_diag[arena] = 0.0f; B.episode_info[arena] = 0.0f; }
 }
 
 __global__ void init_params_kernel(DevBuffers B, int N, float mu) {
-  const int tid = blockIdx.x * blockDim.x + threadIdx.x;
-  if (tid < N * 4) B.params[tid] = (tid & 3) == 0 ? mu : ((tid & 3) == 3 ? 1.0f : 0.0f);
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < N) B.params[i] = make_float4(mu, 0.0f, 0.0f, 1.0f);
 }
 
 // per-arena domain randomisation (BASELINE.json config 4)
@@ -280,8 +322,7 @@ __global__ void randomize_params_kernel(DevConsts K, DevBuffers B, int N, float 
     const float inv = 1.0f / sqrtf(__builtin_fmaf(sl, sl, 1.0f));
     nx = -(sl * c) * inv; ny = -(sl * s) * inv; nz = inv;
   }
-  float* p = B.params + (size_t)i * 4;
-  p[0] = rand_float(mu_lo, mu_hi, u[0]); p[1] = nx; p[2] = ny; p[3] = nz;
+  B.params[i] = make_float4(rand_float(mu_lo, mu_hi, u[0]), nx, ny, nz);
 }
 
 // extras["episode"] (KAMMA.py:480-488): deterministic in-order sum of the per-wave records
@@ -381,7 +422,7 @@ Layout make_layout(int N) {
   put(OIS_BUF_TIMEOUT, (size_t)N);
   put(OIS_BUF_EPISODE_INFO, OIS_EPISODE_INFO_LEN * sizeof(float));
   put(OIS_BUF_ENV0_DIAG, OIS_ENV0_DIAG_LEN * sizeof(float));
-  L.nwaves = (N * 4 + 63) / 64;
+  L.nwaves = (N + kGroup - 1) / kGroup;  // reduction groups of 16 arenas
   L.partials = o; o = align256(o + (size_t)L.nwaves * 32 * sizeof(float));
   L.stamps = o; o = align256(o + (size_t)L.nwaves * sizeof(int32_t));
   L.stat_acc = o; o = align256(o + (size_t)L.nwaves * 8 * sizeof(float));
@@ -543,20 +584,20 @@ int ois_create(const ois_config* cfg, int device, void* workspace_device, size_t
   e->ws = (char*)workspace_device;
   e->N = cfg->num_envs;
   e->device = device;
-  e->grid = (e->N * 4 + kBlock - 1) / kBlock;
+  e->grid = (e->N + kBlock - 1) / kBlock;
   e->seed = cfg->seed;
   e->reset_done = false;
   e->steps_done = 0.0;
   char* w = e->ws;
   DevBuffers& B = e->B;
-  B.pose = (float*)(w + L.off[OIS_BUF_POSE]); B.quat = (float*)(w + L.off[OIS_BUF_QUAT]);
-  B.linvel = (float*)(w + L.off[OIS_BUF_LINVEL]); B.angvel = (float*)(w + L.off[OIS_BUF_ANGVEL]);
-  B.wheel_vel = (float*)(w + L.off[OIS_BUF_WHEEL_VEL]); B.commands = (float*)(w + L.off[OIS_BUF_COMMANDS]);
-  B.counters = (int32_t*)(w + L.off[OIS_BUF_COUNTERS]);
-  B.sums_a = (float*)(w + L.off[OIS_BUF_SUMS_A]); B.sums_b = (float*)(w + L.off[OIS_BUF_SUMS_B]);
-  B.sums_c = (float*)(w + L.off[OIS_BUF_SUMS_C]); B.params = (float*)(w + L.off[OIS_BUF_PARAMS]);
-  B.lam_n = (float*)(w + L.off[OIS_BUF_LAMBDA_N]); B.lam_l = (float*)(w + L.off[OIS_BUF_LAMBDA_L]);
-  B.lam_t = (float*)(w + L.off[OIS_BUF_LAMBDA_T]); B.wheel_torqs = (float*)(w + L.off[OIS_BUF_WHEEL_TORQS]);
+  B.pose = (float4*)(w + L.off[OIS_BUF_POSE]); B.quat = (float4*)(w + L.off[OIS_BUF_QUAT]);
+  B.linvel = (float4*)(w + L.off[OIS_BUF_LINVEL]); B.angvel = (float4*)(w + L.off[OIS_BUF_ANGVEL]);
+  B.wheel_vel = (float4*)(w + L.off[OIS_BUF_WHEEL_VEL]); B.commands = (float4*)(w + L.off[OIS_BUF_COMMANDS]);
+  B.counters = (int4*)(w + L.off[OIS_BUF_COUNTERS]);
+  B.sums_a = (float4*)(w + L.off[OIS_BUF_SUMS_A]); B.sums_b = (float4*)(w + L.off[OIS_BUF_SUMS_B]);
+  B.sums_c = (float4*)(w + L.off[OIS_BUF_SUMS_C]); B.params = (float4*)(w + L.off[OIS_BUF_PARAMS]);
+  B.lam_n = (float4*)(w + L.off[OIS_BUF_LAMBDA_N]); B.lam_l = (float4*)(w + L.off[OIS_BUF_LAMBDA_L]);
+  B.lam_t = (float4*)(w + L.off[OIS_BUF_LAMBDA_T]); B.wheel_torqs = (float4*)(w + L.off[OIS_BUF_WHEEL_TORQS]);
   B.obs = (float*)(w + L.off[OIS_BUF_OBS]); B.rew = (float*)(w + L.off[OIS_BUF_REW]);
   B.done = (uint8_t*)(w + L.off[OIS_BUF_DONE]); B.timeout = (uint8_t*)(w + L.off[OIS_BUF_TIMEOUT]);
   B.episode_info = (float*)(w + L.off[OIS_BUF_EPISODE_INFO]); B.env0_diag = (float*)(w + L.off[OIS_BUF_ENV0_DIAG]);
@@ -564,7 +605,7 @@ int ois_create(const ois_config* cfg, int device, void* workspace_device, size_t
   // default per-arena parameters: mu = cfg.friction, flat plane n = +z
   hipError_t he = hipMemsetAsync(e->ws, 0, L.total, nullptr);
   if (he == hipSuccess) {
-    hipLaunchKernelGGL(init_params_kernel, dim3((e->N * 4 + 255) / 256), dim3(256), 0, nullptr, e->B, e->N, cfg->friction);
+    hipLaunchKernelGGL(init_params_kernel, dim3((e->N + 255) / 256), dim3(256), 0, nullptr, e->B, e->N, cfg->friction);
     he = hipGetLastError();
   }
   if (he == hipSuccess) he = hipStreamSynchronize(nullptr);

@@ -1,0 +1,173 @@
+// ois_physics.h — one physics substep of one arena (docs/SPEC.md §3), executed by one lane.
+//
+// Rigid chassis (6 DoF) + 4 wheel spins, 4 wheel-ground contact points on a plane, each with
+// a normal row and two Coulomb (box) friction rows; the longitudinal row couples the wheel
+// spin. Solver: mass-splitting Jacobi across the 4 contacts (each contact solves against a
+// private copy of the chassis velocity with 4x the inverse mass, the copies are averaged),
+// Gauss-Seidel across the 3 rows of a contact, 4 iterations, warm-started from the previous
+// substep's impulses. The 4 contacts are independent inside an iteration, so the fully
+// unrolled loop over k gives the SIMD four interleavable instruction streams.
+// Mirrors oracle/ois_oracle.c substep() operation for operation.
+#pragma once
+#include "ois_device.h"
+
+namespace ois {
+
+struct Phys {
+  float p[3], q[4], v[3];  // COM position, orientation (w,x,y,z), WORLD linear velocity
+  float wb[3];             // BODY-frame angular velocity (constant between substeps, SPEC §3.2)
+  float n[3], mu;          // ground plane normal (world), friction coefficient
+  float tau[4];            // clipped drive torques, wheel order fl, rl, fr, rr
+  float spin[4];           // absolute wheel spins about the body y axis
+  float ln[4], l1[4], l2[4];  // accumulated normal / longitudinal / lateral contact impulses
+};
+
+OIS_DEV void substep(const DevConsts& K, Phys& S) {
+  float R[9];
+  rotmat(S.q, R);
+  float vb[3], nb[3], wb[3] = {S.wb[0], S.wb[1], S.wb[2]};
+  rotT(R, S.v, vb);
+  rotT(R, S.n, nb);
+  // gravity (world -z) in the body frame
+  vb[0] = __builtin_fmaf(-K.gdt, R[6], vb[0]);
+  vb[1] = __builtin_fmaf(-K.gdt, R[7], vb[1]);
+  vb[2] = __builtin_fmaf(-K.gdt, R[8], vb[2]);
+  // wheel drive + viscous joint damping, reaction on the chassis
+  float Tq[4];
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    const float jv = S.spin[k] - wb[1];
+    Tq[k] = __builtin_fmaf(-K.damping, jv, S.tau[k]);
+    S.spin[k] = __builtin_fmaf(K.dt_over_Is, Tq[k], S.spin[k]);
+  }
+  const float Tsum = (Tq[0] + Tq[1]) + (Tq[2] + Tq[3]);
+  wb[1] = __builtin_fmaf(-K.dt_over_Iy, Tsum, wb[1]);
+  // contact frame shared by the four wheels (common axle direction = body y)
+  float s2 = __builtin_fmaf(nb[2], nb[2], nb[0] * nb[0]);
+  s2 = fmaxf(s2, 1e-12f);
+  const float inv_s = 1.0f / sqrtf(s2);
+  const float dx = -(nb[0] * inv_s), dz = -(nb[2] * inv_s);
+  const float t1x = -dz, t1z = dx;
+  const float t2x = nb[1] * t1z;
+  const float t2y = __builtin_fmaf(nb[2], t1x, -(nb[0] * t1z));
+  const float t2z = -(nb[1] * t1x);
+  const float np = __builtin_fmaf(S.n[2], S.p[2], __builtin_fmaf(S.n[1], S.p[1], S.n[0] * S.p[0]));
+  const float cz = K.cz;
+  float b[4], an[4][3], a1[4][3], a2[4][3], Jan[4][3], Ja1[4][3], Ja2[4][3], mn[4], m1[4], m2[4];
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    // wheel centres relative to the COM, env order fl, rl, fr, rr (urdf:112-142: left = +y, front = +x)
+    const float cx = (k & 1) ? -K.wx : K.wx;
+    const float cy = (k & 2) ? -K.wy : K.wy;
+    const float rx = __builtin_fmaf(K.rw, dx, cx), ry = cy, rz = __builtin_fmaf(K.rw, dz, cz);
+    const float gap = np + __builtin_fmaf(nb[2], rz, __builtin_fmaf(nb[1], ry, nb[0] * rx));
+    b[k] = gap >= 0.0f ? -(gap * K.inv_dt) : fminf(-(gap * K.beta_inv_dt), K.vdep);
+    an[k][0] = __builtin_fmaf(ry, nb[2], -(rz * nb[1]));
+    an[k][1] = __builtin_fmaf(rz, nb[0], -(rx * nb[2]));
+    an[k][2] = __builtin_fmaf(rx, nb[1], -(ry * nb[0]));
+    a1[k][0] = cy * t1z;
+    a1[k][1] = __builtin_fmaf(cz, t1x, -(cx * t1z));
+    a1[k][2] = -(cy * t1x);
+    a2[k][0] = __builtin_fmaf(ry, t2z, -(rz * t2y));
+    a2[k][1] = __builtin_fmaf(rz, t2x, -(rx * t2z));
+    a2[k][2] = __builtin_fmaf(rx, t2y, -(ry * t2x));
+    Jan[k][0] = K.J4x * an[k][0]; Jan[k][1] = K.J4y * an[k][1]; Jan[k][2] = K.J4z * an[k][2];
+    Ja1[k][0] = K.J4x * a1[k][0]; Ja1[k][1] = K.J4y * a1[k][1]; Ja1[k][2] = K.J4z * a1[k][2];
+    Ja2[k][0] = K.J4x * a2[k][0]; Ja2[k][1] = K.J4y * a2[k][1]; Ja2[k][2] = K.J4z * a2[k][2];
+    const float kn = __builtin_fmaf(an[k][2], Jan[k][2], __builtin_fmaf(an[k][1], Jan[k][1], __builtin_fmaf(an[k][0], Jan[k][0], K.im4)));
+    const float k1 = __builtin_fmaf(a1[k][2], Ja1[k][2], __builtin_fmaf(a1[k][1], Ja1[k][1], __builtin_fmaf(a1[k][0], Ja1[k][0], K.im4))) + K.rw2_over_Is;
+    const float k2 = __builtin_fmaf(a2[k][2], Ja2[k][2], __builtin_fmaf(a2[k][1], Ja2[k][1], __builtin_fmaf(a2[k][0], Ja2[k][0], K.im4)));
+    mn[k] = 1.0f / kn;
+    m1[k] = 1.0f / k1;
+    m2[k] = 1.0f / k2;
+  }
+  const float vnx = K.im4 * nb[0], vny = K.im4 * nb[1], vnz = K.im4 * nb[2];
+  const float v1x = K.im4 * t1x, v1z = K.im4 * t1z;
+  const float v2x = K.im4 * t2x, v2y = K.im4 * t2y, v2z = K.im4 * t2z;
+  float vl[4][3], wl[4][3];
+  // warm start: one mass-split averaging pass with the cached impulses
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    const float ln = S.ln[k], l1 = S.l1[k], l2 = S.l2[k];
+    vl[k][0] = __builtin_fmaf(l2, v2x, __builtin_fmaf(l1, v1x, __builtin_fmaf(ln, vnx, vb[0])));
+    vl[k][1] = __builtin_fmaf(l2, v2y, __builtin_fmaf(ln, vny, vb[1]));
+    vl[k][2] = __builtin_fmaf(l2, v2z, __builtin_fmaf(l1, v1z, __builtin_fmaf(ln, vnz, vb[2])));
+#pragma unroll
+    for (int j = 0; j < 3; ++j)
+      wl[k][j] = __builtin_fmaf(l2, Ja2[k][j], __builtin_fmaf(l1, Ja1[k][j], __builtin_fmaf(ln, Jan[k][j], wb[j])));
+    S.spin[k] = __builtin_fmaf(-K.rw_over_Is, l1, S.spin[k]);
+  }
+#pragma unroll
+  for (int j = 0; j < 3; ++j) {
+    vb[j] = 0.25f * ((vl[0][j] + vl[1][j]) + (vl[2][j] + vl[3][j]));
+    wb[j] = 0.25f * ((wl[0][j] + wl[1][j]) + (wl[2][j] + wl[3][j]));
+  }
+  for (int it = 0; it < K.iters; ++it) {
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      float vx = vb[0], vy = vb[1], vz = vb[2], ox = wb[0], oy = wb[1], oz = wb[2];
+      // normal row
+      float u = __builtin_fmaf(an[k][2], oz, __builtin_fmaf(an[k][1], oy, __builtin_fmaf(an[k][0], ox,
+                __builtin_fmaf(nb[2], vz, __builtin_fmaf(nb[1], vy, nb[0] * vx)))));
+      float dl = (b[k] - u) * mn[k];
+      float nw = fmaxf(S.ln[k] + dl, 0.0f);
+      dl = nw - S.ln[k];
+      S.ln[k] = nw;
+      vx = __builtin_fmaf(dl, vnx, vx); vy = __builtin_fmaf(dl, vny, vy); vz = __builtin_fmaf(dl, vnz, vz);
+      ox = __builtin_fmaf(dl, Jan[k][0], ox); oy = __builtin_fmaf(dl, Jan[k][1], oy); oz = __builtin_fmaf(dl, Jan[k][2], oz);
+      const float lim = S.mu * S.ln[k];
+      // longitudinal row (couples the wheel spin)
+      u = __builtin_fmaf(-K.rw, S.spin[k], __builtin_fmaf(a1[k][2], oz, __builtin_fmaf(a1[k][1], oy,
+          __builtin_fmaf(a1[k][0], ox, __builtin_fmaf(t1z, vz, t1x * vx)))));
+      dl = -(u * m1[k]);
+      nw = fminf(fmaxf(S.l1[k] + dl, -lim), lim);
+      dl = nw - S.l1[k];
+      S.l1[k] = nw;
+      vx = __builtin_fmaf(dl, v1x, vx); vz = __builtin_fmaf(dl, v1z, vz);
+      ox = __builtin_fmaf(dl, Ja1[k][0], ox); oy = __builtin_fmaf(dl, Ja1[k][1], oy); oz = __builtin_fmaf(dl, Ja1[k][2], oz);
+      S.spin[k] = __builtin_fmaf(-K.rw_over_Is, dl, S.spin[k]);
+      // lateral row
+      u = __builtin_fmaf(a2[k][2], oz, __builtin_fmaf(a2[k][1], oy, __builtin_fmaf(a2[k][0], ox,
+          __builtin_fmaf(t2z, vz, __builtin_fmaf(t2y, vy, t2x * vx)))));
+      dl = -(u * m2[k]);
+      nw = fminf(fmaxf(S.l2[k] + dl, -lim), lim);
+      dl = nw - S.l2[k];
+      S.l2[k] = nw;
+      vl[k][0] = __builtin_fmaf(dl, v2x, vx); vl[k][1] = __builtin_fmaf(dl, v2y, vy); vl[k][2] = __builtin_fmaf(dl, v2z, vz);
+      wl[k][0] = __builtin_fmaf(dl, Ja2[k][0], ox); wl[k][1] = __builtin_fmaf(dl, Ja2[k][1], oy); wl[k][2] = __builtin_fmaf(dl, Ja2[k][2], oz);
+    }
+    // mass-splitting average over the 4 contacts
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {
+      vb[j] = 0.25f * ((vl[0][j] + vl[1][j]) + (vl[2][j] + vl[3][j]));
+      wb[j] = 0.25f * ((wl[0][j] + wl[1][j]) + (wl[2][j] + wl[3][j]));
+    }
+  }
+  // linear velocity back to the world frame, velocity caps (origin_v18.py:65-70), integrate
+  rot(R, vb, S.v);
+  const float w2 = __builtin_fmaf(wb[2], wb[2], __builtin_fmaf(wb[1], wb[1], wb[0] * wb[0]));
+  if (w2 > K.maxw2) {
+    const float sc = K.maxw / sqrtf(w2);
+    wb[0] *= sc; wb[1] *= sc; wb[2] *= sc;
+  }
+  S.wb[0] = wb[0]; S.wb[1] = wb[1]; S.wb[2] = wb[2];
+#pragma unroll
+  for (int k = 0; k < 4; ++k) S.spin[k] = fminf(fmaxf(S.spin[k], -K.maxw), K.maxw);
+  S.p[0] = __builtin_fmaf(K.dt, S.v[0], S.p[0]);
+  S.p[1] = __builtin_fmaf(K.dt, S.v[1], S.p[1]);
+  S.p[2] = __builtin_fmaf(K.dt, S.v[2], S.p[2]);
+  // q += dt/2 * q (x) (0, w_b), then renormalise
+  const float qw = S.q[0], qx = S.q[1], qy = S.q[2], qz = S.q[3], h = K.half_dt;
+  const float nqw = __builtin_fmaf(-h, __builtin_fmaf(qz, wb[2], __builtin_fmaf(qy, wb[1], qx * wb[0])), qw);
+  const float nqx = __builtin_fmaf(h, __builtin_fmaf(-qz, wb[1], __builtin_fmaf(qy, wb[2], qw * wb[0])), qx);
+  const float nqy = __builtin_fmaf(h, __builtin_fmaf(-qx, wb[2], __builtin_fmaf(qz, wb[0], qw * wb[1])), qy);
+  const float nqz = __builtin_fmaf(h, __builtin_fmaf(-qy, wb[0], __builtin_fmaf(qx, wb[1], qw * wb[2])), qz);
+  const float nn = __builtin_fmaf(nqz, nqz, __builtin_fmaf(nqy, nqy, __builtin_fmaf(nqx, nqx, nqw * nqw)));
+  // |q|^2 = 1 + O((w dt)^2): one Newton step of 1/sqrt is exact to float precision; the exact
+  // form only when the norm has drifted (extreme spin)
+  float inv = __builtin_fmaf(-0.5f, nn, 1.5f);
+  if (fabsf(nn - 1.0f) > 1e-3f) inv = 1.0f / sqrtf(nn);
+  S.q[0] = nqw * inv; S.q[1] = nqx * inv; S.q[2] = nqy * inv; S.q[3] = nqz * inv;
+}
+
+}  // namespace ois

@@ -359,15 +359,17 @@ static inline void rot(const float R[9], const float a[3], float o[3]) {
 
 /* One physics substep (docs/SPEC.md §3). spin[] = absolute wheel spin about the body y
  * axis (joint velocity + chassis w_y). Mass-splitting Jacobi across the 4 wheel contacts,
- * Gauss-Seidel across the 3 rows (normal, longitudinal, lateral) of each contact. */
+ * Gauss-Seidel across the 3 rows (normal, longitudinal, lateral) of each contact.
+ * v is the WORLD linear velocity, wb the BODY-frame angular velocity: a torque-free body
+ * with gyroscopic forces disabled (KAMMA.py:119) keeps its world w constant, and
+ * d(R^T w)/dt = -w_b x w_b = 0, so w_b is carried from substep to substep unchanged. */
 static void substep(const derived* D, float mu, const float n[3], const float tau[4], float p[3],
-                    float q[4], float v[3], float w[3], float spin[4], float ln[4], float l1[4],
+                    float q[4], float v[3], float wb[3], float spin[4], float ln[4], float l1[4],
                     float l2[4]) {
   float R[9];
   rotmat(q, R);
-  float vb[3], wb[3], nb[3];
+  float vb[3], nb[3];
   rotT(R, v, vb);
-  rotT(R, w, wb);
   rotT(R, n, nb);
   /* gravity (world -z) in the body frame */
   vb[0] = fmaf(-D->gdt, R[6], vb[0]);
@@ -481,32 +483,41 @@ static void substep(const derived* D, float mu, const float n[3], const float ta
   }
   /* back to the world frame, velocity caps (origin_v18.py:65-70), integrate */
   rot(R, vb, v);
-  rot(R, wb, w);
-  float w2 = fmaf(w[2], w[2], fmaf(w[1], w[1], w[0] * w[0]));
+  float w2 = fmaf(wb[2], wb[2], fmaf(wb[1], wb[1], wb[0] * wb[0]));
   if (w2 > D->maxw2) {
     float sc = D->maxw / sqrtf(w2);
-    w[0] *= sc; w[1] *= sc; w[2] *= sc;
+    wb[0] *= sc; wb[1] *= sc; wb[2] *= sc;
   }
   for (int k = 0; k < 4; ++k) spin[k] = fminf(fmaxf(spin[k], -D->maxw), D->maxw);
   p[0] = fmaf(D->dt, v[0], p[0]);
   p[1] = fmaf(D->dt, v[1], p[1]);
   p[2] = fmaf(D->dt, v[2], p[2]);
+  /* q += dt/2 * q (x) (0, w_b), then renormalise */
   float qw = q[0], qx = q[1], qy = q[2], qz = q[3], h = D->half_dt;
-  float nqw = fmaf(-h, fmaf(w[2], qz, fmaf(w[1], qy, w[0] * qx)), qw);
-  float nqx = fmaf(h, fmaf(-w[2], qy, fmaf(w[1], qz, w[0] * qw)), qx);
-  float nqy = fmaf(h, fmaf(-w[0], qz, fmaf(w[2], qx, w[1] * qw)), qy);
-  float nqz = fmaf(h, fmaf(-w[1], qx, fmaf(w[0], qy, w[2] * qw)), qz);
+  float nqw = fmaf(-h, fmaf(qz, wb[2], fmaf(qy, wb[1], qx * wb[0])), qw);
+  float nqx = fmaf(h, fmaf(-qz, wb[1], fmaf(qy, wb[2], qw * wb[0])), qx);
+  float nqy = fmaf(h, fmaf(-qx, wb[2], fmaf(qz, wb[0], qw * wb[1])), qy);
+  float nqz = fmaf(h, fmaf(-qy, wb[0], fmaf(qx, wb[1], qw * wb[2])), qz);
   float nn = fmaf(nqz, nqz, fmaf(nqy, nqy, fmaf(nqx, nqx, nqw * nqw)));
-  float inv = 1.0f / sqrtf(nn);
+  /* |q|^2 = 1 + O((w dt)^2): one Newton step of 1/sqrt is exact to float precision; the
+   * exact form only when the norm has drifted (extreme spin) */
+  float inv = fmaf(-0.5f, nn, 1.5f);
+  if (fabsf(nn - 1.0f) > 1e-3f) inv = 1.0f / sqrtf(nn);
   q[0] = nqw * inv; q[1] = nqx * inv; q[2] = nqy * inv; q[3] = nqz * inv;
 }
 
+/* w is the WORLD angular velocity here (converted to the body frame and back) */
 void orc_substep(const ois_config* cfg, float mu, const float n_world[3], const float tau[4],
                  float p[3], float q[4], float v[3], float w[3], float spin[4], float lam_n[4],
                  float lam_l[4], float lam_t[4]) {
   derived D;
   derive(cfg, &D);
-  substep(&D, mu, n_world, tau, p, q, v, w, spin, lam_n, lam_l, lam_t);
+  float R[9], wb[3];
+  rotmat(q, R);
+  rotT(R, w, wb);
+  substep(&D, mu, n_world, tau, p, q, v, wb, spin, lam_n, lam_l, lam_t);
+  rotmat(q, R);
+  rot(R, wb, w);
 }
 
 /* ------------------------------------------------------------------ environment ------ */
@@ -860,9 +871,9 @@ static float step_arena(orc_env* e, int i, const float* act /*[A]*/, uint8_t* rs
   float* LN = &e->lam_n[4 * i];
   float* LL = &e->lam_l[4 * i];
   float* LT = &e->lam_t[4 * i];
-  for (int s = 0; s < nsub; ++s) substep(D, mu, n, wt, p, q, v, w, spin, LN, LL, LT);
+  for (int s = 0; s < nsub; ++s) substep(D, mu, n, wt, p, q, v, wb, spin, LN, LL, LT);
   rotmat(q, R);
-  rotT(R, w, wb);
+  rot(R, wb, w); /* body -> world with the final orientation */
   float jv[4];
   for (int k = 0; k < 4; ++k) jv[k] = spin[k] - wb[1];
 
