@@ -169,7 +169,8 @@ __global__ __launch_bounds__(kBlock) void step_kernel(DevConsts K, DevBuffers B,
         X.ln[k] = S.ln[k]; X.l1[k] = S.l1[k]; X.l2[k] = S.l2[k];
       }
       X.mu = S.mu;
-      for (int i = 0; i < K.nsub; ++i) substep(K, X);
+      substep<true>(K, X);
+      for (int i = 1; i < K.nsub; ++i) substep<false>(K, X);
       rotmat(X.q, R);
       rot(R, X.wb, S.w);  // body -> world with the final orientation
 #pragma unroll

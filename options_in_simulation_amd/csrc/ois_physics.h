@@ -20,8 +20,23 @@ struct Phys {
   float tau[4];            // clipped drive torques, wheel order fl, rl, fr, rr
   float spin[4];           // absolute wheel spins about the body y axis
   float ln[4], l1[4], l2[4];  // accumulated normal / longitudinal / lateral contact impulses
+  float mn[4], m1[4], m2[4], inv_s;  // reciprocal cache (SPEC §3.6), valid inside one policy step
 };
 
+// One Newton step from the previous substep's value: mul/fma only, bit-reproducible.
+OIS_DEV float newton_rcp(float m, float k) {  // m ~ 1/k -> m (2 - k m)
+  const float e = __builtin_fmaf(-k, m, 1.0f);
+  return __builtin_fmaf(m, e, m);
+}
+OIS_DEV float newton_rsqrt(float r, float s2) {  // r ~ 1/sqrt(s2) -> r (1.5 - 0.5 s2 r^2)
+  const float hr = (0.5f * s2) * r;
+  const float e = __builtin_fmaf(-hr, r, 1.5f);
+  return r * e;
+}
+
+// EXACT: first substep of a policy step (IEEE divisions); otherwise the reciprocals are
+// refreshed from the cache.
+template <bool EXACT>
 OIS_DEV void substep(const DevConsts& K, Phys& S) {
   float R[9];
   rotmat(S.q, R);
@@ -45,7 +60,8 @@ OIS_DEV void substep(const DevConsts& K, Phys& S) {
   // contact frame shared by the four wheels (common axle direction = body y)
   float s2 = __builtin_fmaf(nb[2], nb[2], nb[0] * nb[0]);
   s2 = fmaxf(s2, 1e-12f);
-  const float inv_s = 1.0f / sqrtf(s2);
+  const float inv_s = EXACT ? 1.0f / sqrtf(s2) : newton_rsqrt(S.inv_s, s2);
+  S.inv_s = inv_s;
   const float dx = -(nb[0] * inv_s), dz = -(nb[2] * inv_s);
   const float t1x = -dz, t1z = dx;
   const float t2x = nb[1] * t1z;
@@ -53,7 +69,8 @@ OIS_DEV void substep(const DevConsts& K, Phys& S) {
   const float t2z = -(nb[1] * t1x);
   const float np = __builtin_fmaf(S.n[2], S.p[2], __builtin_fmaf(S.n[1], S.p[1], S.n[0] * S.p[0]));
   const float cz = K.cz;
-  float b[4], an[4][3], a1[4][3], a2[4][3], Jan[4][3], Ja1[4][3], Ja2[4][3], mn[4], m1[4], m2[4];
+  float b[4], an[4][3], a1[4][3], a2[4][3], Jan[4][3], Ja1[4][3], Ja2[4][3];
+  float (&mn)[4] = S.mn, (&m1)[4] = S.m1, (&m2)[4] = S.m2;
 #pragma unroll
   for (int k = 0; k < 4; ++k) {
     // wheel centres relative to the COM, env order fl, rl, fr, rr (urdf:112-142: left = +y, front = +x)
@@ -77,9 +94,9 @@ OIS_DEV void substep(const DevConsts& K, Phys& S) {
     const float kn = __builtin_fmaf(an[k][2], Jan[k][2], __builtin_fmaf(an[k][1], Jan[k][1], __builtin_fmaf(an[k][0], Jan[k][0], K.im4)));
     const float k1 = __builtin_fmaf(a1[k][2], Ja1[k][2], __builtin_fmaf(a1[k][1], Ja1[k][1], __builtin_fmaf(a1[k][0], Ja1[k][0], K.im4))) + K.rw2_over_Is;
     const float k2 = __builtin_fmaf(a2[k][2], Ja2[k][2], __builtin_fmaf(a2[k][1], Ja2[k][1], __builtin_fmaf(a2[k][0], Ja2[k][0], K.im4)));
-    mn[k] = 1.0f / kn;
-    m1[k] = 1.0f / k1;
-    m2[k] = 1.0f / k2;
+    mn[k] = EXACT ? 1.0f / kn : newton_rcp(mn[k], kn);
+    m1[k] = EXACT ? 1.0f / k1 : newton_rcp(m1[k], k1);
+    m2[k] = EXACT ? 1.0f / k2 : newton_rcp(m2[k], k2);
   }
   const float vnx = K.im4 * nb[0], vny = K.im4 * nb[1], vnz = K.im4 * nb[2];
   const float v1x = K.im4 * t1x, v1z = K.im4 * t1z;
@@ -102,40 +119,65 @@ OIS_DEV void substep(const DevConsts& K, Phys& S) {
     vb[j] = 0.25f * ((vl[0][j] + vl[1][j]) + (vl[2][j] + vl[3][j]));
     wb[j] = 0.25f * ((wl[0][j] + wl[1][j]) + (wl[2][j] + wl[3][j]));
   }
+  // The 4 contacts are independent within an iteration. The source walks them in LOCK-STEP
+  // (one dot-product / update stage for all four wheels before the next stage) so that the
+  // in-order SIMD always has 4 independent instructions in flight: at 65 536 arenas there is
+  // only one wave per SIMD, and a single dependent fma chain issues every ~1.9 ns against
+  // ~1.3 ns for independent instructions (profiles/r1_valu_rate.txt).
+#define OIS_W4 _Pragma("unroll") for (int k = 0; k < 4; ++k)
   for (int it = 0; it < K.iters; ++it) {
-#pragma unroll
-    for (int k = 0; k < 4; ++k) {
-      float vx = vb[0], vy = vb[1], vz = vb[2], ox = wb[0], oy = wb[1], oz = wb[2];
-      // normal row
-      float u = __builtin_fmaf(an[k][2], oz, __builtin_fmaf(an[k][1], oy, __builtin_fmaf(an[k][0], ox,
-                __builtin_fmaf(nb[2], vz, __builtin_fmaf(nb[1], vy, nb[0] * vx)))));
-      float dl = (b[k] - u) * mn[k];
-      float nw = fmaxf(S.ln[k] + dl, 0.0f);
-      dl = nw - S.ln[k];
-      S.ln[k] = nw;
-      vx = __builtin_fmaf(dl, vnx, vx); vy = __builtin_fmaf(dl, vny, vy); vz = __builtin_fmaf(dl, vnz, vz);
-      ox = __builtin_fmaf(dl, Jan[k][0], ox); oy = __builtin_fmaf(dl, Jan[k][1], oy); oz = __builtin_fmaf(dl, Jan[k][2], oz);
-      const float lim = S.mu * S.ln[k];
-      // longitudinal row (couples the wheel spin)
-      u = __builtin_fmaf(-K.rw, S.spin[k], __builtin_fmaf(a1[k][2], oz, __builtin_fmaf(a1[k][1], oy,
-          __builtin_fmaf(a1[k][0], ox, __builtin_fmaf(t1z, vz, t1x * vx)))));
-      dl = -(u * m1[k]);
-      nw = fminf(fmaxf(S.l1[k] + dl, -lim), lim);
-      dl = nw - S.l1[k];
-      S.l1[k] = nw;
-      vx = __builtin_fmaf(dl, v1x, vx); vz = __builtin_fmaf(dl, v1z, vz);
-      ox = __builtin_fmaf(dl, Ja1[k][0], ox); oy = __builtin_fmaf(dl, Ja1[k][1], oy); oz = __builtin_fmaf(dl, Ja1[k][2], oz);
-      S.spin[k] = __builtin_fmaf(-K.rw_over_Is, dl, S.spin[k]);
-      // lateral row
-      u = __builtin_fmaf(a2[k][2], oz, __builtin_fmaf(a2[k][1], oy, __builtin_fmaf(a2[k][0], ox,
-          __builtin_fmaf(t2z, vz, __builtin_fmaf(t2y, vy, t2x * vx)))));
-      dl = -(u * m2[k]);
-      nw = fminf(fmaxf(S.l2[k] + dl, -lim), lim);
-      dl = nw - S.l2[k];
-      S.l2[k] = nw;
-      vl[k][0] = __builtin_fmaf(dl, v2x, vx); vl[k][1] = __builtin_fmaf(dl, v2y, vy); vl[k][2] = __builtin_fmaf(dl, v2z, vz);
-      wl[k][0] = __builtin_fmaf(dl, Ja2[k][0], ox); wl[k][1] = __builtin_fmaf(dl, Ja2[k][1], oy); wl[k][2] = __builtin_fmaf(dl, Ja2[k][2], oz);
-    }
+    float vx[4], vy[4], vz[4], ox[4], oy[4], oz[4], u[4], dl[4], nw[4], lim[4];
+    // normal row
+    const float unv = __builtin_fmaf(nb[2], vb[2], __builtin_fmaf(nb[1], vb[1], nb[0] * vb[0]));
+    OIS_W4 u[k] = __builtin_fmaf(an[k][0], wb[0], unv);
+    OIS_W4 u[k] = __builtin_fmaf(an[k][1], wb[1], u[k]);
+    OIS_W4 u[k] = __builtin_fmaf(an[k][2], wb[2], u[k]);
+    OIS_W4 dl[k] = (b[k] - u[k]) * mn[k];
+    OIS_W4 nw[k] = fmaxf(S.ln[k] + dl[k], 0.0f);
+    OIS_W4 dl[k] = nw[k] - S.ln[k];
+    OIS_W4 S.ln[k] = nw[k];
+    OIS_W4 vx[k] = __builtin_fmaf(dl[k], vnx, vb[0]);
+    OIS_W4 vz[k] = __builtin_fmaf(dl[k], vnz, vb[2]);
+    OIS_W4 ox[k] = __builtin_fmaf(dl[k], Jan[k][0], wb[0]);
+    OIS_W4 oy[k] = __builtin_fmaf(dl[k], Jan[k][1], wb[1]);
+    OIS_W4 oz[k] = __builtin_fmaf(dl[k], Jan[k][2], wb[2]);
+    OIS_W4 vy[k] = __builtin_fmaf(dl[k], vny, vb[1]);
+    OIS_W4 lim[k] = S.mu * S.ln[k];
+    // longitudinal row (couples the wheel spin)
+    OIS_W4 u[k] = t1x * vx[k];
+    OIS_W4 u[k] = __builtin_fmaf(t1z, vz[k], u[k]);
+    OIS_W4 u[k] = __builtin_fmaf(a1[k][0], ox[k], u[k]);
+    OIS_W4 u[k] = __builtin_fmaf(a1[k][1], oy[k], u[k]);
+    OIS_W4 u[k] = __builtin_fmaf(a1[k][2], oz[k], u[k]);
+    OIS_W4 u[k] = __builtin_fmaf(-K.rw, S.spin[k], u[k]);
+    OIS_W4 dl[k] = -(u[k] * m1[k]);
+    OIS_W4 nw[k] = fminf(fmaxf(S.l1[k] + dl[k], -lim[k]), lim[k]);
+    OIS_W4 dl[k] = nw[k] - S.l1[k];
+    OIS_W4 S.l1[k] = nw[k];
+    OIS_W4 vx[k] = __builtin_fmaf(dl[k], v1x, vx[k]);
+    OIS_W4 vz[k] = __builtin_fmaf(dl[k], v1z, vz[k]);
+    OIS_W4 ox[k] = __builtin_fmaf(dl[k], Ja1[k][0], ox[k]);
+    OIS_W4 oy[k] = __builtin_fmaf(dl[k], Ja1[k][1], oy[k]);
+    OIS_W4 oz[k] = __builtin_fmaf(dl[k], Ja1[k][2], oz[k]);
+    OIS_W4 S.spin[k] = __builtin_fmaf(-K.rw_over_Is, dl[k], S.spin[k]);
+    // lateral row
+    OIS_W4 u[k] = t2x * vx[k];
+    OIS_W4 u[k] = __builtin_fmaf(t2y, vy[k], u[k]);
+    OIS_W4 u[k] = __builtin_fmaf(t2z, vz[k], u[k]);
+    OIS_W4 u[k] = __builtin_fmaf(a2[k][0], ox[k], u[k]);
+    OIS_W4 u[k] = __builtin_fmaf(a2[k][1], oy[k], u[k]);
+    OIS_W4 u[k] = __builtin_fmaf(a2[k][2], oz[k], u[k]);
+    OIS_W4 dl[k] = -(u[k] * m2[k]);
+    OIS_W4 nw[k] = fminf(fmaxf(S.l2[k] + dl[k], -lim[k]), lim[k]);
+    OIS_W4 dl[k] = nw[k] - S.l2[k];
+    OIS_W4 S.l2[k] = nw[k];
+    OIS_W4 vl[k][0] = __builtin_fmaf(dl[k], v2x, vx[k]);
+    OIS_W4 vl[k][1] = __builtin_fmaf(dl[k], v2y, vy[k]);
+    OIS_W4 vl[k][2] = __builtin_fmaf(dl[k], v2z, vz[k]);
+    OIS_W4 wl[k][0] = __builtin_fmaf(dl[k], Ja2[k][0], ox[k]);
+    OIS_W4 wl[k][1] = __builtin_fmaf(dl[k], Ja2[k][1], oy[k]);
+    OIS_W4 wl[k][2] = __builtin_fmaf(dl[k], Ja2[k][2], oz[k]);
+#undef OIS_W4
     // mass-splitting average over the 4 contacts
 #pragma unroll
     for (int j = 0; j < 3; ++j) {

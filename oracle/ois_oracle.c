@@ -363,9 +363,29 @@ static inline void rot(const float R[9], const float a[3], float o[3]) {
  * v is the WORLD linear velocity, wb the BODY-frame angular velocity: a torque-free body
  * with gyroscopic forces disabled (KAMMA.py:119) keeps its world w constant, and
  * d(R^T w)/dt = -w_b x w_b = 0, so w_b is carried from substep to substep unchanged. */
+/* Reciprocal cache carried from substep to substep inside one policy step (SPEC §3.6): the
+ * row effective masses 1/k and 1/s change by O(1e-3) between substeps, so after the first
+ * substep (exact IEEE division) they are refreshed by ONE Newton step from the previous
+ * value — multiplications and fmas only, bit-reproducible on CPU and GPU. The effective mass
+ * is only the gain of the projected Gauss-Seidel update: its 1e-6 relative error does not
+ * move the fixed point of the solve. */
+typedef struct {
+  float mn[4], m1[4], m2[4], inv_s;
+} rcache;
+
+static inline float newton_rcp(float m, float k) { /* m ~ 1/k -> m (2 - k m) */
+  float e = fmaf(-k, m, 1.0f);
+  return fmaf(m, e, m);
+}
+static inline float newton_rsqrt(float r, float s2) { /* r ~ 1/sqrt(s2) -> r (1.5 - 0.5 s2 r^2) */
+  float hr = (0.5f * s2) * r;
+  float e = fmaf(-hr, r, 1.5f);
+  return r * e;
+}
+
 static void substep(const derived* D, float mu, const float n[3], const float tau[4], float p[3],
                     float q[4], float v[3], float wb[3], float spin[4], float ln[4], float l1[4],
-                    float l2[4]) {
+                    float l2[4], rcache* C, int exact) {
   float R[9];
   rotmat(q, R);
   float vb[3], nb[3];
@@ -388,7 +408,8 @@ static void substep(const derived* D, float mu, const float n[3], const float ta
   /* contact frame shared by the four wheels (common axle direction = body y) */
   float s2 = fmaf(nb[2], nb[2], nb[0] * nb[0]);
   s2 = fmaxf(s2, 1e-12f);
-  float inv_s = 1.0f / sqrtf(s2);
+  float inv_s = exact ? 1.0f / sqrtf(s2) : newton_rsqrt(C->inv_s, s2);
+  C->inv_s = inv_s;
   float dx = -(nb[0] * inv_s), dz = -(nb[2] * inv_s);
   float t1x = -dz, t1z = dx;
   float t2x = nb[1] * t1z;
@@ -396,7 +417,8 @@ static void substep(const derived* D, float mu, const float n[3], const float ta
   float t2z = -(nb[1] * t1x);
   float np = fmaf(n[2], p[2], fmaf(n[1], p[1], n[0] * p[0]));
 
-  float b[4], an[4][3], a1[4][3], a2[4][3], Jan[4][3], Ja1[4][3], Ja2[4][3], mn[4], m1[4], m2[4];
+  float b[4], an[4][3], a1[4][3], a2[4][3], Jan[4][3], Ja1[4][3], Ja2[4][3];
+  float *mn = C->mn, *m1 = C->m1, *m2 = C->m2;
   for (int k = 0; k < 4; ++k) {
     float cx = D->cx[k], cy = D->cy[k], cz = D->cz;
     float rx = fmaf(D->rw, dx, cx), ry = cy, rz = fmaf(D->rw, dz, cz);
@@ -419,9 +441,9 @@ static void substep(const derived* D, float mu, const float n[3], const float ta
     float kn = fmaf(an[k][2], Jan[k][2], fmaf(an[k][1], Jan[k][1], fmaf(an[k][0], Jan[k][0], D->im4)));
     float k1 = fmaf(a1[k][2], Ja1[k][2], fmaf(a1[k][1], Ja1[k][1], fmaf(a1[k][0], Ja1[k][0], D->im4))) + D->rw2_over_Is;
     float k2 = fmaf(a2[k][2], Ja2[k][2], fmaf(a2[k][1], Ja2[k][1], fmaf(a2[k][0], Ja2[k][0], D->im4)));
-    mn[k] = 1.0f / kn;
-    m1[k] = 1.0f / k1;
-    m2[k] = 1.0f / k2;
+    mn[k] = exact ? 1.0f / kn : newton_rcp(mn[k], kn);
+    m1[k] = exact ? 1.0f / k1 : newton_rcp(m1[k], k1);
+    m2[k] = exact ? 1.0f / k2 : newton_rcp(m2[k], k2);
   }
   float vnx = D->im4 * nb[0], vny = D->im4 * nb[1], vnz = D->im4 * nb[2];
   float v1x = D->im4 * t1x, v1z = D->im4 * t1z;
@@ -515,7 +537,8 @@ void orc_substep(const ois_config* cfg, float mu, const float n_world[3], const 
   float R[9], wb[3];
   rotmat(q, R);
   rotT(R, w, wb);
-  substep(&D, mu, n_world, tau, p, q, v, wb, spin, lam_n, lam_l, lam_t);
+  rcache C;
+  substep(&D, mu, n_world, tau, p, q, v, wb, spin, lam_n, lam_l, lam_t, &C, 1);
   rotmat(q, R);
   rot(R, wb, w);
 }
@@ -871,7 +894,8 @@ static float step_arena(orc_env* e, int i, const float* act /*[A]*/, uint8_t* rs
   float* LN = &e->lam_n[4 * i];
   float* LL = &e->lam_l[4 * i];
   float* LT = &e->lam_t[4 * i];
-  for (int s = 0; s < nsub; ++s) substep(D, mu, n, wt, p, q, v, wb, spin, LN, LL, LT);
+  rcache C;
+  for (int s = 0; s < nsub; ++s) substep(D, mu, n, wt, p, q, v, wb, spin, LN, LL, LT, &C, s == 0);
   rotmat(q, R);
   rot(R, wb, w); /* body -> world with the final orientation */
   float jv[4];

@@ -1,0 +1,268 @@
+#!/usr/bin/env python3
+"""Generates the golden fixtures under tests/golden/ (run from the repo root):
+
+    python tests/golden/make_golden.py
+
+1. refmath_*.npz — the REFERENCE-FOLLOWED math. The reference's env module cannot be imported
+   (it needs Isaac Sim / gym / pxr: ModuleNotFoundError), so the formulas of
+   src/my_envs/KAMMA.py (and KA_DDPG_4D.py) are transcribed here line by line into torch-CPU
+   float32 tensor expressions — one torch op per reference op, same operand order — and
+   evaluated on seeded random inputs. Only inputs and outputs are stored. The transcription is
+   build code written for this repo; each block cites the reference lines it follows. The
+   quaternion helpers restate omni.isaac.core.utils.torch.rotations (third-party, not in the
+   reference tree) from the published isaacgym torch_utils formulas of the same names.
+2. traj_*.npz — ORACLE trajectories (CPU oracle, oracle/ois_oracle.c) for BASELINE.json
+   configs 1/2 in miniature plus the expert-only run: the HIP kernel must reproduce them
+   (tests/test_gpu_golden.py), and the oracle must keep reproducing them (regression pin).
+   These pin oracle <-> kernel parity only: the physics itself is parity-unpinned.
+"""
+import os
+import sys
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+sys.path.insert(0, ROOT)
+
+F = torch.float32
+
+
+# ----------------------------------------------------------------------------------------
+# third-party helpers restated (wxyz quaternions)
+def quat_apply(a, b):
+    xyz = a[:, 1:]
+    t = xyz.cross(b, dim=-1) * 2
+    return b + a[:, :1] * t + xyz.cross(t, dim=-1)
+
+
+def quat_mul(a, b):
+    w1, x1, y1, z1 = a[:, 0], a[:, 1], a[:, 2], a[:, 3]
+    w2, x2, y2, z2 = b[:, 0], b[:, 1], b[:, 2], b[:, 3]
+    ww = (z1 + x1) * (x2 + y2)
+    yy = (w1 - y1) * (w2 + z2)
+    zz = (w1 + y1) * (w2 - z2)
+    xx = ww + yy + zz
+    qq = 0.5 * (xx + (z1 - x1) * (x2 - y2))
+    w = qq - ww + (z1 - y1) * (y2 - z2)
+    x = qq - xx + (x1 + w1) * (x2 + w2)
+    y = qq - yy + (w1 - x1) * (y2 + z2)
+    z = qq - zz + (z1 + y1) * (w2 - x2)
+    return torch.stack([w, x, y, z], dim=-1)
+
+
+def torch_rand_float_from(lower, upper, u):
+    """torch_rand_float(lower, upper, shape) = (upper - lower) * torch.rand(shape) + lower, with the
+    uniform draw `u` passed in (the fixtures carry the draws so any RNG can replay them)."""
+    return (upper - lower) * u + lower
+
+
+# ----------------------------------------------------------------------------------------
+def refmath_step(seed=0, n=257):
+    g = torch.Generator().manual_seed(seed)
+    r = lambda *s, lo=-1.0, hi=1.0: (hi - lo) * torch.rand(*s, generator=g, dtype=F) + lo  # noqa: E731
+    out = {}
+    # ---- inputs ----
+    commands = torch.stack([r(n, lo=0.0, hi=2.0), r(n, lo=-0.5, hi=0.5), r(n, lo=-0.3, hi=0.3), r(n, lo=1.0, hi=1.1)], 1)
+    v_forward_projected = r(n, lo=-0.5, hi=2.5)
+    base_velocities = r(n, 6, lo=-1.0, hi=1.0)
+    actions = r(n, 4, lo=-0.2, hi=1.6)          # beyond [0,1] so the +-4 clip is exercised
+    sim_steps = torch.randint(0, 600000, (n,), generator=g)
+    rand_vals = torch.rand(n, 1, generator=g, dtype=F)
+    Kp, Kp_omega, vehicle_mass, vehicle_inertia, dt, action_scale = 0.035, 0.665, 25.0, 1.05, 0.1, 3.0
+    max_sim_steps = 400000.0
+    out.update(commands=commands, v_forward_projected=v_forward_projected, base_velocities=base_velocities,
+               actions=actions, sim_steps=sim_steps.to(torch.int32), rand_vals=rand_vals[:, 0])
+
+    # ---- KAMMA.py:604-624 criteria controller ----
+    desired_v = commands[:, 0]
+    desired_omega = commands[:, 2]
+    current_v = v_forward_projected
+    current_omega = base_velocities[:, 5]
+    v_delta = desired_v - current_v
+    omega_delta = desired_omega - current_omega
+    ac_left = Kp * (vehicle_mass * (v_delta / dt)) - Kp_omega * (vehicle_inertia * (omega_delta / dt))
+    ac_right = Kp * (vehicle_mass * (v_delta / dt)) + Kp_omega * (vehicle_inertia * (omega_delta / dt))
+    criteria_action = torch.stack([ac_left, ac_left, ac_right, ac_right], dim=1)
+    out.update(v_delta=v_delta, omega_delta=omega_delta, ac_left=ac_left, ac_right=ac_right)
+
+    # ---- KAMMA.py:627-628 gamma schedule ----
+    gamma_assist = torch.clamp(1.0 - (sim_steps.float() / max_sim_steps), min=0.0)
+    out.update(gamma=gamma_assist)
+
+    # ---- KAMMA.py:632-636 stochastic switch, :649 clip, :656 guiding reward ----
+    gamma = gamma_assist.view(-1, 1)
+    mask = (rand_vals < gamma).float()
+    execution_action = mask * criteria_action + (1 - mask) * (actions * action_scale)
+    wheel_torqs = torch.clip(execution_action, -4.0, 4.0)
+    guiding_reward = -torch.norm(wheel_torqs - criteria_action, dim=1)
+    out.update(switch_torques=execution_action, switch_wheel_torqs=wheel_torqs, switch_guiding=guiding_reward)
+
+    # ---- KA_DDPG_4D.py:627-631 deterministic blend, :637 guiding on the unclipped policy torque ----
+    blend = (torch.tensor(1.0) - gamma) * actions * action_scale + gamma * criteria_action
+    blend_wheel = torch.clip(blend, -4.0, 4.0)
+    blend_guiding = -torch.norm(actions * action_scale - criteria_action, dim=1)
+    out.update(blend_torques=blend, blend_wheel_torqs=blend_wheel, blend_guiding=blend_guiding)
+
+    # ---- KAMMA.py:736-764 is_done ----
+    q = torch.nn.functional.normalize(r(n, 4), dim=1)
+    q[: n // 3] = torch.nn.functional.normalize(torch.tensor([[1.0, 0.02, -0.03, 0.4]]) + 0.05 * r(n // 3, 4), dim=1)
+    base_pos = r(n, 3, lo=-60.0, hi=60.0)
+    base_pos[::2] *= 0.1
+    episode_buf = torch.randint(0, 120, (n,), generator=g)
+    max_episode_length = 100
+    timeout_buf = torch.where(episode_buf >= max_episode_length - 1, torch.ones(n, dtype=torch.long),
+                              torch.zeros(n, dtype=torch.long))
+    gravity_vec = torch.tensor([0.0, 0.0, -1.0]).repeat((n, 1))
+    projected_gravity = quat_apply(q, gravity_vec)
+    has_fallen = projected_gravity[:, 2] > 0.0
+    reset_buf = has_fallen.clone()
+    reset_buf = torch.where(timeout_buf.bool(), torch.ones_like(reset_buf), reset_buf)
+    bounds = torch.tensor([-50.0, 50.0, -50.0, 50.0])
+    out_of_bounds = (base_pos[:, 0] < bounds[0]) | (base_pos[:, 0] > bounds[1]) | \
+                    (base_pos[:, 1] < bounds[2]) | (base_pos[:, 1] > bounds[3])
+    reset_buf = torch.where(out_of_bounds, torch.ones_like(reset_buf), reset_buf)
+    out.update(quat=q, base_pos=base_pos, episode_buf=episode_buf.to(torch.int32),
+               timeout=timeout_buf.to(torch.uint8), reset=reset_buf.to(torch.uint8))
+
+    # ---- KAMMA.py:767-822 calculate_metrics (terminalReward 0.0 and 1.5: the ~timeout quirk) ----
+    previous_linear_velocity = r(n, lo=-0.5, hi=2.5)
+    previous_angular_velocity = r(n)
+    gamma2 = gamma_assist
+    episode_sums = r(n, 8, lo=-5.0, hi=5.0)
+    out.update(prev_lin_in=previous_linear_velocity.clone(), prev_ang_in=previous_angular_velocity.clone(),
+               sums_in=episode_sums.clone())
+    for tag, terminal in (("t0", 0.0), ("t15", 1.5)):
+        linear_acc = (v_forward_projected - previous_linear_velocity) / dt
+        angular_acc = (base_velocities[:, 5] - previous_angular_velocity) / dt
+        r1 = v_delta ** 2 + 5 * (omega_delta ** 2)
+        r2 = linear_acc ** 2 + angular_acc ** 2
+        r3 = torch.sum(wheel_torqs ** 2, dim=1)
+        w1, w2, w3 = -25.0, -0.02, -0.09
+        rdense = w1 * r1 + w2 * r2 + w3 * r3
+        sparse_reward = torch.where((torch.abs(v_delta) < 0.01) & (torch.abs(omega_delta) < 0.01),
+                                    torch.full_like(v_delta, 0.2), torch.zeros_like(v_delta))
+        observed_reward = rdense + sparse_reward
+        rew_buf = (1 - gamma2) * observed_reward + gamma2 * guiding_reward
+        rew_buf = rew_buf + terminal * reset_buf * ~timeout_buf
+        sums = episode_sums.clone()
+        for k, val in enumerate((w1 * r1, w2 * r2, w3 * r3, rdense, sparse_reward, guiding_reward, observed_reward, rew_buf)):
+            sums[:, k] += val
+        out.update({f"lin_acc_{tag}": linear_acc, f"ang_acc_{tag}": angular_acc, f"rew_{tag}": rew_buf,
+                    f"sums_out_{tag}": sums})
+    # exercise the sparse bonus explicitly
+    out.update(sparse_hit=((torch.abs(v_delta) < 0.01) & (torch.abs(omega_delta) < 0.01)).to(torch.uint8))
+
+    # ---- KAMMA.py:701-710 forward projection ----
+    forward_vec = torch.tensor([1.0, 0.0, 0.0]).repeat((n, 1))
+    forward = quat_apply(q, forward_vec)
+    forward_norm = forward / torch.norm(forward, dim=1, keepdim=True)
+    v_global = base_velocities[:, 0:3]
+    v_fwd = torch.sum(v_global * forward_norm, dim=1)
+    out.update(v_fwd=v_fwd)
+
+    # ---- KAMMA.py:833 observation + rl_task.py:99 clamp ----
+    obs = torch.cat([desired_v.unsqueeze(1), desired_omega.unsqueeze(1), v_delta.unsqueeze(1), omega_delta.unsqueeze(1),
+                     out["lin_acc_t0"].unsqueeze(1), out["ang_acc_t0"].unsqueeze(1)], dim=1)
+    out.update(obs=torch.clamp(obs, -1000.0, 1000.0))
+    return {k: v.numpy() for k, v in out.items()}
+
+
+def refmath_reset(seed=1, n=513):
+    """KAMMA.py:417-460, 490-496, 569-575: pose / command part of reset_idx given the 8 draws."""
+    g = torch.Generator().manual_seed(seed)
+    u = torch.rand(n, 8, generator=g, dtype=F)
+    base_init_state = torch.tensor([0.0, 0.0, 0.1, 1.0, 0.0, 0.0, 0.0, 0, 0, 0, 0, 0, 0], dtype=F)
+    cmd_x, cmd_y, cmd_yaw = (1.0, 2.0), (-0.5, 0.5), (1.0, 1.1)
+    base_pos = base_init_state[0:3].repeat(n, 1)
+    base_pos[:, 0:2] += torch_rand_float_from(-0.5, 0.5, u[:, 0:2])
+    random_angle = torch_rand_float_from(0, 2 * torch.pi, u[:, 2])
+    quat_z = torch.stack([torch.cos(random_angle / 2), torch.zeros_like(random_angle), torch.zeros_like(random_angle),
+                          torch.sin(random_angle / 2)], dim=-1)
+    base_quat = quat_mul(quat_z, base_init_state[3:7].repeat(n, 1))
+    commands = torch.zeros(n, 4, dtype=F)
+    commands[:, 0] = torch_rand_float_from(cmd_x[0], cmd_x[1], u[:, 3])
+    commands[:, 1] = torch_rand_float_from(cmd_y[0], cmd_y[1], u[:, 4])
+    commands[:, 3] = torch_rand_float_from(cmd_yaw[0], cmd_yaw[1], u[:, 5])
+    commands *= (torch.norm(commands[:, :2], dim=1) > 0.25).unsqueeze(1)
+    x_vel = torch_rand_float_from(cmd_x[0], cmd_x[1], u[:, 6])
+    commands[:, 0] = torch.clamp(x_vel, min=0.0)  # max(x_vel, 0.0) per arena
+    commands[:, 2] = 0.0
+    return {"u": u.numpy(), "base_pos": base_pos.numpy(), "base_quat": base_quat.numpy(), "commands": commands.numpy(),
+            "angle": random_angle.numpy()}
+
+
+def refmath_extras(seed=2, n=64):
+    """KAMMA.py:470-488: derived ratio sums and the means that go into extras['episode']."""
+    g = torch.Generator().manual_seed(seed)
+    sums = 10.0 * (torch.rand(n, 8, generator=g, dtype=F) - 0.7)
+    gamma2 = torch.full((n,), 0.375, dtype=F)
+    ids = torch.arange(0, n, 3)
+    one, hundred, L = torch.tensor(1.0), torch.tensor(100.0), 10.0
+    keys = {}
+    for j, name in enumerate(["r1", "r2", "r3", "dense", "sparse"]):
+        keys[name + "_over_final"] = L * (hundred * (one - gamma2) * sums[:, j] / sums[:, 7])
+    keys["guiding_over_final"] = L * (hundred * gamma2 * sums[:, 5] / sums[:, 7])
+    keys["observed_over_final"] = L * (hundred * (one - gamma2) * sums[:, 6] / sums[:, 7])
+    out = {"sums": sums.numpy(), "gamma2": gamma2.numpy(), "ids": ids.numpy().astype(np.int32)}
+    for j in range(8):
+        out[f"mean_sum{j}"] = (torch.mean(sums[ids, j]) / L).numpy()
+    for k, v in keys.items():
+        out["mean_" + k] = (torch.mean(v[ids]) / L).numpy()
+    return out
+
+
+# ----------------------------------------------------------------------------------------
+def trajectories():
+    from options_in_simulation_amd import _abi, build_config
+    from oracle.binding import OracleEnv
+    out = {}
+
+    def record(name, variant, n, steps, policy, seed, sample_every=1, **kw):
+        cfg = build_config(variant=variant, num_envs=n, seed=seed, **kw)
+        env = OracleEnv(cfg)
+        env.reset(seed)
+        rng = np.random.default_rng(seed)
+        obs0, rew0, done_count, acts = [], [], [], []
+        for t in range(steps):
+            if policy == "zero":
+                a = np.zeros((n, cfg.action_dim), np.float32)
+            else:
+                a = rng.uniform(0.0, 1.0, size=(n, cfg.action_dim)).astype(np.float32)
+            env.step(a)
+            if t % sample_every == 0:
+                obs0.append(env.obs[0].copy()); rew0.append(env.rew.copy()); done_count.append(int(env.done.sum()))
+        st = env.state()
+        d = {"obs_env0": np.array(obs0), "rew": np.array(rew0), "done_count": np.array(done_count, np.int32),
+             "episode_info": env.episode_info(), "seed": np.int64(seed), "steps": np.int32(steps), "n": np.int32(n)}
+        for bid, arr in st.items():
+            d[f"buf{bid}"] = arr
+        s = env.stats()
+        d["stats"] = np.array([s.episodes, s.return_sum, s.return_sqsum, s.return_min, s.return_max, s.length_sum, s.steps])
+        out[name] = d
+
+    # BASELINE.json configs[0]: 1 env, flat, zero torque, 1000 steps, gamma = 0 (KAMMA_eval switches)
+    record("traj_config1_zero_torque", "KAMMA_eval", 1, 1000, "zero", 42)
+    # configs[1] in miniature: random torque policy, gamma = 0
+    record("traj_random_torque", "KAMMA_eval", 8, 1000, "random", 42, sample_every=4)
+    # expert only (gamma = 1 forever): the classical controller of the reference's figure
+    record("traj_expert_only", "KAMMA_g11_g21", 8, 300, "zero", 7)
+    # the shipped training variant with a fast gamma decay so both branches of the switch run
+    record("traj_kamma_switch", "KAMMA_medium", 16, 300, "random", 3, max_sim_steps=200.0)
+    return out
+
+
+def main():
+    np.savez_compressed(os.path.join(HERE, "refmath_step.npz"), **refmath_step())
+    np.savez_compressed(os.path.join(HERE, "refmath_reset.npz"), **refmath_reset())
+    np.savez_compressed(os.path.join(HERE, "refmath_extras.npz"), **refmath_extras())
+    for name, d in trajectories().items():
+        np.savez_compressed(os.path.join(HERE, name + ".npz"), **d)
+    for f in sorted(os.listdir(HERE)):
+        if f.endswith(".npz"):
+            print(f, os.path.getsize(os.path.join(HERE, f)), "bytes")
+
+
+if __name__ == "__main__":
+    main()
