@@ -116,6 +116,8 @@ typedef struct ois_config {
   float cmd_x_lo, cmd_x_hi;   /* randomCommandVelocityRanges.linear_x  KAMMA.py:71 */
   float cmd_y_lo, cmd_y_hi;   /* linear_y                          KAMMA.py:72  */
   float cmd_yaw_lo, cmd_yaw_hi; /* yaw                             KAMMA.py:73  */
+  float cmd_x_span, cmd_y_span, cmd_yaw_span; /* float32 of the Python DOUBLE (hi - lo): torch_rand_float
+                                 multiplies the fp32 draw by that scalar (KAMMA.py:448-456) */
   float init_pos[3];          /* baseInitState.pos                 KAMMA.py:44  */
   float init_quat[4];         /* baseInitState.rot (w,x,y,z)       KAMMA.py:45  */
   float init_lin_vel[3];      /* vLinear                           KAMMA.py:46  */

@@ -93,6 +93,9 @@ class OisConfig(C.Structure):
         ("cmd_y_hi", C.c_float),
         ("cmd_yaw_lo", C.c_float),
         ("cmd_yaw_hi", C.c_float),
+        ("cmd_x_span", C.c_float),
+        ("cmd_y_span", C.c_float),
+        ("cmd_yaw_span", C.c_float),
         ("init_pos", C.c_float * 3),
         ("init_quat", C.c_float * 4),
         ("init_lin_vel", C.c_float * 3),

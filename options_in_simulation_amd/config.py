@@ -211,6 +211,10 @@ def build_config(task_cfg: Optional[Dict[str, Any]] = None, variant: str = "KAMM
     c.cmd_x_lo, c.cmd_x_hi = map(float, rng["linear_x"])          # KAMMA.py:245
     c.cmd_y_lo, c.cmd_y_hi = map(float, rng["linear_y"])          # KAMMA.py:246
     c.cmd_yaw_lo, c.cmd_yaw_hi = map(float, rng["yaw"])           # KAMMA.py:247
+    # torch_rand_float: (upper - lower) is a Python double, rounded to fp32 when it meets the tensor
+    c.cmd_x_span = float(rng["linear_x"][1]) - float(rng["linear_x"][0])
+    c.cmd_y_span = float(rng["linear_y"][1]) - float(rng["linear_y"][0])
+    c.cmd_yaw_span = float(rng["yaw"][1]) - float(rng["yaw"][0])
     init = env["baseInitState"]
     c.init_pos[:] = [float(x) for x in init["pos"]]               # KAMMA.py:251
     c.init_quat[:] = [float(x) for x in init["rot"]]

@@ -38,7 +38,8 @@ struct DevConsts {
   float Kp, Kp_omega, vehicle_mass, vehicle_inertia, policy_dt, action_scale, torque_clip, w1, w2,
       w3, sparse_bonus, sparse_threshold, terminal_reward, max_sim_steps, gamma1_const,
       gamma2_const, bounds, clip_obs, episode_length_s, eval_ramp_steps;
-  float cmd_x_lo, cmd_x_hi, cmd_y_lo, cmd_y_hi, cmd_yaw_lo, cmd_yaw_hi, spawn_xy_range;
+  float cmd_x_lo, cmd_x_hi, cmd_y_lo, cmd_y_hi, cmd_yaw_lo, cmd_yaw_hi, cmd_x_span, cmd_y_span, cmd_yaw_span,
+      spawn_xy_range;
   float init_pos[3], init_quat[4], init_lin_vel[3], init_ang_vel[3], init_dof_vel[4];
   int action_dim, mix_mode, gamma1_mode, gamma2_mode, guiding_mode, cmd_sampler, eval_sums,
       max_episode_length;
@@ -169,6 +170,8 @@ struct Arena {
 
 // torch_rand_float(lower, upper) = (upper - lower) * rand + lower  (KAMMA.py:424-456)
 OIS_DEV float rand_float(float lo, float hi, float u) { return (hi - lo) * u + lo; }
+// same with the span (upper - lower) precomputed in double by the host, as Python does
+OIS_DEV float rand_span(float lo, float span, float u) { return span * u + lo; }
 
 // a11: KAMMA.py:701-710
 OIS_DEV float forward_projection(const float q[4], const float v[3]) {
@@ -229,13 +232,13 @@ OIS_DEV void reset_arena(const DevConsts& K, int64_t gid, float gamma1, float ga
   sincos_det(ang / 2.0f, s, c);
   const float qz[4] = {c, 0.0f, 0.0f, s};
   quat_mul(qz, K.init_quat, S.q);  // :434
-  const float cx = rand_float(K.cmd_x_lo, K.cmd_x_hi, u[3]);      // :448
-  const float cy = rand_float(K.cmd_y_lo, K.cmd_y_hi, u[4]);      // :451
-  const float ch = rand_float(K.cmd_yaw_lo, K.cmd_yaw_hi, u[5]);  // :454
+  const float cx = rand_span(K.cmd_x_lo, K.cmd_x_span, u[3]);      // :448
+  const float cy = rand_span(K.cmd_y_lo, K.cmd_y_span, u[4]);      // :451
+  const float ch = rand_span(K.cmd_yaw_lo, K.cmd_yaw_span, u[5]);  // :454
   const float keep = sqrtf(cx * cx + cy * cy) > 0.25f ? 1.0f : 0.0f;  // :458
   S.cmd[1] = cy * keep;
   S.cmd[3] = ch * keep;
-  float x_vel = rand_float(K.cmd_x_lo, K.cmd_x_hi, u[6]);  // :571 (u[7]: discarded omega draw :572)
+  float x_vel = rand_span(K.cmd_x_lo, K.cmd_x_span, u[6]);  // :571 (u[7]: discarded omega draw :572)
   if (K.cmd_sampler == OIS_CMD_BOX) {  // KAMMA_curr1.py:577-598
     const float progress = fminf(1.0f, (float)S.sim_steps / K.max_sim_steps);
     const float factor = 0.1f + (1.0f - 0.1f) * progress;

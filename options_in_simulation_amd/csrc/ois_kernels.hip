@@ -486,6 +486,7 @@ void derive(const ois_config* c, DevConsts* K) {
   K->episode_length_s = c->episode_length_s; K->eval_ramp_steps = c->eval_ramp_steps;
   K->cmd_x_lo = c->cmd_x_lo; K->cmd_x_hi = c->cmd_x_hi; K->cmd_y_lo = c->cmd_y_lo; K->cmd_y_hi = c->cmd_y_hi;
   K->cmd_yaw_lo = c->cmd_yaw_lo; K->cmd_yaw_hi = c->cmd_yaw_hi; K->spawn_xy_range = c->spawn_xy_range;
+  K->cmd_x_span = c->cmd_x_span; K->cmd_y_span = c->cmd_y_span; K->cmd_yaw_span = c->cmd_yaw_span;
   for (int k = 0; k < 3; ++k) { K->init_pos[k] = c->init_pos[k]; K->init_lin_vel[k] = c->init_lin_vel[k]; K->init_ang_vel[k] = c->init_ang_vel[k]; }
   for (int k = 0; k < 4; ++k) { K->init_quat[k] = c->init_quat[k]; K->init_dof_vel[k] = c->init_dof_vel[k]; }
   K->action_dim = c->action_dim; K->mix_mode = c->mix_mode; K->gamma1_mode = c->gamma1_mode; K->gamma2_mode = c->gamma2_mode;
@@ -539,6 +540,7 @@ int ois_config_default(ois_config* c) {
   c->terminal_reward = 0.0f;
   c->cmd_x_lo = 1.0f; c->cmd_x_hi = 2.0f;  // --linear_x [1,2]
   c->cmd_y_lo = -0.5f; c->cmd_y_hi = 0.5f; c->cmd_yaw_lo = 1.0f; c->cmd_yaw_hi = 1.1f;
+  c->cmd_x_span = (float)(2.0 - 1.0); c->cmd_y_span = (float)(0.5 - -0.5); c->cmd_yaw_span = (float)(1.1 - 1.0);
   c->init_pos[0] = 0.0f; c->init_pos[1] = 0.0f; c->init_pos[2] = 0.1f;
   c->init_quat[0] = 1.0f;
   c->spawn_xy_range = 0.5f; c->bounds = 50.0f; c->clip_obs = 1000.0f; c->eval_ramp_steps = 50000.0f;

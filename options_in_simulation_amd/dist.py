@@ -46,9 +46,10 @@ def gather_stats(st: _abi.OisStats, device=None, group=None) -> List[_abi.OisSta
     backend = dist.get_backend(group)
     dev = torch.device("cpu") if backend == "gloo" else (device or torch.device("cuda", torch.cuda.current_device()))
     mine = stats_to_tensor(st, dev)
-    out = torch.empty((dist.get_world_size(group), mine.numel()), dtype=torch.float64, device=dev)
+    world = dist.get_world_size(group)
+    out = torch.empty(world * mine.numel(), dtype=torch.float64, device=dev)  # flat: gloo and RCCL both accept it
     dist.all_gather_into_tensor(out, mine, group=group)
-    return [tensor_to_stats(row) for row in out.cpu()]
+    return [tensor_to_stats(row) for row in out.view(world, -1).cpu()]
 
 
 def merge_stats(parts: List[_abi.OisStats]) -> dict:

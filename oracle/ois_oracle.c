@@ -268,6 +268,8 @@ void orc_forward_projection(int n, const float* quat4, const float* linvel3, flo
 /* torch_rand_float(lower, upper, ...) = (upper - lower) * rand + lower
  * (omni.isaac.core.utils.torch.maths, third-party; call sites :424-456, :571-572) */
 static inline float rand_float(float lo, float hi, float u) { return (hi - lo) * u + lo; }
+/* same with the span (upper - lower) precomputed in double by the host, as Python does */
+static inline float rand_span(float lo, float span, float u) { return span * u + lo; }
 
 /* a9 pose + command part, KAMMA.py:422-460 and 490-496 / 569-575 */
 void orc_reset_draws(const ois_config* cfg, const float u[8], float pos3[3], float quat4[4],
@@ -281,16 +283,16 @@ void orc_reset_draws(const ois_config* cfg, const float u[8], float pos3[3], flo
   orc_sincos(ang / 2.0f, &s, &c);                        /* :428, :431 */
   float qz[4] = {c, 0.0f, 0.0f, s};
   orc_quat_mul(qz, cfg->init_quat, quat4);               /* :434 */
-  float cx = rand_float(cfg->cmd_x_lo, cfg->cmd_x_hi, u[3]);       /* :448 */
-  float cy = rand_float(cfg->cmd_y_lo, cfg->cmd_y_hi, u[4]);       /* :451 */
-  float ch = rand_float(cfg->cmd_yaw_lo, cfg->cmd_yaw_hi, u[5]);   /* :454 */
+  float cx = rand_span(cfg->cmd_x_lo, cfg->cmd_x_span, u[3]);       /* :448 */
+  float cy = rand_span(cfg->cmd_y_lo, cfg->cmd_y_span, u[4]);       /* :451 */
+  float ch = rand_span(cfg->cmd_yaw_lo, cfg->cmd_yaw_span, u[5]);   /* :454 */
   float keep = sqrtf(cx * cx + cy * cy) > 0.25f ? 1.0f : 0.0f;     /* :458 */
   commands4[0] = cx * keep;
   commands4[1] = cy * keep;
   commands4[2] = 0.0f * keep; /* commands[:,2] is still 0 here (zero-initialised :378) */
   commands4[3] = ch * keep;
   /* sample_velocity_command, randsampling branch :569-575 (u[7] is the discarded omega draw) */
-  float x_vel = rand_float(cfg->cmd_x_lo, cfg->cmd_x_hi, u[6]);    /* :571 */
+  float x_vel = rand_span(cfg->cmd_x_lo, cfg->cmd_x_span, u[6]);    /* :571 */
   commands4[0] = x_vel > 0.0f ? x_vel : 0.0f;                      /* :575 max(x_vel, 0.0), :495 */
   commands4[2] = 0.0f;                                             /* :574, :496 */
 }

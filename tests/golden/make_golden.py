@@ -169,12 +169,13 @@ def refmath_step(seed=0, n=257):
     return {k: v.numpy() for k, v in out.items()}
 
 
-def refmath_reset(seed=1, n=513):
-    """KAMMA.py:417-460, 490-496, 569-575: pose / command part of reset_idx given the 8 draws."""
+def refmath_reset(seed=1, n=513, cmd_x=(1.0, 2.0)):
+    """KAMMA.py:417-460, 490-496, 569-575: pose / command part of reset_idx given the 8 draws.
+    cmd_x = (0.0, 0.4) makes |commands[:, :2]| <= 0.25 common, so the zeroing at :458 is hit."""
     g = torch.Generator().manual_seed(seed)
     u = torch.rand(n, 8, generator=g, dtype=F)
     base_init_state = torch.tensor([0.0, 0.0, 0.1, 1.0, 0.0, 0.0, 0.0, 0, 0, 0, 0, 0, 0], dtype=F)
-    cmd_x, cmd_y, cmd_yaw = (1.0, 2.0), (-0.5, 0.5), (1.0, 1.1)
+    cmd_y, cmd_yaw = (-0.5, 0.5), (1.0, 1.1)
     base_pos = base_init_state[0:3].repeat(n, 1)
     base_pos[:, 0:2] += torch_rand_float_from(-0.5, 0.5, u[:, 0:2])
     random_angle = torch_rand_float_from(0, 2 * torch.pi, u[:, 2])
@@ -215,47 +216,15 @@ def refmath_extras(seed=2, n=64):
 
 # ----------------------------------------------------------------------------------------
 def trajectories():
-    from options_in_simulation_amd import _abi, build_config
     from oracle.binding import OracleEnv
-    out = {}
-
-    def record(name, variant, n, steps, policy, seed, sample_every=1, **kw):
-        cfg = build_config(variant=variant, num_envs=n, seed=seed, **kw)
-        env = OracleEnv(cfg)
-        env.reset(seed)
-        rng = np.random.default_rng(seed)
-        obs0, rew0, done_count, acts = [], [], [], []
-        for t in range(steps):
-            if policy == "zero":
-                a = np.zeros((n, cfg.action_dim), np.float32)
-            else:
-                a = rng.uniform(0.0, 1.0, size=(n, cfg.action_dim)).astype(np.float32)
-            env.step(a)
-            if t % sample_every == 0:
-                obs0.append(env.obs[0].copy()); rew0.append(env.rew.copy()); done_count.append(int(env.done.sum()))
-        st = env.state()
-        d = {"obs_env0": np.array(obs0), "rew": np.array(rew0), "done_count": np.array(done_count, np.int32),
-             "episode_info": env.episode_info(), "seed": np.int64(seed), "steps": np.int32(steps), "n": np.int32(n)}
-        for bid, arr in st.items():
-            d[f"buf{bid}"] = arr
-        s = env.stats()
-        d["stats"] = np.array([s.episodes, s.return_sum, s.return_sqsum, s.return_min, s.return_max, s.length_sum, s.steps])
-        out[name] = d
-
-    # BASELINE.json configs[0]: 1 env, flat, zero torque, 1000 steps, gamma = 0 (KAMMA_eval switches)
-    record("traj_config1_zero_torque", "KAMMA_eval", 1, 1000, "zero", 42)
-    # configs[1] in miniature: random torque policy, gamma = 0
-    record("traj_random_torque", "KAMMA_eval", 8, 1000, "random", 42, sample_every=4)
-    # expert only (gamma = 1 forever): the classical controller of the reference's figure
-    record("traj_expert_only", "KAMMA_g11_g21", 8, 300, "zero", 7)
-    # the shipped training variant with a fast gamma decay so both branches of the switch run
-    record("traj_kamma_switch", "KAMMA_medium", 16, 300, "random", 3, max_sim_steps=200.0)
-    return out
+    from tests.golden_replay import TRAJ_SPECS, run_spec
+    return {name: run_spec(spec, lambda cfg: OracleEnv(cfg), to_numpy=lambda x: x) for name, spec in TRAJ_SPECS.items()}
 
 
 def main():
     np.savez_compressed(os.path.join(HERE, "refmath_step.npz"), **refmath_step())
     np.savez_compressed(os.path.join(HERE, "refmath_reset.npz"), **refmath_reset())
+    np.savez_compressed(os.path.join(HERE, "refmath_reset_small_cmd.npz"), **refmath_reset(seed=5, n=257, cmd_x=(0.0, 0.4)))
     np.savez_compressed(os.path.join(HERE, "refmath_extras.npz"), **refmath_extras())
     for name, d in trajectories().items():
         np.savez_compressed(os.path.join(HERE, name + ".npz"), **d)

@@ -1,0 +1,126 @@
+"""C-ABI library (loads on a CPU-only machine, no compute calls) and the config layer."""
+import ctypes as C
+import os
+import re
+import subprocess
+
+import numpy as np
+import pytest
+
+from options_in_simulation_amd import _abi, build_config, default_task_cfg
+from options_in_simulation_amd.config import VARIANTS, composite_body
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module")
+def lib():
+    from options_in_simulation_amd import _native
+    if not os.path.exists(_native.LIB_PATH):
+        import __graft_entry__
+        __graft_entry__.build()
+    return _native.load()
+
+
+def test_library_exports_every_symbol_of_the_header(lib):
+    header = open(os.path.join(ROOT, "include", "ois.h")).read()
+    declared = set(re.findall(r"\b(ois_[a-z0-9_]+)\s*\(", header))
+    declared -= {"ois_env"}
+    assert declared, "no declarations parsed"
+    from options_in_simulation_amd import _native
+    assert declared == set(_native.SYMBOLS), "python binding list and include/ois.h disagree"
+    nm = subprocess.run(["nm", "-D", "--defined-only", _native.LIB_PATH], capture_output=True, text=True, check=True).stdout
+    exported = set(re.findall(r"\bT (ois_[a-z0-9_]+)", nm))
+    assert declared <= exported, f"missing exports: {declared - exported}"
+    assert lib.ois_abi_version() == _abi.ABI_VERSION
+
+
+def test_struct_layout_matches_the_library(lib):
+    c = _abi.OisConfig()
+    assert lib.ois_config_default(C.byref(c)) == 0
+    assert c.struct_bytes == C.sizeof(_abi.OisConfig)  # sizeof(ois_config) as compiled by hipcc
+    py = build_config(variant="KAMMA_medium", num_envs=1)
+    for name, _ in _abi.OisConfig._fields_:
+        a, b = getattr(c, name), getattr(py, name)
+        a, b = (list(a), list(b)) if hasattr(a, "__len__") else (a, b)
+        assert a == b, f"ois_config_default and build_config disagree on {name}: {a} vs {b}"
+
+
+def test_workspace_size_and_config_validation(lib):
+    c = build_config(variant="KAMMA_medium", num_envs=65536)
+    nbytes = lib.ois_workspace_bytes(C.byref(c))
+    state = 15 * 65536 * 16 + 65536 * (24 + 4 + 1 + 1)
+    assert state <= nbytes < state + 4 * 1024 * 1024
+    for field, bad in (("num_envs", 0), ("action_dim", 3), ("solver_iterations", 0), ("sim_dt", 0.0),
+                       ("body_mass", -1.0), ("struct_bytes", 12), ("cmd_sampler", _abi.CMD_GRID)):
+        c = build_config(variant="KAMMA_medium", num_envs=8)
+        setattr(c, field, bad)
+        assert lib.ois_workspace_bytes(C.byref(c)) == 0, field
+        assert lib.ois_last_error().decode() != ""
+
+
+def test_null_and_order_errors_without_touching_a_gpu(lib):
+    assert lib.ois_step(None, None, None) == _abi.EINVAL
+    assert lib.ois_reset(None, 0, None) == _abi.EINVAL
+    assert lib.ois_buffer(None, 0, None, None) == _abi.EINVAL
+    assert lib.ois_workspace_bytes(None) == 0
+    assert lib.ois_state_bytes(None) == 0
+    h = C.c_void_p()
+    c = build_config(variant="KAMMA_medium", num_envs=8)
+    assert lib.ois_create(C.byref(c), 0, None, 0, C.byref(h)) == _abi.EINVAL  # null workspace, checked before HIP
+
+
+def test_product_fails_loudly_without_gpu():
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    from options_in_simulation_amd.vecenv import NativeEnv, VecEnv
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        NativeEnv(build_config(variant="KAMMA_medium", num_envs=4))
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        VecEnv(num_envs=4)
+
+
+def test_product_never_imports_the_oracle():
+    pkg = os.path.join(ROOT, "options_in_simulation_amd")
+    for dirpath, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith((".py", ".h", ".hip", ".c", ".cpp")):
+                txt = open(os.path.join(dirpath, f)).read()
+                assert not re.search(r"^\s*(from|import)\s+oracle\b", txt, re.M), f      # python import
+                assert not re.search(r'#\s*include\s+["<][^">]*oracle', txt), f          # C include
+                assert "libois_oracle" not in txt and not re.search(r"\borc_[a-z_]+\s*\(", txt), f  # link / call
+
+
+def test_task_cfg_surface_and_variants():
+    cfg = default_task_cfg()
+    env = cfg["task"]["env"]
+    assert env["control"]["stiffness"] == 0.035 and env["randomCommandVelocityRanges"]["linear_x"] == [1.0, 2.0]
+    c = build_config(cfg, variant="KAMMA_medium", num_envs=7, seed=9)
+    assert (c.num_envs, c.seed, c.decimation, c.extra_substeps, c.max_episode_length) == (7, 9, 10, 10, 100)
+    assert c.policy_dt == np.float32(0.1) and c.Kp == np.float32(0.035) and c.max_sim_steps == 500000.0
+    raw = build_config(default_task_cfg(script_overrides=False), variant="KAMMA", num_envs=1)
+    assert raw.Kp == 1.0 and raw.cmd_x_lo == raw.cmd_x_hi == 1.5 and raw.max_sim_steps == 400000.0
+    assert set(VARIANTS) >= {"KAMMA", "KAMMA_medium", "KAMMA_g11_g21", "KAMMA_g1d_g21", "KAMMA_curr1", "KAMMA_eval",
+                             "KA_DDPG_4D", "KA_DDPG_2D", "KA_DDPG_1D"}
+    e = build_config(variant="KAMMA_eval", num_envs=1)
+    assert (e.gamma1_mode, e.gamma1_const, e.cmd_sampler, e.eval_sums) == (_abi.GAMMA_CONST, 0.0, _abi.CMD_EVAL, 1)
+    d = build_config(variant="KA_DDPG_2D", num_envs=1)
+    assert (d.action_dim, d.mix_mode, d.guiding_mode) == (2, _abi.MIX_BLEND, _abi.GUIDE_POLICY)
+    with pytest.raises(ValueError):
+        build_config(variant="nope")
+    with pytest.raises(TypeError):
+        build_config(variant="KAMMA", not_a_field=1)
+    # patched keys flow through (what train_*.py:63-91 do)
+    cfg["task"]["env"]["control"]["stiffness"] = 0.05
+    cfg["task"]["env"]["terrain"]["staticFriction"] = 0.6
+    cfg["task"]["env"]["learn"]["episodeLength_s"] = 5.0
+    p = build_config(cfg, variant="KAMMA", num_envs=1)
+    assert p.Kp == np.float32(0.05) and p.friction == np.float32(0.6) and p.max_episode_length == 50
+
+
+def test_composite_body_from_urdf_numbers():
+    m, com, (ixx, iyy, izz) = composite_body()
+    assert m == 25.0  # = vehicle_mass KAMMA.py:174
+    assert com == pytest.approx(4 * 0.056 / 25)
+    assert ixx == pytest.approx(0.70054, abs=1e-4) and iyy == pytest.approx(0.94864, abs=1e-4) and izz == pytest.approx(1.4681, abs=1e-4)

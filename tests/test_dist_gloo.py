@@ -1,0 +1,76 @@
+"""N>1 path on CPU: world_size-2 gloo. Arena sharding + the one all-gather of episode
+statistics per logging interval. The oracle stands in for the per-rank
+environment (the HIP env needs a GPU; its sharding is covered by -m gpu tests)."""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from options_in_simulation_amd import _abi, build_config
+from options_in_simulation_amd.dist import gather_stats, merge_stats, shard_range
+
+
+def test_shard_range_partitions():
+    for total, world in ((524288, 8), (10, 3), (7, 8), (65536, 1)):
+        spans = [shard_range(total, r, world) for r in range(world)]
+        assert spans[0][0] == 0 and spans[-1][1] == total
+        assert all(a[1] == b[0] for a, b in zip(spans, spans[1:]))
+        sizes = [b - a for a, b in spans]
+        assert max(sizes) - min(sizes) <= 1
+    with pytest.raises(ValueError):
+        shard_range(10, 3, 3)
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def _worker(rank, world, port, total, steps, out_dir):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from oracle.binding import OracleEnv
+    lo, hi = shard_range(total, rank, world)
+    env = OracleEnv(build_config(variant="KAMMA_medium", num_envs=hi - lo, seed=11, arena_offset=lo, max_sim_steps=80.0))
+    env.reset(11)
+    env.rollout(steps, _abi.POLICY_RANDOM)
+    parts = gather_stats(env.stats(reset_after=True))
+    assert len(parts) == world
+    merged = merge_stats(parts)
+    np.save(os.path.join(out_dir, f"state_{rank}.npy"), env.buffer(_abi.BUF_POSE))
+    if rank == 0:
+        np.save(os.path.join(out_dir, "merged.npy"), np.array([merged["episodes"], merged["return_mean"], merged["return_min"],
+                                                                 merged["return_max"], merged["steps"], merged["length_mean"]]))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_rank_sharded_run_matches_single_process(tmp_path):
+    total, steps, world = 100, 110, 2
+    mp.spawn(_worker, args=(world, _free_port(), total, steps, str(tmp_path)), nprocs=world, join=True)
+    from oracle.binding import OracleEnv
+    full = OracleEnv(build_config(variant="KAMMA_medium", num_envs=total, seed=11, max_sim_steps=80.0))
+    full.reset(11)
+    full.rollout(steps, _abi.POLICY_RANDOM)
+    cat = np.concatenate([np.load(tmp_path / f"state_{r}.npy") for r in range(world)])
+    assert np.array_equal(cat, full.buffer(_abi.BUF_POSE))  # sharding does not change any arena
+    merged = np.load(tmp_path / "merged.npy")
+    st = full.stats()
+    assert merged[0] == st.episodes == total
+    assert merged[1] == pytest.approx(st.return_sum / st.episodes, rel=1e-5)
+    assert merged[2] == pytest.approx(st.return_min, rel=1e-6) and merged[3] == pytest.approx(st.return_max, rel=1e-6)
+    assert merged[4] == total * steps and merged[5] == 99.0
+
+
+def test_gather_without_process_group_is_identity():
+    st = _abi.OisStats()
+    st.episodes, st.return_sum = 3.0, -6.0
+    assert gather_stats(st)[0].episodes == 3.0
+    m = merge_stats([st])
+    assert m["return_mean"] == -2.0
+    assert merge_stats([_abi.OisStats()])["return_mean"] is None

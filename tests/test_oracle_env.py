@@ -1,0 +1,187 @@
+"""CPU oracle, environment level: the reference's step/reset semantics (SURVEY.md §8a notes
+1-5), the golden trajectories, sharding invariance and the rollout entry point."""
+import os
+
+import numpy as np
+import pytest
+
+from options_in_simulation_amd import _abi, build_config
+from oracle.binding import OracleEnv
+
+G = os.path.join(os.path.dirname(__file__), "golden")
+
+
+def test_timeout_at_99_and_auto_reset():
+    """KAMMA.py:741: timeout when episode_buf >= max_episode_length - 1 -> 99-step episodes
+    (note 4); reset_idx zeroes episode_buf, bumps episode_count, sim_steps never resets."""
+    N = 5
+    env = OracleEnv(build_config(variant="KAMMA_medium", num_envs=N, seed=1))
+    env.reset(1)
+    cnt = env.buffer(_abi.BUF_COUNTERS)
+    assert (cnt[:, 0] == 0).all() and (cnt[:, 1] == 0).all() and (cnt[:, 2] == 1).all()  # post_reset: reset_idx(all)
+    z = np.zeros((N, 4), np.float32)
+    for t in range(1, 250):
+        env.step(z)
+        if t in (99, 198):
+            assert env.done.all() and env.timeout.all() and (cnt[:, 0] == 0).all()
+        else:
+            assert not env.done.any()
+            assert (cnt[:, 0] == (t % 99)).all()
+        assert (cnt[:, 1] == t).all()
+    assert (cnt[:, 2] == 3).all()
+
+
+def test_observation_mixes_new_commands_with_old_deltas():
+    """note 3 / a10: at a reset step obs[0:2] are the NEW commands (views of commands, KAMMA.py:
+    604-605) while v_delta was computed from the old command before the physics (:609)."""
+    N = 4
+    env = OracleEnv(build_config(variant="KAMMA_g11_g21", num_envs=N, seed=2))
+    env.reset(2)
+    z = np.zeros((N, 4), np.float32)
+    for _ in range(98):
+        env.step(z)
+    old_cmd = env.buffer(_abi.BUF_COMMANDS)[:, 0].copy()
+    v_prev = env.buffer(_abi.BUF_POSE)[:, 3].copy()
+    env.step(z)  # step 99: every arena times out
+    assert env.done.all()
+    new_cmd = env.buffer(_abi.BUF_COMMANDS)[:, 0]
+    assert not np.array_equal(old_cmd, new_cmd)
+    assert np.array_equal(env.obs[:, 0], new_cmd)            # desired_v shows the post-reset command
+    assert np.array_equal(env.obs[:, 2], old_cmd - v_prev)   # v_delta is the pre-physics one
+    # after the reset: velocities zero -> next step's v_forward_projected is 0; prev_* are NOT reset
+    assert (env.buffer(_abi.BUF_POSE)[:, 3] == 0).all()
+    assert (env.buffer(_abi.BUF_LINVEL)[:, :3] == 0).all()
+    assert (env.buffer(_abi.BUF_LINVEL)[:, 3] != 0).any()    # previous_linear_velocity survives (note 3)
+    assert (env.buffer(_abi.BUF_SUMS_B) == 0).all()           # episode sums zeroed (:485)
+
+
+def test_linear_acc_lags_one_step_angular_acc_is_fresh():
+    """note 1: lin_acc(t) uses v_forward_projected from the end of step t-1 (KAMMA.py:770) while
+    ang_acc(t) uses the post-physics yaw rate of step t (:771)."""
+    env = OracleEnv(build_config(variant="KAMMA_g11_g21", num_envs=1, seed=3))
+    env.reset(3)
+    z = np.zeros((1, 4), np.float32)
+    vf, wz, obs = [0.0], [0.0], []
+    for _ in range(6):
+        env.step(z)
+        vf.append(float(env.buffer(_abi.BUF_POSE)[0, 3])); wz.append(float(env.buffer(_abi.BUF_ANGVEL)[0, 2]))
+        obs.append(env.obs[0].copy())
+    dt = np.float32(0.1)
+    for t in range(2, 6):  # obs[t] belongs to step t+1
+        lin = (np.float32(vf[t]) - np.float32(vf[t - 1])) / dt
+        ang = (np.float32(wz[t + 1]) - np.float32(wz[t])) / dt
+        assert obs[t][4] == lin and obs[t][5] == ang
+
+
+def test_kamma_switch_uses_expert_while_gamma_is_one_and_policy_when_zero():
+    N = 64
+    a = np.full((N, 4), 0.5, np.float32)
+    env = OracleEnv(build_config(variant="KAMMA_g11_g21", num_envs=N, seed=4))  # gamma == 1
+    env.reset(4); env.step(a)
+    crit = 0.035 * (25.0 * (env.obs[:, 2] / 0.1))
+    np.testing.assert_allclose(env.buffer(_abi.BUF_WHEEL_TORQS)[:, 0], np.clip(crit, -4, 4), rtol=1e-6)
+    assert (env.rew <= 0).all()  # reward = guiding only = -||clipped - criteria||
+    env = OracleEnv(build_config(variant="KAMMA_eval", num_envs=N, seed=4))  # gamma == 0
+    env.reset(4); env.step(a)
+    assert (env.buffer(_abi.BUF_WHEEL_TORQS) == 1.5).all()
+    # mixed: gamma = 0.5 -> roughly half of the arenas follow the expert
+    env = OracleEnv(build_config(variant="KAMMA_medium", num_envs=4096, seed=4, gamma1_mode=_abi.GAMMA_CONST,
+                                 gamma1_const=0.5))
+    env.reset(4); env.step(np.full((4096, 4), 0.5, np.float32))
+    frac = np.mean(env.buffer(_abi.BUF_WHEEL_TORQS)[:, 0] != 1.5)
+    assert 0.45 < frac < 0.55
+
+
+def test_action_dim_expansion():
+    for variant, A in (("KA_DDPG_2D", 2), ("KA_DDPG_1D", 1)):
+        cfg = build_config(variant=variant, num_envs=3, seed=1, gamma1_mode=_abi.GAMMA_CONST, gamma1_const=0.0)
+        env = OracleEnv(cfg)
+        env.reset(1)
+        a = np.array([[0.1, 0.3], [0.2, -0.4], [1.0, 0.9]], np.float32)[:, :A]
+        env.step(a)
+        wt = env.buffer(_abi.BUF_WHEEL_TORQS)
+        if A == 2:  # [T_l, T_r] -> [l, l, r, r]  KA_DDPG_2D.py:623-624
+            np.testing.assert_allclose(wt, 3.0 * a[:, [0, 0, 1, 1]], rtol=1e-6)
+        else:       # repeated x4            KA_DDPG_1D.py:600-603
+            np.testing.assert_allclose(wt, 3.0 * a[:, [0, 0, 0, 0]], rtol=1e-6)
+
+
+def test_extras_record_and_episode_stats():
+    N = 40
+    env = OracleEnv(build_config(variant="KAMMA_medium", num_envs=N, seed=5, max_sim_steps=150.0))
+    env.reset(5)
+    ei = env.episode_info()  # the record of post_reset: sums are 0, ratios 0/0 (KAMMA.py:470-476)
+    assert ei[_abi.EI_COUNT] == N and ei[8] == 0.0 and np.isnan(ei[9]) and ei[16] == 1.0 and ei[_abi.EI_STEP] == 0
+    rng = np.random.default_rng(0)
+    rets = np.zeros(N)
+    for t in range(1, 100):
+        env.step(rng.uniform(0, 1, (N, 4)).astype(np.float32))
+        rets += env.rew
+    ei = env.episode_info()
+    assert ei[_abi.EI_COUNT] == N and ei[_abi.EI_STEP] == 99
+    np.testing.assert_allclose(ei[8], rets.mean() / 10.0, rtol=1e-4)  # rew_Final reward = mean(sum)/episodeLength_s
+    g = np.float32(1.0) - np.float32(98) / np.float32(150.0)
+    assert ei[16] == g and ei[17] == g                                 # gammas of the step that reset (:486-487)
+    st = env.stats()
+    assert st.episodes == N and st.length_sum == 99 * N and st.steps == 99 * N
+    np.testing.assert_allclose(st.return_sum, rets.sum(), rtol=1e-4)
+    assert st.return_min == pytest.approx(rets.min(), rel=1e-4) and st.return_max == pytest.approx(rets.max(), rel=1e-4)
+    assert env.stats(reset_after=True).episodes == N and env.stats().episodes == 0
+
+
+def test_rollout_equals_steps_and_random_policy_is_reproducible():
+    N, K = 50, 30
+    cfg = build_config(variant="KAMMA_medium", num_envs=N, seed=6, max_sim_steps=40.0)
+    a = np.random.default_rng(1).uniform(0, 1, (K, N, 4)).astype(np.float32)
+    e1, e2 = OracleEnv(cfg), OracleEnv(cfg)
+    e1.reset(6); e2.reset(6)
+    rs = e1.rollout(K, _abi.POLICY_EXTERNAL, a, want_reward_sum=True)
+    tot = np.zeros(N, np.float32)
+    for k in range(K):
+        e2.step(a[k]); tot += e2.rew
+    for bid, arr in e1.state().items():
+        assert np.array_equal(arr, e2.state()[bid], equal_nan=True), bid
+    np.testing.assert_allclose(rs, tot, rtol=1e-6)
+    e3, e4 = OracleEnv(cfg), OracleEnv(cfg, threads=4)
+    e3.reset(6); e4.reset(6)
+    e3.rollout(K, _abi.POLICY_RANDOM); e4.rollout(K, _abi.POLICY_RANDOM)
+    for bid, arr in e3.state().items():
+        assert np.array_equal(arr, e4.state()[bid], equal_nan=True), f"OpenMP run differs in buffer {bid}"
+
+
+def test_sharding_invariance():
+    """global arena ids key the RNG: a shard reproduces its slice of the unsharded run bit for bit."""
+    N = 96
+    full = OracleEnv(build_config(variant="KAMMA_medium", num_envs=N, seed=7, max_sim_steps=50.0))
+    parts = [OracleEnv(build_config(variant="KAMMA_medium", num_envs=N // 3, seed=7, max_sim_steps=50.0,
+                                    arena_offset=r * (N // 3))) for r in range(3)]
+    full.reset(7); [p.reset(7) for p in parts]
+    full.rollout(120, _abi.POLICY_RANDOM); [p.rollout(120, _abi.POLICY_RANDOM) for p in parts]
+    for bid, arr in full.state().items():
+        cat = np.concatenate([p.state()[bid] for p in parts])
+        assert np.array_equal(arr, cat, equal_nan=True), bid
+    tot = sum(p.stats().episodes for p in parts)
+    assert tot == full.stats().episodes == N
+
+
+def test_domain_randomisation_parameters():
+    env = OracleEnv(build_config(variant="KAMMA_medium", num_envs=2000, seed=8))
+    slopes = [-0.3, -0.2, 0.0, 0.2, 0.3]  # origin_terrain_generator.py:92
+    env.randomize_params(0.5, 1.0, slopes)
+    p = env.buffer(_abi.BUF_PARAMS)
+    assert p[:, 0].min() >= 0.5 and p[:, 0].max() < 1.0
+    np.testing.assert_allclose(np.linalg.norm(p[:, 1:], axis=1), 1.0, atol=1e-6)
+    tan = np.sqrt(p[:, 1] ** 2 + p[:, 2] ** 2) / p[:, 3]
+    assert {round(float(t), 3) for t in tan} == {0.0, 0.2, 0.3}
+    env.reset(8)
+    env.rollout(50, _abi.POLICY_ZERO)
+    assert np.isfinite(env.obs).all()
+
+
+@pytest.mark.parametrize("name", ["traj_config1_zero_torque", "traj_random_torque", "traj_expert_only", "traj_kamma_switch"])
+def test_oracle_reproduces_golden_trajectories(name):
+    """regression pin of the oracle itself (the same fixtures gate the HIP kernel in
+    tests/test_gpu_golden.py)."""
+    from tests.golden_replay import replay
+    d = np.load(os.path.join(G, name + ".npz"))
+    replay(d, name, lambda cfg: OracleEnv(cfg), to_numpy=lambda x: x, exact=True)

@@ -1,0 +1,150 @@
+"""CPU oracle: RNG known-answer vectors, deterministic trig, and physical sanity of the
+build-defined rigid-body model (docs/SPEC.md §3). The physics has no reference vectors
+(PhysX is not in the reference: parity unpinned), so these are property tests: equilibria,
+conservation-style invariants and closed-form steady states."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+from options_in_simulation_amd import _abi, build_config
+from oracle.binding import OracleEnv, fptr
+
+# Philox4x32-10 known-answer vectors (Random123 kat_vectors: counter, key -> output)
+KAT = [
+    ([0, 0, 0, 0], [0, 0], [0x6627e8d5, 0xe169c58d, 0xbc57ac4c, 0x9b00dbd8]),
+    ([0xffffffff] * 4, [0xffffffff] * 2, [0x408f276d, 0x41c83b0e, 0xa20bc7c6, 0x6d5451fd]),
+    ([0x243f6a88, 0x85a308d3, 0x13198a2e, 0x03707344], [0xa4093822, 0x299f31d0],
+     [0xd16cfe09, 0x94fdcceb, 0x5001e420, 0x24126ea1]),
+]
+
+
+@pytest.mark.parametrize("ctr,key,expect", KAT)
+def test_philox_known_answers(oracle_lib, ctr, key, expect):
+    c, k, o = (C.c_uint32 * 4)(*ctr), (C.c_uint32 * 2)(*key), (C.c_uint32 * 4)()
+    oracle_lib.orc_philox4x32_10(c, k, o)
+    assert list(o) == expect
+
+
+def test_u01_range_and_exactness(oracle_lib):
+    assert oracle_lib.orc_u01(0) == 0.0
+    assert oracle_lib.orc_u01(0xffffffff) == np.float32(1.0 - 2.0 ** -24)
+    assert oracle_lib.orc_u01(0x80000000) == 0.5
+
+
+def test_deterministic_sincos_accuracy(oracle_lib):
+    xs = np.linspace(0, np.pi, 20001, dtype=np.float32)
+    err = 0.0
+    for x in xs:
+        s, c = C.c_float(), C.c_float()
+        oracle_lib.orc_sincos(float(x), C.byref(s), C.byref(c))
+        err = max(err, abs(s.value - np.sin(np.float64(x))), abs(c.value - np.cos(np.float64(x))))
+    assert err < 2e-7
+
+
+def run(cfg, steps, action=None, seed=42):
+    env = OracleEnv(cfg)
+    env.reset(seed)
+    a = np.zeros((cfg.num_envs, cfg.action_dim), np.float32) if action is None else action
+    for _ in range(steps):
+        env.step(a)
+    return env
+
+
+def test_rest_equilibrium_is_exact():
+    """zero torque: the robot drops 3.85 cm, settles with the wheels touching (no sink, no
+    jitter) and each wheel carries m g dt / 4 of normal impulse per substep."""
+    cfg = build_config(variant="KAMMA_eval", num_envs=4)
+    env = run(cfg, 20)
+    z_expected = cfg.wheel_radius - (cfg.wheel_pos[2] - cfg.com_height)
+    np.testing.assert_allclose(env.buffer(_abi.BUF_POSE)[:, 2], z_expected, atol=2e-6)
+    np.testing.assert_allclose(env.buffer(_abi.BUF_LINVEL)[:, :3], 0.0, atol=1e-5)
+    np.testing.assert_allclose(env.buffer(_abi.BUF_ANGVEL)[:, :3], 0.0, atol=1e-5)
+    np.testing.assert_allclose(env.buffer(_abi.BUF_LAMBDA_N), cfg.body_mass * cfg.gravity * cfg.sim_dt / 4, rtol=1e-4)
+    q = env.buffer(_abi.BUF_QUAT)
+    np.testing.assert_allclose(np.linalg.norm(q, axis=1), 1.0, atol=1e-6)
+
+
+def test_constant_torque_steady_state():
+    """equal torque tau on 4 wheels: steady wheel speed = tau / c (viscous joint damping),
+    rolling without slip, no yaw."""
+    cfg = build_config(variant="KAMMA_eval", num_envs=2)
+    a = np.full((2, 4), 1.0 / 3.0, np.float32)  # tau = 1 N m
+    env = run(cfg, 80, a)
+    w = 1.0 / cfg.wheel_damping
+    np.testing.assert_allclose(env.buffer(_abi.BUF_WHEEL_VEL), w, rtol=1e-3)
+    np.testing.assert_allclose(env.buffer(_abi.BUF_POSE)[:, 3], w * cfg.wheel_radius, rtol=1e-3)  # v_forward
+    np.testing.assert_allclose(env.buffer(_abi.BUF_ANGVEL)[:, 2], 0.0, atol=1e-4)
+    # no NET lateral force (the 4 lateral rows on 3 chassis DoF admit a self-equilibrated
+    # left/right squeeze, which the warm start legitimately keeps from the initial drop)
+    np.testing.assert_allclose(env.buffer(_abi.BUF_LAMBDA_T).sum(axis=1), 0.0, atol=1e-4)
+    np.testing.assert_allclose(env.buffer(_abi.BUF_LINVEL)[:, 2], 0.0, atol=1e-5)
+
+
+def test_static_friction_holds_on_a_slope_and_slides_above_mu():
+    """plane tilted by atan(0.3) ACROSS the robot (downhill = body y, where the wheels cannot
+    roll): holds with mu = 0.85 — the warm-started impulses are exact static friction, no creep —
+    and slides with mu = 0.2."""
+    for mu, holds in ((0.85, True), (0.2, False)):
+        cfg = build_config(variant="KAMMA_eval", num_envs=1, friction=mu)
+        env = OracleEnv(cfg)
+        env.reset(3)
+        w, x, y, z = env.buffer(_abi.BUF_QUAT)[0].astype(np.float64)
+        ey = np.array([2 * (x * y - w * z), 1 - 2 * (x * x + z * z), 2 * (y * z + w * x)])  # body y in the world
+        sl = 0.3
+        n = (np.array([0.0, 0.0, 1.0]) - sl * ey) / np.sqrt(1 + sl * sl)
+        env.buffer(_abi.BUF_PARAMS)[0] = [mu, n[0], n[1], n[2]]
+        env.buffer(_abi.BUF_POSE)[0, 2] += 0.3  # lift clear of the tilted plane, let it drop
+        for _ in range(40):
+            env.step(np.zeros((1, 4), np.float32))
+        speed = np.linalg.norm(env.buffer(_abi.BUF_LINVEL)[0, :3])
+        if holds:
+            assert speed < 1e-3
+        else:
+            assert speed > 1.0
+
+
+def test_free_fall_without_ground_contact():
+    cfg = build_config(variant="KAMMA_eval", num_envs=1, init_pos=[0.0, 0.0, 5.0], decimation=1, extra_substeps=0)
+    env = OracleEnv(cfg)
+    env.reset(1)
+    for _ in range(10):
+        env.step(np.zeros((1, 4), np.float32))
+    # semi-implicit Euler: v = -g t, z = z0 - g dt^2 n(n+1)/2
+    t = 10 * cfg.sim_dt
+    assert env.buffer(_abi.BUF_LINVEL)[0, 2] == pytest.approx(-cfg.gravity * t, rel=1e-5)
+    z0 = 5.0 + cfg.com_height
+    assert env.buffer(_abi.BUF_POSE)[0, 2] == pytest.approx(z0 - cfg.gravity * cfg.sim_dt ** 2 * 55, rel=1e-5)
+
+
+def test_straight_line_symmetry_and_no_energy_gain_at_rest():
+    cfg = build_config(variant="KAMMA_g11_g21", num_envs=8)
+    env = run(cfg, 60)
+    # expert controller, cmd_yaw = 0: left/right torques equal, yaw rate ~ 0, lateral slip ~ 0
+    wt = env.buffer(_abi.BUF_WHEEL_TORQS)
+    assert np.array_equal(wt[:, 0], wt[:, 1]) and np.array_equal(wt[:, 2], wt[:, 3])  # [L, L, R, R] KAMMA.py:624
+    np.testing.assert_allclose(wt[:, 0], wt[:, 2], atol=1e-4)  # yaw error ~ 0 -> left = right
+    np.testing.assert_allclose(env.buffer(_abi.BUF_ANGVEL)[:, 2], 0.0, atol=2e-4)
+    assert np.isfinite(env.obs).all() and np.isfinite(env.rew).all()
+
+
+def test_angular_velocity_cap():
+    cfg = build_config(variant="KAMMA_eval", num_envs=1, init_ang_vel=[0.0, 0.0, 500.0], init_pos=[0.0, 0.0, 3.0])
+    env = OracleEnv(cfg)
+    env.reset(1)
+    env.step(np.zeros((1, 4), np.float32))
+    assert np.linalg.norm(env.buffer(_abi.BUF_ANGVEL)[0, :3]) <= cfg.max_angular_velocity * (1 + 1e-5)
+    np.testing.assert_allclose(np.linalg.norm(env.buffer(_abi.BUF_QUAT)[0]), 1.0, atol=1e-5)
+
+
+def test_substep_entry_point_matches_env(oracle_lib):
+    """orc_substep (world-frame angular velocity in/out) composes to the same motion as the env."""
+    cfg = build_config(variant="KAMMA_eval", num_envs=1)
+    p = np.array([0, 0, 0.2], np.float32); q = np.array([1, 0, 0, 0], np.float32)
+    v = np.zeros(3, np.float32); w = np.zeros(3, np.float32); spin = np.zeros(4, np.float32)
+    ln, l1, l2 = (np.zeros(4, np.float32) for _ in range(3))
+    nrm = np.array([0, 0, 1], np.float32); tau = np.zeros(4, np.float32)
+    for _ in range(300):
+        oracle_lib.orc_substep(C.byref(cfg), 0.85, fptr(nrm), fptr(tau), fptr(p), fptr(q), fptr(v), fptr(w), fptr(spin),
+                               fptr(ln), fptr(l1), fptr(l2))
+    assert p[2] == pytest.approx(cfg.wheel_radius - (cfg.wheel_pos[2] - cfg.com_height), abs=1e-5)
