@@ -54,6 +54,16 @@ def usable_cores():
     return max(1, min(n, int(os.environ.get("OIS_CPU_THREADS", "16"))))
 
 
+def pmc_traffic(n_arenas):
+    """HBM bytes per step_kernel launch from the committed PMC run (bench.py cannot collect
+    counters on itself). Only returned when the profile was taken at this arena count."""
+    try:
+        d = json.load(open(os.path.join(ROOT, "profiles", "r1_pmc_traffic.json")))
+        return d["hbm_bytes_per_launch"] if int(d["arenas"]) == int(n_arenas) else None
+    except (OSError, KeyError, ValueError):
+        return None
+
+
 def cpu_baseline(n_arenas, seconds_target=12.0):
     """time the oracle on the host cores: same task, same actor-free step (random actions)."""
     import numpy as np
@@ -67,7 +77,7 @@ def cpu_baseline(n_arenas, seconds_target=12.0):
     t0 = time.perf_counter()
     env.rollout(4, _abi.POLICY_RANDOM)
     per_step = (time.perf_counter() - t0) / 4
-    steps = int(max(8, min(2000, seconds_target / max(per_step, 1e-6))))
+    steps = int(max(8, min(50000, seconds_target / max(per_step, 1e-6))))
     t0 = time.perf_counter()
     env.rollout(steps, _abi.POLICY_RANDOM)
     dt = time.perf_counter() - t0
@@ -172,11 +182,14 @@ def main():
                        "solver_iterations": cfg.solver_iterations, "sharding": f"arenas x{world}, no data-path collective",
                        "stats_allgather_every": args.log_interval},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": pmc_traffic(N),
                          "kernel": "step_kernel", "kernel_ms": kernel_ms,
                          "algorithmic_bytes_per_launch": ALGO_BYTES_PER_ENV_STEP * N,
-                         "note": "kernel is fp32-VALU bound (20 substeps x 4-iteration contact solve per env-step); "
-                                 "see DESIGN.md for the VALU roofline"},
+                         "traffic_source": "profiles/r1_pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, "
+                                           "separate passes, FETCH_SIZE x2 per the gfx950 correction)",
+                         "note": "HBM is not the limiter: the kernel is fp32-VALU issue bound (20 substeps x "
+                                 "4-iteration contact solve = ~30k VALU instructions per env-step, one wave per SIMD "
+                                 "at 65 536 arenas); VALU roofline in DESIGN.md §5"},
             "env_only_env_steps_per_s": N / (kernel_ms * 1e-3),
         }
         if gathered:
