@@ -11,7 +11,7 @@ import os
 from . import _abi
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "libois_hip.so")
+LIB_PATH = os.environ.get("OIS_LIB_OVERRIDE") or os.path.join(_HERE, "lib", "libois_hip.so")  # override: kernel experiments only
 
 # every symbol include/ois.h declares (tests/test_abi.py checks the exports against the header)
 SYMBOLS = (

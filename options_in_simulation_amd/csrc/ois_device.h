@@ -153,8 +153,33 @@ OIS_DEV void rot(const float R[9], const float a[3], float o[3]) {  // o = R a
 
 OIS_DEV float clipf(float x, float lo, float hi) { return fminf(fmaxf(x, lo), hi); }
 
+// ---------------------------------------------------------------- lanes per arena -----
+// LPA = 1: one lane owns the whole arena (4 wheels).  LPA = 2: two adjacent lanes share an
+// arena, lane h = tid & 1 owns the wheels {2h, 2h+1} = the left (fl, rl) or right (fr, rr)
+// side; chassis state is replicated in both lanes. At 65 536 arenas LPA = 2 puts two waves on
+// every SIMD (a single wave per SIMD issues a VALU instruction only every ~1.5-1.9 ns against
+// ~1.2 ns with two, profiles/r1_valu_rate.txt) at the price of computing the chassis part
+// twice and of one quad_perm DPP add per cross-side sum. Wheel sums keep the SPEC order
+// (w0 + w1) + (w2 + w3): each lane adds its own pair, then the partner's pair.
+template <int CTRL>
+OIS_DEV float dpp(float x) {
+  return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x), CTRL, 0xF, 0xF, true));
+}
+template <int LPA>
+OIS_DEV float side_sum(float own) {  // own = sum over this lane's wheels
+  if (LPA == 1) return own;
+  return own + dpp<0xB1>(own);  // quad_perm [1,0,3,2]: partner lane; a + b == b + a bitwise
+}
+template <int LPA>
+OIS_DEV float sum_wheels(const float* x) {  // x[4 / LPA]
+  if (LPA == 1) return (x[0] + x[1]) + (x[2] + x[3]);
+  return side_sum<2>(x[0] + x[1]);
+}
+
 // ---------------------------------------------------------------- per-arena state -----
-struct Arena {
+template <int LPA>
+struct ArenaT {
+  static constexpr int WPL = 4 / LPA;  // wheels per lane
   float p[3], vfwd;      // COM position, v_forward_projected of the previous step
   float q[4];
   float v[3], prev_lin;  // world linear velocity, previous_linear_velocity[:,0]
@@ -162,10 +187,10 @@ struct Arena {
   float cmd[4];
   int ep_buf, sim_steps, ep_count;
   float mu, n[3];
-  float jv[4];                  // wheel joint velocities (dof_vel), order fl, rl, fr, rr
-  float ln[4], l1[4], l2[4];    // cached contact impulses per wheel
-  float wt[4];                  // clipped wheel torques (wheel_torqs)
-  float sa[4], sb[4], sc[4];    // episode sums: r1 r2 r3 dense | sparse guiding observed final | eval
+  float jv[WPL];                      // wheel joint velocities (dof_vel) of this lane's wheels
+  float ln[WPL], l1[WPL], l2[WPL];    // cached contact impulses
+  float wt[WPL];                      // clipped wheel torques (wheel_torqs)
+  float sa[4], sb[4], sc[4];          // episode sums: r1 r2 r3 dense | sparse guiding observed final | eval
 };
 
 // torch_rand_float(lower, upper) = (upper - lower) * rand + lower  (KAMMA.py:424-456)
@@ -198,8 +223,10 @@ OIS_DEV void contrib_identity(ResetContrib& c) {
   for (int k = 0; k < 4; ++k) c.m[k] = -__builtin_inff();
 }
 
-// reset_idx for one arena (KAMMA.py:417-498)
-OIS_DEV void reset_arena(const DevConsts& K, int64_t gid, float gamma1, float gamma2, Arena& S, ResetContrib& rc) {
+// reset_idx for one arena (KAMMA.py:417-498). wheel0 = index of this lane's first wheel.
+template <int LPA>
+OIS_DEV void reset_arena(const DevConsts& K, int64_t gid, int wheel0, float gamma1, float gamma2, ArenaT<LPA>& S,
+                         ResetContrib& rc) {
   const float Sf = S.sb[3];                   // "Final reward" sum
   const float hg = 100.0f * (1.0f - gamma2);  // :470
   const float gg = 100.0f * gamma2;           // :475
@@ -260,16 +287,21 @@ OIS_DEV void reset_arena(const DevConsts& K, int64_t gid, float gamma1, float ga
 #pragma unroll
   for (int k = 0; k < 3; ++k) { S.v[k] = K.init_lin_vel[k]; S.w[k] = K.init_ang_vel[k]; }  // :435
 #pragma unroll
-  for (int k = 0; k < 4; ++k) { S.jv[k] = K.init_dof_vel[k]; S.ln[k] = 0.0f; S.l1[k] = 0.0f; S.l2[k] = 0.0f; }  // :438
+  for (int k = 0; k < ArenaT<LPA>::WPL; ++k) {
+    const int gk = wheel0 + k;  // :438
+    S.jv[k] = gk == 0 ? K.init_dof_vel[0] : (gk == 1 ? K.init_dof_vel[1] : (gk == 2 ? K.init_dof_vel[2] : K.init_dof_vel[3]));
+    S.ln[k] = 0.0f; S.l1[k] = 0.0f; S.l2[k] = 0.0f;
+  }
   S.ep_buf = 0;     // :462
   S.ep_count += 1;  // :463
 }
 
-// Pairwise butterfly over the 16 arenas (= 16 consecutive lanes) of a reduction group.
-template <int OP>
+// Pairwise butterfly over the 16 arenas (= 16 * LPA consecutive lanes) of a reduction group;
+// with LPA = 2 both lanes of an arena hold the same value, so the butterfly skips lane bit 0.
+template <int OP, int LPA>
 OIS_DEV float group_reduce16(float x) {
 #pragma unroll
-  for (int m = 1; m < kGroup; m <<= 1) {
+  for (int m = LPA; m < kGroup * LPA; m <<= 1) {
     const float y = __shfl_xor(x, m, 64);
     x = OP == 0 ? x + y : fmaxf(x, y);
   }
@@ -279,14 +311,15 @@ OIS_DEV float group_reduce16(float x) {
 // Record of a reset event + finished-episode accumulators for the group of this lane.
 // Must be called by all 64 lanes of the wave (shuffles); only groups with a resetting arena
 // write. group = arena / 16.
+template <int LPA>
 OIS_DEV void group_record(const DevBuffers& B, int group, int lane, bool group_has_reset, const ResetContrib& rc,
                           int stamp, bool count_stats) {
   float rs[kRecSum], rm[4];
 #pragma unroll
-  for (int k = 0; k < kRecSum; ++k) rs[k] = group_reduce16<0>(rc.s[k]);
+  for (int k = 0; k < kRecSum; ++k) rs[k] = group_reduce16<0, LPA>(rc.s[k]);
 #pragma unroll
-  for (int k = 0; k < 4; ++k) rm[k] = group_reduce16<1>(rc.m[k]);
-  if ((lane & (kGroup - 1)) == 0 && group_has_reset) {
+  for (int k = 0; k < 4; ++k) rm[k] = group_reduce16<1, LPA>(rc.m[k]);
+  if ((lane & (kGroup * LPA - 1)) == 0 && group_has_reset) {
     float* P = B.partials + (size_t)group * 32;
 #pragma unroll
     for (int k = 0; k < kRecSum; ++k) P[k] = rs[k];
@@ -300,6 +333,14 @@ OIS_DEV void group_record(const DevBuffers& B, int group, int lane, bool group_h
       A[6] = fmaxf(A[6], rm[2]); A[7] = fmaxf(A[7], rm[3]);
     }
   }
+}
+
+// does the 16-arena group of this lane contain a set bit of the wave ballot?
+template <int LPA>
+OIS_DEV bool group_any(unsigned long long ballot, int lane) {
+  constexpr int span = kGroup * LPA;  // 16 or 32 lanes
+  const unsigned long long mask = span == 64 ? ~0ull : ((1ull << span) - 1ull);
+  return ((ballot >> (lane & ~(span - 1))) & mask) != 0ull;
 }
 
 }  // namespace ois

@@ -3,9 +3,10 @@
 // post_physics_step (src/my_envs/KAMMA.py:596-727) with PhysX replaced by the build-defined
 // rigid-body model of docs/SPEC.md §3.
 //
-// One launch = one (or k) policy step(s) for all arenas, one arena per lane: controller ->
-// action mixing -> torque clip -> 20 contact-solver substeps -> termination -> reward ->
-// auto-reset -> observation -> forward-speed projection, state in registers throughout.
+// One launch = one (or k) policy step(s) for all arenas: controller -> action mixing ->
+// torque clip -> 20 contact-solver substeps -> termination -> reward -> auto-reset ->
+// observation -> forward-speed projection, state in registers throughout.
+// LPA lanes per arena (ois_device.h): 1 = a lane owns an arena, 2 = a lane pair shares one.
 #include <hip/hip_runtime.h>
 
 #include <cmath>
@@ -20,82 +21,98 @@ using namespace ois;
 
 namespace {
 
-constexpr int kBlock = 64;  // one wave per workgroup: 65 536 arenas = 1024 workgroups = 1 per SIMD
+constexpr int kBlock = 64;  // one wave per workgroup
+#ifndef OIS_STEP_BOUNDS
+#define OIS_STEP_BOUNDS __launch_bounds__(kBlock)
+#endif
 
 // ------------------------------------------------------------------ load / store ------
-OIS_DEV void load_arena(const DevConsts& K, const DevBuffers& B, int i, Arena& S) {
+OIS_DEV void unpack(const float4 t, float* d) { d[0] = t.x; d[1] = t.y; d[2] = t.z; d[3] = t.w; }
+template <int LPA>
+OIS_DEV void load_wheels(const float4* base, int arena, int h, float* d) {  // this lane's wheels of a [N][4] row
+  if (LPA == 1) { unpack(base[arena], d); }
+  else { const float2 t = reinterpret_cast<const float2*>(base)[arena * 2 + h]; d[0] = t.x; d[1] = t.y; }
+}
+template <int LPA>
+OIS_DEV void store_wheels(float4* base, int arena, int h, const float* s) {
+  if (LPA == 1) base[arena] = make_float4(s[0], s[1], s[2], s[3]);
+  else reinterpret_cast<float2*>(base)[arena * 2 + h] = make_float2(s[0], s[1]);
+}
+
+template <int LPA>
+OIS_DEV void load_arena(const DevConsts& K, const DevBuffers& B, int i, int h, ArenaT<LPA>& S) {
   const float4 po = B.pose[i], qu = B.quat[i], lv = B.linvel[i], av = B.angvel[i], cm = B.commands[i];
-  const float4 pr = B.params[i], jv = B.wheel_vel[i], ln = B.lam_n[i], l1 = B.lam_l[i], l2 = B.lam_t[i];
-  const float4 sa = B.sums_a[i], sb = B.sums_b[i];
+  const float4 pr = B.params[i], sa = B.sums_a[i], sb = B.sums_b[i];
   const int4 ct = B.counters[i];
   S.p[0] = po.x; S.p[1] = po.y; S.p[2] = po.z; S.vfwd = po.w;
-  S.q[0] = qu.x; S.q[1] = qu.y; S.q[2] = qu.z; S.q[3] = qu.w;
+  unpack(qu, S.q);
   S.v[0] = lv.x; S.v[1] = lv.y; S.v[2] = lv.z; S.prev_lin = lv.w;
   S.w[0] = av.x; S.w[1] = av.y; S.w[2] = av.z; S.prev_ang = av.w;
-  S.cmd[0] = cm.x; S.cmd[1] = cm.y; S.cmd[2] = cm.z; S.cmd[3] = cm.w;
+  unpack(cm, S.cmd);
   S.ep_buf = ct.x; S.sim_steps = ct.y; S.ep_count = ct.z;
   S.mu = pr.x; S.n[0] = pr.y; S.n[1] = pr.z; S.n[2] = pr.w;
-  S.jv[0] = jv.x; S.jv[1] = jv.y; S.jv[2] = jv.z; S.jv[3] = jv.w;
-  S.ln[0] = ln.x; S.ln[1] = ln.y; S.ln[2] = ln.z; S.ln[3] = ln.w;
-  S.l1[0] = l1.x; S.l1[1] = l1.y; S.l1[2] = l1.z; S.l1[3] = l1.w;
-  S.l2[0] = l2.x; S.l2[1] = l2.y; S.l2[2] = l2.z; S.l2[3] = l2.w;
-  S.sa[0] = sa.x; S.sa[1] = sa.y; S.sa[2] = sa.z; S.sa[3] = sa.w;
-  S.sb[0] = sb.x; S.sb[1] = sb.y; S.sb[2] = sb.z; S.sb[3] = sb.w;
+  unpack(sa, S.sa); unpack(sb, S.sb);
+  load_wheels<LPA>(B.wheel_vel, i, h, S.jv);
+  load_wheels<LPA>(B.lam_n, i, h, S.ln);
+  load_wheels<LPA>(B.lam_l, i, h, S.l1);
+  load_wheels<LPA>(B.lam_t, i, h, S.l2);
   if (K.eval_sums) {
-    const float4 sc = B.sums_c[i], wt = B.wheel_torqs[i];
-    S.sc[0] = sc.x; S.sc[1] = sc.y; S.sc[2] = sc.z; S.sc[3] = sc.w;
-    S.wt[0] = wt.x; S.wt[1] = wt.y; S.wt[2] = wt.z; S.wt[3] = wt.w;
+    unpack(B.sums_c[i], S.sc);
+    load_wheels<LPA>(B.wheel_torqs, i, h, S.wt);
   } else {
-    for (int k = 0; k < 4; ++k) { S.sc[k] = 0.0f; S.wt[k] = 0.0f; }
+    for (int k = 0; k < 4; ++k) S.sc[k] = 0.0f;
+    for (int k = 0; k < ArenaT<LPA>::WPL; ++k) S.wt[k] = 0.0f;
   }
 }
 
-OIS_DEV void store_arena(const DevConsts& K, const DevBuffers& B, int i, const Arena& S) {
-  B.pose[i] = make_float4(S.p[0], S.p[1], S.p[2], S.vfwd);
-  B.quat[i] = make_float4(S.q[0], S.q[1], S.q[2], S.q[3]);
-  B.linvel[i] = make_float4(S.v[0], S.v[1], S.v[2], S.prev_lin);
-  B.angvel[i] = make_float4(S.w[0], S.w[1], S.w[2], S.prev_ang);
-  B.commands[i] = make_float4(S.cmd[0], S.cmd[1], S.cmd[2], S.cmd[3]);
-  B.counters[i] = make_int4(S.ep_buf, S.sim_steps, S.ep_count, 0);
-  B.wheel_vel[i] = make_float4(S.jv[0], S.jv[1], S.jv[2], S.jv[3]);
-  B.lam_n[i] = make_float4(S.ln[0], S.ln[1], S.ln[2], S.ln[3]);
-  B.lam_l[i] = make_float4(S.l1[0], S.l1[1], S.l1[2], S.l1[3]);
-  B.lam_t[i] = make_float4(S.l2[0], S.l2[1], S.l2[2], S.l2[3]);
-  B.sums_a[i] = make_float4(S.sa[0], S.sa[1], S.sa[2], S.sa[3]);
-  B.sums_b[i] = make_float4(S.sb[0], S.sb[1], S.sb[2], S.sb[3]);
-  if (K.eval_sums) B.sums_c[i] = make_float4(S.sc[0], S.sc[1], S.sc[2], S.sc[3]);
-  B.wheel_torqs[i] = make_float4(S.wt[0], S.wt[1], S.wt[2], S.wt[3]);
+template <int LPA>
+OIS_DEV void store_arena(const DevConsts& K, const DevBuffers& B, int i, int h, const ArenaT<LPA>& S) {
+  if (h == 0) {  // chassis rows are replicated in the lane pair: one lane writes them
+    B.pose[i] = make_float4(S.p[0], S.p[1], S.p[2], S.vfwd);
+    B.quat[i] = make_float4(S.q[0], S.q[1], S.q[2], S.q[3]);
+    B.linvel[i] = make_float4(S.v[0], S.v[1], S.v[2], S.prev_lin);
+    B.angvel[i] = make_float4(S.w[0], S.w[1], S.w[2], S.prev_ang);
+    B.commands[i] = make_float4(S.cmd[0], S.cmd[1], S.cmd[2], S.cmd[3]);
+    B.counters[i] = make_int4(S.ep_buf, S.sim_steps, S.ep_count, 0);
+    B.sums_a[i] = make_float4(S.sa[0], S.sa[1], S.sa[2], S.sa[3]);
+    B.sums_b[i] = make_float4(S.sb[0], S.sb[1], S.sb[2], S.sb[3]);
+    if (K.eval_sums) B.sums_c[i] = make_float4(S.sc[0], S.sc[1], S.sc[2], S.sc[3]);
+  }
+  store_wheels<LPA>(B.wheel_vel, i, h, S.jv);
+  store_wheels<LPA>(B.lam_n, i, h, S.ln);
+  store_wheels<LPA>(B.lam_l, i, h, S.l1);
+  store_wheels<LPA>(B.lam_t, i, h, S.l2);
+  store_wheels<LPA>(B.wheel_torqs, i, h, S.wt);
 }
 
 // ------------------------------------------------------------------ the step kernel ---
-__global__ __launch_bounds__(kBlock) void step_kernel(DevConsts K, DevBuffers B, const float* __restrict__ actions,
+template <int LPA>
+__global__ OIS_STEP_BOUNDS void step_kernel(DevConsts K, DevBuffers B, const float* __restrict__ actions,
                                                       float* __restrict__ reward_sum, int N, int ksteps, int policy) {
-  const int arena = blockIdx.x * kBlock + threadIdx.x;
+  constexpr int W = 4 / LPA;
+  const int tid = blockIdx.x * kBlock + threadIdx.x;
   const int lane = threadIdx.x & 63;
+  const int arena = tid / LPA;
+  const int h = LPA == 1 ? 0 : (tid & 1);  // which side of the arena this lane owns
+  const int wheel0 = h * W;
   const bool valid = arena < N;
   const int la = valid ? arena : N - 1;  // tail lanes shadow the last arena and store nothing
   const int64_t gid = K.arena_offset + la;
   const int A = K.action_dim;
 
-  Arena S;
-  load_arena(K, B, la, S);
+  ArenaT<LPA> S;
+  load_arena<LPA>(K, B, la, h, S);
   float rsum = 0.0f;
 
   for (int s = 0; s < ksteps; ++s) {
     const bool last = s == ksteps - 1;
-    // ---- actions -> 4 wheels (KA_DDPG_2D.py:623-624, KA_DDPG_1D.py:600-603) ----
+    // ---- actions -> this lane's wheels (KA_DDPG_2D.py:623-624, KA_DDPG_1D.py:600-603) ----
     float a4[4] = {0.0f, 0.0f, 0.0f, 0.0f};
     if (policy == OIS_POLICY_EXTERNAL) {
       const float* ap = actions + ((size_t)s * N + la) * A;
-      if (A == 4) {
-        const float4 t = *reinterpret_cast<const float4*>(ap);
-        a4[0] = t.x; a4[1] = t.y; a4[2] = t.z; a4[3] = t.w;
-      } else if (A == 2) {
-        const float2 t = *reinterpret_cast<const float2*>(ap);
-        a4[0] = a4[1] = t.x; a4[2] = a4[3] = t.y;
-      } else {
-        a4[0] = a4[1] = a4[2] = a4[3] = ap[0];
-      }
+      if (A == 4) { unpack(*reinterpret_cast<const float4*>(ap), a4); }
+      else if (A == 2) { const float2 t = *reinterpret_cast<const float2*>(ap); a4[0] = a4[1] = t.x; a4[2] = a4[3] = t.y; }
+      else { a4[0] = a4[1] = a4[2] = a4[3] = ap[0]; }
     } else if (policy == OIS_POLICY_RANDOM) {
       float u[4];
       draw4(K, gid, (uint32_t)S.sim_steps, PURPOSE_ACTION, u);
@@ -103,6 +120,9 @@ __global__ __launch_bounds__(kBlock) void step_kernel(DevConsts K, DevBuffers B,
       else if (A == 2) { a4[0] = a4[1] = u[0]; a4[2] = a4[3] = u[1]; }
       else { a4[0] = a4[1] = a4[2] = a4[3] = u[0]; }
     }
+    float aw[W];
+#pragma unroll
+    for (int k = 0; k < W; ++k) aw[k] = (LPA == 1) ? a4[k] : (h ? a4[2 + k] : a4[k]);
     // ---- pre_physics_step (KAMMA.py:596-656) ----
     const float current_v = S.vfwd;      // :607
     const float current_omega = S.w[2];  // :608
@@ -121,63 +141,69 @@ __global__ __launch_bounds__(kBlock) void step_kernel(DevConsts K, DevBuffers B,
       draw4(K, gid, (uint32_t)S.sim_steps, PURPOSE_MASK, u);  // torch.rand(num_envs, 1) :633
       rnd = u[0];
     }
-    float torq[4], wt[4], pol[4], d2[4];
+    float torq[W], wt[W], pol[W], d2[W], w2s[W];
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      const float crit = j < 2 ? ac_left : ac_right;  // :624 order fl, rl, fr, rr
-      pol[j] = a4[j] * K.action_scale;
+    for (int k = 0; k < W; ++k) {
+      const bool left = (LPA == 1) ? (k < 2) : (h == 0);
+      const float crit = left ? ac_left : ac_right;  // :624 order fl, rl, fr, rr
+      pol[k] = aw[k] * K.action_scale;
       float t;
       if (K.mix_mode == OIS_MIX_SWITCH) {
         const float mask = rnd < gamma1 ? 1.0f : 0.0f;  // :634
-        t = mask * crit + (1.0f - mask) * pol[j];        // :635
+        t = mask * crit + (1.0f - mask) * pol[k];        // :635
       } else {
-        t = ((1.0f - gamma1) * a4[j]) * K.action_scale + gamma1 * crit;  // KA_DDPG_4D.py:631
+        t = ((1.0f - gamma1) * aw[k]) * K.action_scale + gamma1 * crit;  // KA_DDPG_4D.py:631
       }
-      torq[j] = t;
-      wt[j] = clipf(t, -K.torque_clip, K.torque_clip);  // :649
-      const float d = (K.guiding_mode == OIS_GUIDE_EXECUTED ? wt[j] : pol[j]) - crit;
-      d2[j] = d * d;
+      torq[k] = t;
+      wt[k] = clipf(t, -K.torque_clip, K.torque_clip);  // :649
+      const float d = (K.guiding_mode == OIS_GUIDE_EXECUTED ? wt[k] : pol[k]) - crit;
+      d2[k] = d * d;
+      w2s[k] = wt[k] * wt[k];
     }
-    const float guiding = -sqrtf((d2[0] + d2[1]) + (d2[2] + d2[3]));  // :656 / KA_DDPG_4D.py:637
+    const float guiding = -sqrtf(sum_wheels<LPA>(d2));  // :656 / KA_DDPG_4D.py:637
     if (K.eval_sums) {  // KAMMA_eval.py:677-685
-      float e2[4];
+      float e2[W];
 #pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        const float old = S.sc[3] != 0.0f ? S.wt[j] : 0.0f;
-        const float df = old - wt[j];
-        e2[j] = df * df;
+      for (int k = 0; k < W; ++k) {
+        const float old = S.sc[3] != 0.0f ? S.wt[k] : 0.0f;
+        const float df = old - wt[k];
+        e2[k] = df * df;
       }
-      S.sc[0] += ((e2[0] + e2[1]) + (e2[2] + e2[3])) / 10.0f;
+      S.sc[0] += sum_wheels<LPA>(e2) / 10.0f;
       S.sc[2] += S.cmd[0] / 10.0f;
       S.sc[3] = 1.0f;
     }
 #pragma unroll
-    for (int j = 0; j < 4; ++j) S.wt[j] = wt[j];
+    for (int k = 0; k < W; ++k) S.wt[k] = wt[k];
 
     // ---- physics: decimation (:646-653) + controlFrequencyInv (:43) substeps ----
     float R[9];
     {
-      Phys X;
+      PhysT<LPA> X;
       float wb[3];
       rotmat(S.q, R);
       rotT(R, S.w, wb);
 #pragma unroll
       for (int k = 0; k < 3; ++k) { X.p[k] = S.p[k]; X.v[k] = S.v[k]; X.wb[k] = wb[k]; X.n[k] = S.n[k]; }
 #pragma unroll
-      for (int k = 0; k < 4; ++k) {
-        X.q[k] = S.q[k]; X.tau[k] = wt[k]; X.spin[k] = S.jv[k] + wb[1];
+      for (int k = 0; k < 4; ++k) X.q[k] = S.q[k];
+#pragma unroll
+      for (int k = 0; k < W; ++k) {
+        X.tau[k] = wt[k]; X.spin[k] = S.jv[k] + wb[1];
         X.ln[k] = S.ln[k]; X.l1[k] = S.l1[k]; X.l2[k] = S.l2[k];
       }
       X.mu = S.mu;
-      substep<true>(K, X);
-      for (int i = 1; i < K.nsub; ++i) substep<false>(K, X);
+      substep<true, LPA>(K, wheel0, X);
+      for (int i = 1; i < K.nsub; ++i) substep<false, LPA>(K, wheel0, X);
       rotmat(X.q, R);
       rot(R, X.wb, S.w);  // body -> world with the final orientation
 #pragma unroll
       for (int k = 0; k < 3; ++k) { S.p[k] = X.p[k]; S.v[k] = X.v[k]; }
 #pragma unroll
-      for (int k = 0; k < 4; ++k) {
-        S.q[k] = X.q[k]; S.jv[k] = X.spin[k] - X.wb[1];
+      for (int k = 0; k < 4; ++k) S.q[k] = X.q[k];
+#pragma unroll
+      for (int k = 0; k < W; ++k) {
+        S.jv[k] = X.spin[k] - X.wb[1];
         S.ln[k] = X.ln[k]; S.l1[k] = X.l1[k]; S.l2[k] = X.l2[k];
       }
     }
@@ -202,7 +228,7 @@ __global__ __launch_bounds__(kBlock) void step_kernel(DevConsts K, DevBuffers B,
     S.prev_ang = S.w[2];                                           // :775
     const float r1 = vd * vd + 5.0f * (od * od);                   // :779
     const float r2 = lin_acc * lin_acc + ang_acc * ang_acc;        // :781
-    const float r3 = (wt[0] * wt[0] + wt[1] * wt[1]) + (wt[2] * wt[2] + wt[3] * wt[3]);  // :783
+    const float r3 = sum_wheels<LPA>(w2s);                         // :783
     const float c1 = K.w1 * r1, c2 = K.w2 * r2, c3 = K.w3 * r3;
     const float rdense = (c1 + c2) + c3;                           // :786
     const float sparse = (fabsf(vd) < K.sparse_threshold && fabsf(od) < K.sparse_threshold) ? K.sparse_bonus : 0.0f;
@@ -217,52 +243,58 @@ __global__ __launch_bounds__(kBlock) void step_kernel(DevConsts K, DevBuffers B,
     ResetContrib rc;
     contrib_identity(rc);
     const bool do_reset = reset && valid;
-    if (reset) reset_arena(K, gid, gamma1, gamma2, S, rc);
+    if (reset) reset_arena<LPA>(K, gid, wheel0, gamma1, gamma2, S, rc);
     if (!valid) contrib_identity(rc);
     // outputs (only the last step of a rollout is observable)
     if (last && valid) {
-      // get_observations (:833); desired_* are views of commands -> post-reset values; clamp: rl_task.py:99
-      float* o = B.obs + (size_t)arena * 6;
-      const float co = K.clip_obs;
-      *reinterpret_cast<float2*>(o) = make_float2(clipf(S.cmd[0], -co, co), clipf(S.cmd[2], -co, co));
-      *reinterpret_cast<float2*>(o + 2) = make_float2(clipf(vd, -co, co), clipf(od, -co, co));
-      *reinterpret_cast<float2*>(o + 4) = make_float2(clipf(lin_acc, -co, co), clipf(ang_acc, -co, co));
-      B.rew[arena] = rew;
-      B.done[arena] = reset ? 1 : 0;
-      B.timeout[arena] = timeout ? 1 : 0;
+      if (h == 0) {
+        // get_observations (:833); desired_* are views of commands -> post-reset values; clamp: rl_task.py:99
+        float* o = B.obs + (size_t)arena * 6;
+        const float co = K.clip_obs;
+        *reinterpret_cast<float2*>(o) = make_float2(clipf(S.cmd[0], -co, co), clipf(S.cmd[2], -co, co));
+        *reinterpret_cast<float2*>(o + 2) = make_float2(clipf(vd, -co, co), clipf(od, -co, co));
+        *reinterpret_cast<float2*>(o + 4) = make_float2(clipf(lin_acc, -co, co), clipf(ang_acc, -co, co));
+        B.rew[arena] = rew;
+        B.done[arena] = reset ? 1 : 0;
+        B.timeout[arena] = timeout ? 1 : 0;
+      }
       if (arena == 0) {  // task.observed_components ingredients (:840-867)
         float* d = B.env0_diag;
-        d[0] = S.cmd[0]; d[1] = current_v; d[2] = S.cmd[2]; d[3] = current_omega; d[4] = vd; d[5] = od;
-        d[6] = lin_acc; d[7] = ang_acc; d[8] = (float)S.ep_count;
-        for (int j = 0; j < 4; ++j) { d[9 + j] = torq[j]; d[15 + j] = pol[j]; }
-        d[13] = ac_left; d[14] = ac_right;
-        d[19] = gamma2; d[20] = c1; d[21] = c2; d[22] = c3; d[23] = rdense; d[24] = sparse; d[25] = observed;
-        d[26] = guiding; d[27] = rew; d[28] = gamma1;
+        for (int k = 0; k < W; ++k) {
+          const int gk = wheel0 + k;
+          const int ti = gk < 2 ? 9 + gk : 11 + (gk - 2);  // torque_apl fl rl | fr rr at 9,10,11,12
+          d[ti] = torq[k];
+          d[15 + gk] = pol[k];
+        }
+        if (h == 0) {
+          d[0] = S.cmd[0]; d[1] = current_v; d[2] = S.cmd[2]; d[3] = current_omega; d[4] = vd; d[5] = od;
+          d[6] = lin_acc; d[7] = ang_acc; d[8] = (float)S.ep_count;
+          d[13] = ac_left; d[14] = ac_right;
+          d[19] = gamma2; d[20] = c1; d[21] = c2; d[22] = c3; d[23] = rdense; d[24] = sparse; d[25] = observed;
+          d[26] = guiding; d[27] = rew; d[28] = gamma1;
+        }
       }
     }
     // tail of post_physics_step (:701-710) on the possibly reset state
     S.vfwd = forward_projection(S.q, S.v);
     // per-group record of the reset event (extras["episode"], episode statistics)
     const unsigned long long m = __ballot(do_reset);
-    if (m != 0ull) {
-      const bool grp = ((m >> (lane & ~(kGroup - 1))) & 0xFFFFull) != 0ull;
-      group_record(B, arena / kGroup, lane, grp, rc, S.sim_steps, true);
-    }
+    if (m != 0ull) group_record<LPA>(B, arena / kGroup, lane, group_any<LPA>(m, lane), rc, S.sim_steps, true);
   }
   if (valid) {
-    store_arena(K, B, arena, S);
-    if (reward_sum != nullptr) reward_sum[arena] = rsum;
+    store_arena<LPA>(K, B, arena, h, S);
+    if (reward_sum != nullptr && h == 0) reward_sum[arena] = rsum;
   }
 }
 
 // ------------------------------------------------------------------ post_reset --------
-// KAMMA.py:366-414: zero the task buffers, reset_idx(all arenas).
+// KAMMA.py:366-414: zero the task buffers, reset_idx(all arenas). One lane per arena.
 __global__ __launch_bounds__(kBlock) void reset_kernel(DevConsts K, DevBuffers B, int N) {
   const int arena = blockIdx.x * kBlock + threadIdx.x;
   const int lane = threadIdx.x & 63;
   const bool valid = arena < N;
   const int la = valid ? arena : N - 1;
-  Arena S;
+  ArenaT<1> S;
   for (int k = 0; k < 3; ++k) { S.p[k] = 0.0f; S.v[k] = 0.0f; S.w[k] = 0.0f; S.n[k] = 0.0f; }
   for (int k = 0; k < 4; ++k) {
     S.q[k] = 0.0f; S.cmd[k] = 0.0f; S.jv[k] = 0.0f; S.ln[k] = 0.0f; S.l1[k] = 0.0f; S.l2[k] = 0.0f; S.wt[k] = 0.0f;
@@ -274,15 +306,14 @@ __global__ __launch_bounds__(kBlock) void reset_kernel(DevConsts K, DevBuffers B
   const float g1 = K.gamma1_mode == OIS_GAMMA_CONST ? K.gamma1_const : 1.0f;
   const float g2 = K.gamma2_mode == OIS_GAMMA_CONST ? K.gamma2_const : 1.0f;
   ResetContrib rc;
-  reset_arena(K, K.arena_offset + la, g1, g2, S, rc);
+  reset_arena<1>(K, K.arena_offset + la, 0, g1, g2, S, rc);
   if (!valid) contrib_identity(rc);
   if ((lane & (kGroup - 1)) == 0 && valid) {  // clear the finished-episode accumulators of this group
     float* Acc = B.stat_acc + (size_t)(arena / kGroup) * 8;
     for (int k = 0; k < 4; ++k) { Acc[k] = 0.0f; Acc[4 + k] = -__builtin_inff(); }
   }
   const unsigned long long m = __ballot(valid);
-  const bool grp = ((m >> (lane & ~(kGroup - 1))) & 0xFFFFull) != 0ull;
-  group_record(B, arena / kGroup, lane, grp, rc, 0, false);
+  group_record<1>(B, arena / kGroup, lane, group_any<1>(m, lane), rc, 0, false);
   if (valid) {
     // params are owned by ois_create / ois_randomize_params: keep them
     B.pose[arena] = make_float4(S.p[0], S.p[1], S.p[2], S.vfwd);
@@ -506,6 +537,7 @@ struct ois_env {
   Layout L;
   char* ws;
   int N, device, grid;
+  int lpa;  // lanes per arena of the step kernel (1 | 2)
   uint64_t seed;  // seed of the last ois_reset (RNG key of the episode stream)
   bool reset_done;
   double steps_done;
@@ -588,6 +620,15 @@ int ois_create(const ois_config* cfg, int device, void* workspace_device, size_t
   e->N = cfg->num_envs;
   e->device = device;
   e->grid = (e->N + kBlock - 1) / kBlock;
+  {
+    // Lanes per arena. Measured on MI355X at 65 536 arenas: a lane pair per arena
+    // (2 waves per SIMD, 825 instr/lane-substep) runs a fused 20-step rollout in 51-53 us/step
+    // against 53-55 us for one lane per arena (1 wave per SIMD, 1494 instr), but a single-step
+    // launch in 80 us against 60 us. One lane per arena is the default; OIS_LANES_PER_ARENA=2
+    // selects the pair layout (both are bit-identical to the oracle and covered by the tests).
+    const char* w = getenv("OIS_LANES_PER_ARENA");
+    e->lpa = (w && w[0] == '2') ? 2 : 1;
+  }
   e->seed = cfg->seed;
   e->reset_done = false;
   e->steps_done = 0.0;
@@ -638,8 +679,13 @@ int ois_reset(ois_env* e, uint64_t seed, void* stream) {
 
 static int launch_steps(ois_env* e, int k, int policy, const float* actions, float* reward_sum, void* stream) {
   HIP_TRY(hipSetDevice(e->device));
-  hipLaunchKernelGGL(step_kernel, dim3(e->grid), dim3(kBlock), 0, (hipStream_t)stream, e->K, e->B, actions, reward_sum,
-                     e->N, k, policy);
+  if (e->lpa == 2) {
+    hipLaunchKernelGGL(step_kernel<2>, dim3((2 * e->N + kBlock - 1) / kBlock), dim3(kBlock), 0, (hipStream_t)stream, e->K,
+                       e->B, actions, reward_sum, e->N, k, policy);
+  } else {
+    hipLaunchKernelGGL(step_kernel<1>, dim3(e->grid), dim3(kBlock), 0, (hipStream_t)stream, e->K, e->B, actions,
+                       reward_sum, e->N, k, policy);
+  }
   HIP_TRY(hipGetLastError());
   e->steps_done += (double)e->N * (double)k;
   return OIS_OK;

@@ -1,26 +1,32 @@
-// ois_physics.h — one physics substep of one arena (docs/SPEC.md §3), executed by one lane.
+// ois_physics.h — one physics substep of one arena (docs/SPEC.md §3).
 //
 // Rigid chassis (6 DoF) + 4 wheel spins, 4 wheel-ground contact points on a plane, each with
 // a normal row and two Coulomb (box) friction rows; the longitudinal row couples the wheel
 // spin. Solver: mass-splitting Jacobi across the 4 contacts (each contact solves against a
 // private copy of the chassis velocity with 4x the inverse mass, the copies are averaged),
 // Gauss-Seidel across the 3 rows of a contact, 4 iterations, warm-started from the previous
-// substep's impulses. The 4 contacts are independent inside an iteration, so the fully
-// unrolled loop over k gives the SIMD four interleavable instruction streams.
+// substep's impulses.
+//
+// Written once for LPA = 1 (one lane owns all 4 contacts) and LPA = 2 (two lanes own the
+// left / right pair of contacts; cross-side sums are one DPP add). The contacts of a lane are
+// walked in LOCK-STEP (one dot-product / update stage for all of them before the next stage)
+// so that the in-order SIMD has independent instructions in flight.
 // Mirrors oracle/ois_oracle.c substep() operation for operation.
 #pragma once
 #include "ois_device.h"
 
 namespace ois {
 
-struct Phys {
+template <int LPA>
+struct PhysT {
+  static constexpr int WPL = 4 / LPA;
   float p[3], q[4], v[3];  // COM position, orientation (w,x,y,z), WORLD linear velocity
   float wb[3];             // BODY-frame angular velocity (constant between substeps, SPEC §3.2)
   float n[3], mu;          // ground plane normal (world), friction coefficient
-  float tau[4];            // clipped drive torques, wheel order fl, rl, fr, rr
-  float spin[4];           // absolute wheel spins about the body y axis
-  float ln[4], l1[4], l2[4];  // accumulated normal / longitudinal / lateral contact impulses
-  float mn[4], m1[4], m2[4], inv_s;  // reciprocal cache (SPEC §3.6), valid inside one policy step
+  float tau[WPL];          // clipped drive torques of this lane's wheels
+  float spin[WPL];         // absolute wheel spins about the body y axis
+  float ln[WPL], l1[WPL], l2[WPL];         // accumulated normal / longitudinal / lateral impulses
+  float mn[WPL], m1[WPL], m2[WPL], inv_s;  // reciprocal cache (SPEC §3.6), valid inside one policy step
 };
 
 // One Newton step from the previous substep's value: mul/fma only, bit-reproducible.
@@ -34,10 +40,17 @@ OIS_DEV float newton_rsqrt(float r, float s2) {  // r ~ 1/sqrt(s2) -> r (1.5 - 0
   return r * e;
 }
 
+// 0.25 * ((c0 + c1) + (c2 + c3)) over the per-contact copies of one velocity component
+template <int LPA>
+OIS_DEV float average4(const float (&c)[4 / LPA]) { return 0.25f * sum_wheels<LPA>(c); }
+
 // EXACT: first substep of a policy step (IEEE divisions); otherwise the reciprocals are
-// refreshed from the cache.
-template <bool EXACT>
-OIS_DEV void substep(const DevConsts& K, Phys& S) {
+// refreshed from the cache. wheel0 = index of this lane's first wheel (0, or 2 for the
+// right-side lane when LPA = 2).
+template <bool EXACT, int LPA>
+OIS_DEV void substep(const DevConsts& K, int wheel0, PhysT<LPA>& S) {
+  constexpr int W = 4 / LPA;
+#define OIS_WH _Pragma("unroll") for (int k = 0; k < W; ++k)
   float R[9];
   rotmat(S.q, R);
   float vb[3], nb[3], wb[3] = {S.wb[0], S.wb[1], S.wb[2]};
@@ -48,14 +61,13 @@ OIS_DEV void substep(const DevConsts& K, Phys& S) {
   vb[1] = __builtin_fmaf(-K.gdt, R[7], vb[1]);
   vb[2] = __builtin_fmaf(-K.gdt, R[8], vb[2]);
   // wheel drive + viscous joint damping, reaction on the chassis
-  float Tq[4];
-#pragma unroll
-  for (int k = 0; k < 4; ++k) {
+  float Tq[W];
+  OIS_WH {
     const float jv = S.spin[k] - wb[1];
     Tq[k] = __builtin_fmaf(-K.damping, jv, S.tau[k]);
     S.spin[k] = __builtin_fmaf(K.dt_over_Is, Tq[k], S.spin[k]);
   }
-  const float Tsum = (Tq[0] + Tq[1]) + (Tq[2] + Tq[3]);
+  const float Tsum = sum_wheels<LPA>(Tq);
   wb[1] = __builtin_fmaf(-K.dt_over_Iy, Tsum, wb[1]);
   // contact frame shared by the four wheels (common axle direction = body y)
   float s2 = __builtin_fmaf(nb[2], nb[2], nb[0] * nb[0]);
@@ -69,13 +81,13 @@ OIS_DEV void substep(const DevConsts& K, Phys& S) {
   const float t2z = -(nb[1] * t1x);
   const float np = __builtin_fmaf(S.n[2], S.p[2], __builtin_fmaf(S.n[1], S.p[1], S.n[0] * S.p[0]));
   const float cz = K.cz;
-  float b[4], an[4][3], a1[4][3], a2[4][3], Jan[4][3], Ja1[4][3], Ja2[4][3];
-  float (&mn)[4] = S.mn, (&m1)[4] = S.m1, (&m2)[4] = S.m2;
-#pragma unroll
-  for (int k = 0; k < 4; ++k) {
+  float b[W], an[W][3], a1[W][3], a2[W][3], Jan[W][3], Ja1[W][3], Ja2[W][3];
+  float (&mn)[W] = S.mn, (&m1)[W] = S.m1, (&m2)[W] = S.m2;
+  OIS_WH {
     // wheel centres relative to the COM, env order fl, rl, fr, rr (urdf:112-142: left = +y, front = +x)
-    const float cx = (k & 1) ? -K.wx : K.wx;
-    const float cy = (k & 2) ? -K.wy : K.wy;
+    const int gk = wheel0 + k;
+    const float cx = (k & 1) ? -K.wx : K.wx;  // wheel0 is even: parity of gk = parity of k
+    const float cy = (gk & 2) ? -K.wy : K.wy;
     const float rx = __builtin_fmaf(K.rw, dx, cx), ry = cy, rz = __builtin_fmaf(K.rw, dz, cz);
     const float gap = np + __builtin_fmaf(nb[2], rz, __builtin_fmaf(nb[1], ry, nb[0] * rx));
     b[k] = gap >= 0.0f ? -(gap * K.inv_dt) : fminf(-(gap * K.beta_inv_dt), K.vdep);
@@ -101,89 +113,72 @@ OIS_DEV void substep(const DevConsts& K, Phys& S) {
   const float vnx = K.im4 * nb[0], vny = K.im4 * nb[1], vnz = K.im4 * nb[2];
   const float v1x = K.im4 * t1x, v1z = K.im4 * t1z;
   const float v2x = K.im4 * t2x, v2y = K.im4 * t2y, v2z = K.im4 * t2z;
-  float vl[4][3], wl[4][3];
+  float vx[W], vy[W], vz[W], ox[W], oy[W], oz[W];
   // warm start: one mass-split averaging pass with the cached impulses
-#pragma unroll
-  for (int k = 0; k < 4; ++k) {
-    const float ln = S.ln[k], l1 = S.l1[k], l2 = S.l2[k];
-    vl[k][0] = __builtin_fmaf(l2, v2x, __builtin_fmaf(l1, v1x, __builtin_fmaf(ln, vnx, vb[0])));
-    vl[k][1] = __builtin_fmaf(l2, v2y, __builtin_fmaf(ln, vny, vb[1]));
-    vl[k][2] = __builtin_fmaf(l2, v2z, __builtin_fmaf(l1, v1z, __builtin_fmaf(ln, vnz, vb[2])));
-#pragma unroll
-    for (int j = 0; j < 3; ++j)
-      wl[k][j] = __builtin_fmaf(l2, Ja2[k][j], __builtin_fmaf(l1, Ja1[k][j], __builtin_fmaf(ln, Jan[k][j], wb[j])));
-    S.spin[k] = __builtin_fmaf(-K.rw_over_Is, l1, S.spin[k]);
-  }
-#pragma unroll
-  for (int j = 0; j < 3; ++j) {
-    vb[j] = 0.25f * ((vl[0][j] + vl[1][j]) + (vl[2][j] + vl[3][j]));
-    wb[j] = 0.25f * ((wl[0][j] + wl[1][j]) + (wl[2][j] + wl[3][j]));
-  }
-  // The 4 contacts are independent within an iteration. The source walks them in LOCK-STEP
-  // (one dot-product / update stage for all four wheels before the next stage) so that the
-  // in-order SIMD always has 4 independent instructions in flight: at 65 536 arenas there is
-  // only one wave per SIMD, and a single dependent fma chain issues every ~1.9 ns against
-  // ~1.3 ns for independent instructions (profiles/r1_valu_rate.txt).
-#define OIS_W4 _Pragma("unroll") for (int k = 0; k < 4; ++k)
+  OIS_WH vx[k] = __builtin_fmaf(S.l2[k], v2x, __builtin_fmaf(S.l1[k], v1x, __builtin_fmaf(S.ln[k], vnx, vb[0])));
+  OIS_WH vy[k] = __builtin_fmaf(S.l2[k], v2y, __builtin_fmaf(S.ln[k], vny, vb[1]));
+  OIS_WH vz[k] = __builtin_fmaf(S.l2[k], v2z, __builtin_fmaf(S.l1[k], v1z, __builtin_fmaf(S.ln[k], vnz, vb[2])));
+  OIS_WH ox[k] = __builtin_fmaf(S.l2[k], Ja2[k][0], __builtin_fmaf(S.l1[k], Ja1[k][0], __builtin_fmaf(S.ln[k], Jan[k][0], wb[0])));
+  OIS_WH oy[k] = __builtin_fmaf(S.l2[k], Ja2[k][1], __builtin_fmaf(S.l1[k], Ja1[k][1], __builtin_fmaf(S.ln[k], Jan[k][1], wb[1])));
+  OIS_WH oz[k] = __builtin_fmaf(S.l2[k], Ja2[k][2], __builtin_fmaf(S.l1[k], Ja1[k][2], __builtin_fmaf(S.ln[k], Jan[k][2], wb[2])));
+  OIS_WH S.spin[k] = __builtin_fmaf(-K.rw_over_Is, S.l1[k], S.spin[k]);
+  vb[0] = average4<LPA>(vx); vb[1] = average4<LPA>(vy); vb[2] = average4<LPA>(vz);
+  wb[0] = average4<LPA>(ox); wb[1] = average4<LPA>(oy); wb[2] = average4<LPA>(oz);
   for (int it = 0; it < K.iters; ++it) {
-    float vx[4], vy[4], vz[4], ox[4], oy[4], oz[4], u[4], dl[4], nw[4], lim[4];
+    float u[W], dl[W], nw[W], lim[W];
     // normal row
     const float unv = __builtin_fmaf(nb[2], vb[2], __builtin_fmaf(nb[1], vb[1], nb[0] * vb[0]));
-    OIS_W4 u[k] = __builtin_fmaf(an[k][0], wb[0], unv);
-    OIS_W4 u[k] = __builtin_fmaf(an[k][1], wb[1], u[k]);
-    OIS_W4 u[k] = __builtin_fmaf(an[k][2], wb[2], u[k]);
-    OIS_W4 dl[k] = (b[k] - u[k]) * mn[k];
-    OIS_W4 nw[k] = fmaxf(S.ln[k] + dl[k], 0.0f);
-    OIS_W4 dl[k] = nw[k] - S.ln[k];
-    OIS_W4 S.ln[k] = nw[k];
-    OIS_W4 vx[k] = __builtin_fmaf(dl[k], vnx, vb[0]);
-    OIS_W4 vz[k] = __builtin_fmaf(dl[k], vnz, vb[2]);
-    OIS_W4 ox[k] = __builtin_fmaf(dl[k], Jan[k][0], wb[0]);
-    OIS_W4 oy[k] = __builtin_fmaf(dl[k], Jan[k][1], wb[1]);
-    OIS_W4 oz[k] = __builtin_fmaf(dl[k], Jan[k][2], wb[2]);
-    OIS_W4 vy[k] = __builtin_fmaf(dl[k], vny, vb[1]);
-    OIS_W4 lim[k] = S.mu * S.ln[k];
+    OIS_WH u[k] = __builtin_fmaf(an[k][0], wb[0], unv);
+    OIS_WH u[k] = __builtin_fmaf(an[k][1], wb[1], u[k]);
+    OIS_WH u[k] = __builtin_fmaf(an[k][2], wb[2], u[k]);
+    OIS_WH dl[k] = (b[k] - u[k]) * mn[k];
+    OIS_WH nw[k] = fmaxf(S.ln[k] + dl[k], 0.0f);
+    OIS_WH dl[k] = nw[k] - S.ln[k];
+    OIS_WH S.ln[k] = nw[k];
+    OIS_WH vx[k] = __builtin_fmaf(dl[k], vnx, vb[0]);
+    OIS_WH vz[k] = __builtin_fmaf(dl[k], vnz, vb[2]);
+    OIS_WH ox[k] = __builtin_fmaf(dl[k], Jan[k][0], wb[0]);
+    OIS_WH oy[k] = __builtin_fmaf(dl[k], Jan[k][1], wb[1]);
+    OIS_WH oz[k] = __builtin_fmaf(dl[k], Jan[k][2], wb[2]);
+    OIS_WH vy[k] = __builtin_fmaf(dl[k], vny, vb[1]);
+    OIS_WH lim[k] = S.mu * S.ln[k];
     // longitudinal row (couples the wheel spin)
-    OIS_W4 u[k] = t1x * vx[k];
-    OIS_W4 u[k] = __builtin_fmaf(t1z, vz[k], u[k]);
-    OIS_W4 u[k] = __builtin_fmaf(a1[k][0], ox[k], u[k]);
-    OIS_W4 u[k] = __builtin_fmaf(a1[k][1], oy[k], u[k]);
-    OIS_W4 u[k] = __builtin_fmaf(a1[k][2], oz[k], u[k]);
-    OIS_W4 u[k] = __builtin_fmaf(-K.rw, S.spin[k], u[k]);
-    OIS_W4 dl[k] = -(u[k] * m1[k]);
-    OIS_W4 nw[k] = fminf(fmaxf(S.l1[k] + dl[k], -lim[k]), lim[k]);
-    OIS_W4 dl[k] = nw[k] - S.l1[k];
-    OIS_W4 S.l1[k] = nw[k];
-    OIS_W4 vx[k] = __builtin_fmaf(dl[k], v1x, vx[k]);
-    OIS_W4 vz[k] = __builtin_fmaf(dl[k], v1z, vz[k]);
-    OIS_W4 ox[k] = __builtin_fmaf(dl[k], Ja1[k][0], ox[k]);
-    OIS_W4 oy[k] = __builtin_fmaf(dl[k], Ja1[k][1], oy[k]);
-    OIS_W4 oz[k] = __builtin_fmaf(dl[k], Ja1[k][2], oz[k]);
-    OIS_W4 S.spin[k] = __builtin_fmaf(-K.rw_over_Is, dl[k], S.spin[k]);
+    OIS_WH u[k] = t1x * vx[k];
+    OIS_WH u[k] = __builtin_fmaf(t1z, vz[k], u[k]);
+    OIS_WH u[k] = __builtin_fmaf(a1[k][0], ox[k], u[k]);
+    OIS_WH u[k] = __builtin_fmaf(a1[k][1], oy[k], u[k]);
+    OIS_WH u[k] = __builtin_fmaf(a1[k][2], oz[k], u[k]);
+    OIS_WH u[k] = __builtin_fmaf(-K.rw, S.spin[k], u[k]);
+    OIS_WH dl[k] = -(u[k] * m1[k]);
+    OIS_WH nw[k] = fminf(fmaxf(S.l1[k] + dl[k], -lim[k]), lim[k]);
+    OIS_WH dl[k] = nw[k] - S.l1[k];
+    OIS_WH S.l1[k] = nw[k];
+    OIS_WH vx[k] = __builtin_fmaf(dl[k], v1x, vx[k]);
+    OIS_WH vz[k] = __builtin_fmaf(dl[k], v1z, vz[k]);
+    OIS_WH ox[k] = __builtin_fmaf(dl[k], Ja1[k][0], ox[k]);
+    OIS_WH oy[k] = __builtin_fmaf(dl[k], Ja1[k][1], oy[k]);
+    OIS_WH oz[k] = __builtin_fmaf(dl[k], Ja1[k][2], oz[k]);
+    OIS_WH S.spin[k] = __builtin_fmaf(-K.rw_over_Is, dl[k], S.spin[k]);
     // lateral row
-    OIS_W4 u[k] = t2x * vx[k];
-    OIS_W4 u[k] = __builtin_fmaf(t2y, vy[k], u[k]);
-    OIS_W4 u[k] = __builtin_fmaf(t2z, vz[k], u[k]);
-    OIS_W4 u[k] = __builtin_fmaf(a2[k][0], ox[k], u[k]);
-    OIS_W4 u[k] = __builtin_fmaf(a2[k][1], oy[k], u[k]);
-    OIS_W4 u[k] = __builtin_fmaf(a2[k][2], oz[k], u[k]);
-    OIS_W4 dl[k] = -(u[k] * m2[k]);
-    OIS_W4 nw[k] = fminf(fmaxf(S.l2[k] + dl[k], -lim[k]), lim[k]);
-    OIS_W4 dl[k] = nw[k] - S.l2[k];
-    OIS_W4 S.l2[k] = nw[k];
-    OIS_W4 vl[k][0] = __builtin_fmaf(dl[k], v2x, vx[k]);
-    OIS_W4 vl[k][1] = __builtin_fmaf(dl[k], v2y, vy[k]);
-    OIS_W4 vl[k][2] = __builtin_fmaf(dl[k], v2z, vz[k]);
-    OIS_W4 wl[k][0] = __builtin_fmaf(dl[k], Ja2[k][0], ox[k]);
-    OIS_W4 wl[k][1] = __builtin_fmaf(dl[k], Ja2[k][1], oy[k]);
-    OIS_W4 wl[k][2] = __builtin_fmaf(dl[k], Ja2[k][2], oz[k]);
-#undef OIS_W4
+    OIS_WH u[k] = t2x * vx[k];
+    OIS_WH u[k] = __builtin_fmaf(t2y, vy[k], u[k]);
+    OIS_WH u[k] = __builtin_fmaf(t2z, vz[k], u[k]);
+    OIS_WH u[k] = __builtin_fmaf(a2[k][0], ox[k], u[k]);
+    OIS_WH u[k] = __builtin_fmaf(a2[k][1], oy[k], u[k]);
+    OIS_WH u[k] = __builtin_fmaf(a2[k][2], oz[k], u[k]);
+    OIS_WH dl[k] = -(u[k] * m2[k]);
+    OIS_WH nw[k] = fminf(fmaxf(S.l2[k] + dl[k], -lim[k]), lim[k]);
+    OIS_WH dl[k] = nw[k] - S.l2[k];
+    OIS_WH S.l2[k] = nw[k];
+    OIS_WH vx[k] = __builtin_fmaf(dl[k], v2x, vx[k]);
+    OIS_WH vy[k] = __builtin_fmaf(dl[k], v2y, vy[k]);
+    OIS_WH vz[k] = __builtin_fmaf(dl[k], v2z, vz[k]);
+    OIS_WH ox[k] = __builtin_fmaf(dl[k], Ja2[k][0], ox[k]);
+    OIS_WH oy[k] = __builtin_fmaf(dl[k], Ja2[k][1], oy[k]);
+    OIS_WH oz[k] = __builtin_fmaf(dl[k], Ja2[k][2], oz[k]);
     // mass-splitting average over the 4 contacts
-#pragma unroll
-    for (int j = 0; j < 3; ++j) {
-      vb[j] = 0.25f * ((vl[0][j] + vl[1][j]) + (vl[2][j] + vl[3][j]));
-      wb[j] = 0.25f * ((wl[0][j] + wl[1][j]) + (wl[2][j] + wl[3][j]));
-    }
+    vb[0] = average4<LPA>(vx); vb[1] = average4<LPA>(vy); vb[2] = average4<LPA>(vz);
+    wb[0] = average4<LPA>(ox); wb[1] = average4<LPA>(oy); wb[2] = average4<LPA>(oz);
   }
   // linear velocity back to the world frame, velocity caps (origin_v18.py:65-70), integrate
   rot(R, vb, S.v);
@@ -193,8 +188,7 @@ OIS_DEV void substep(const DevConsts& K, Phys& S) {
     wb[0] *= sc; wb[1] *= sc; wb[2] *= sc;
   }
   S.wb[0] = wb[0]; S.wb[1] = wb[1]; S.wb[2] = wb[2];
-#pragma unroll
-  for (int k = 0; k < 4; ++k) S.spin[k] = fminf(fmaxf(S.spin[k], -K.maxw), K.maxw);
+  OIS_WH S.spin[k] = fminf(fmaxf(S.spin[k], -K.maxw), K.maxw);
   S.p[0] = __builtin_fmaf(K.dt, S.v[0], S.p[0]);
   S.p[1] = __builtin_fmaf(K.dt, S.v[1], S.p[1]);
   S.p[2] = __builtin_fmaf(K.dt, S.v[2], S.p[2]);
@@ -210,6 +204,7 @@ OIS_DEV void substep(const DevConsts& K, Phys& S) {
   float inv = __builtin_fmaf(-0.5f, nn, 1.5f);
   if (fabsf(nn - 1.0f) > 1e-3f) inv = 1.0f / sqrtf(nn);
   S.q[0] = nqw * inv; S.q[1] = nqx * inv; S.q[2] = nqy * inv; S.q[3] = nqz * inv;
+#undef OIS_WH
 }
 
 }  // namespace ois
