@@ -15,7 +15,7 @@
 #include <cstring>
 #include <new>
 
-#include "ois_physics.h"
+#include "ois_physics_pk.h"
 
 using namespace ois;
 
@@ -86,7 +86,7 @@ OIS_DEV void store_arena(const DevConsts& K, const DevBuffers& B, int i, int h, 
 }
 
 // ------------------------------------------------------------------ the step kernel ---
-template <int LPA>
+template <int LPA, bool PK>
 __global__ OIS_STEP_BOUNDS void step_kernel(DevConsts K, DevBuffers B, const float* __restrict__ actions,
                                                       float* __restrict__ reward_sum, int N, int ksteps, int policy) {
   constexpr int W = 4 / LPA;
@@ -193,8 +193,13 @@ __global__ OIS_STEP_BOUNDS void step_kernel(DevConsts K, DevBuffers B, const flo
         X.ln[k] = S.ln[k]; X.l1[k] = S.l1[k]; X.l2[k] = S.l2[k];
       }
       X.mu = S.mu;
-      substep<true, LPA>(K, wheel0, X);
-      for (int i = 1; i < K.nsub; ++i) substep<false, LPA>(K, wheel0, X);
+      if constexpr (PK && LPA == 1) {  // packed fp32 over wheel pairs (ois_physics_pk.h)
+        substep_pk<true>(K, X);
+        for (int i = 1; i < K.nsub; ++i) substep_pk<false>(K, X);
+      } else {
+        substep<true, LPA>(K, wheel0, X);
+        for (int i = 1; i < K.nsub; ++i) substep<false, LPA>(K, wheel0, X);
+      }
       rotmat(X.q, R);
       rot(R, X.wb, S.w);  // body -> world with the final orientation
 #pragma unroll
@@ -538,6 +543,7 @@ struct ois_env {
   char* ws;
   int N, device, grid;
   int lpa;  // lanes per arena of the step kernel (1 | 2)
+  bool packed;  // LPA = 1 only: per-wheel math on v_pk_*_f32 (ois_physics_pk.h)
   uint64_t seed;  // seed of the last ois_reset (RNG key of the episode stream)
   bool reset_done;
   double steps_done;
@@ -628,6 +634,13 @@ int ois_create(const ois_config* cfg, int device, void* workspace_device, size_t
     // selects the pair layout (both are bit-identical to the oracle and covered by the tests).
     const char* w = getenv("OIS_LANES_PER_ARENA");
     e->lpa = (w && w[0] == '2') ? 2 : 1;
+    // Packed fp32 over wheel pairs pays exactly while every SIMD holds at most one wave
+    // (measured: 44 vs 55 us/step at 65 536 arenas, 80 vs 67 us at 81 920): a lone wave issues
+    // a v_pk_fma_f32 as fast as a v_fma_f32, two co-resident waves do not.
+    int cus = 0;
+    if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device) != hipSuccess || cus <= 0) cus = 256;
+    const char* pk = getenv("OIS_PACKED");
+    e->packed = pk ? (pk[0] == '1') : (e->grid <= 4 * cus);
   }
   e->seed = cfg->seed;
   e->reset_done = false;
@@ -680,10 +693,13 @@ int ois_reset(ois_env* e, uint64_t seed, void* stream) {
 static int launch_steps(ois_env* e, int k, int policy, const float* actions, float* reward_sum, void* stream) {
   HIP_TRY(hipSetDevice(e->device));
   if (e->lpa == 2) {
-    hipLaunchKernelGGL(step_kernel<2>, dim3((2 * e->N + kBlock - 1) / kBlock), dim3(kBlock), 0, (hipStream_t)stream, e->K,
-                       e->B, actions, reward_sum, e->N, k, policy);
+    hipLaunchKernelGGL((step_kernel<2, false>), dim3((2 * e->N + kBlock - 1) / kBlock), dim3(kBlock), 0,
+                       (hipStream_t)stream, e->K, e->B, actions, reward_sum, e->N, k, policy);
+  } else if (e->packed) {
+    hipLaunchKernelGGL((step_kernel<1, true>), dim3(e->grid), dim3(kBlock), 0, (hipStream_t)stream, e->K, e->B, actions,
+                       reward_sum, e->N, k, policy);
   } else {
-    hipLaunchKernelGGL(step_kernel<1>, dim3(e->grid), dim3(kBlock), 0, (hipStream_t)stream, e->K, e->B, actions,
+    hipLaunchKernelGGL((step_kernel<1, false>), dim3(e->grid), dim3(kBlock), 0, (hipStream_t)stream, e->K, e->B, actions,
                        reward_sum, e->N, k, policy);
   }
   HIP_TRY(hipGetLastError());

@@ -1,0 +1,219 @@
+// ois_physics_pk.h — the LPA = 1 substep with the per-wheel math on PACKED fp32.
+//
+// Same operations in the same order as substep<EXACT, 1> (ois_physics.h), so the results are
+// bit-identical; only the instruction selection differs: the wheels of an axle — (fl, fr) and (rl, rr) — ride
+// in the two halves of float2 operands, which hipcc lowers to v_pk_fma_f32 / v_pk_mul_f32 /
+// v_pk_add_f32 (IEEE per element). Why it pays in THIS regime only: at 65 536 arenas there is
+// one wave per SIMD, and a lone wave issues one VALU instruction per ~4 cycles whether it is
+// a v_fma_f32 or a v_pk_fma_f32 (tools/valu_rate.hip: 2.0-2.4 ns vs 2.5 ns), so a packed
+// instruction does two wheels for the price of one. With two or more waves per SIMD the
+// scalar rate doubles and packing buys nothing (measured earlier in the 4-lanes-per-arena
+// layout), hence the scalar path is kept for large N.
+#pragma once
+#include "ois_physics.h"
+
+namespace ois {
+
+typedef float f2 __attribute__((ext_vector_type(2)));
+
+OIS_DEV f2 fma2(f2 a, f2 b, f2 c) { return __builtin_elementwise_fma(a, b, c); }
+OIS_DEV f2 fma2(float a, f2 b, f2 c) { return __builtin_elementwise_fma((f2)(a), b, c); }
+OIS_DEV f2 fma2(f2 a, float b, f2 c) { return __builtin_elementwise_fma(a, (f2)(b), c); }
+OIS_DEV f2 fma2(f2 a, f2 b, float c) { return __builtin_elementwise_fma(a, b, (f2)(c)); }
+OIS_DEV f2 fma2(f2 a, float b, float c) { return __builtin_elementwise_fma(a, (f2)(b), (f2)(c)); }
+OIS_DEV f2 fma2(float a, f2 b, float c) { return __builtin_elementwise_fma((f2)(a), b, (f2)(c)); }
+OIS_DEV f2 max2(f2 a, f2 b) { f2 r; r.x = fmaxf(a.x, b.x); r.y = fmaxf(a.y, b.y); return r; }
+OIS_DEV f2 min2(f2 a, f2 b) { f2 r; r.x = fminf(a.x, b.x); r.y = fminf(a.y, b.y); return r; }
+// pair j = wheels (j, j + 2): j = 0 front (fl, fr), j = 1 rear (rl, rr). With this pairing the
+// SPEC's wheel sum (w0 + w1) + (w2 + w3) is one packed add {w0 + w1, w2 + w3} and one scalar add.
+OIS_DEV f2 ld2(const float* p) { f2 r; r.x = p[0]; r.y = p[2]; return r; }
+OIS_DEV void st2(float* p, f2 v) { p[0] = v.x; p[2] = v.y; }
+OIS_DEV float sum4(const f2 (&c)[2]) { const f2 s = c[0] + c[1]; return s.x + s.y; }
+// clamp(x, -lim, lim) with lim >= 0: one v_med3_f32 instead of v_max + v_min (same value for
+// every non-NaN input)
+OIS_DEV f2 clamp2(f2 x, f2 lim) {
+  f2 r;
+  r.x = __builtin_amdgcn_fmed3f(x.x, -lim.x, lim.x);
+  r.y = __builtin_amdgcn_fmed3f(x.y, -lim.y, lim.y);
+  return r;
+}
+OIS_DEV f2 newton_rcp2(f2 m, f2 k) {
+  const f2 e = fma2(-k, m, 1.0f);
+  return fma2(m, e, m);
+}
+
+template <bool EXACT>
+OIS_DEV void substep_pk(const DevConsts& K, PhysT<1>& S) {
+#define OIS_PR _Pragma("unroll") for (int j = 0; j < 2; ++j)
+  float R[9];
+  rotmat(S.q, R);
+  float vb[3], nb[3], wb[3] = {S.wb[0], S.wb[1], S.wb[2]};
+  rotT(R, S.v, vb);
+  rotT(R, S.n, nb);
+  vb[0] = __builtin_fmaf(-K.gdt, R[6], vb[0]);
+  vb[1] = __builtin_fmaf(-K.gdt, R[7], vb[1]);
+  vb[2] = __builtin_fmaf(-K.gdt, R[8], vb[2]);
+  f2 spin[2], tau[2], ln[2], l1[2], l2[2], mn[2], m1[2], m2[2];
+  OIS_PR {
+    spin[j] = ld2(&S.spin[j]); tau[j] = ld2(&S.tau[j]);
+    ln[j] = ld2(&S.ln[j]); l1[j] = ld2(&S.l1[j]); l2[j] = ld2(&S.l2[j]);
+    mn[j] = ld2(&S.mn[j]); m1[j] = ld2(&S.m1[j]); m2[j] = ld2(&S.m2[j]);
+  }
+  // wheel drive + viscous joint damping, reaction on the chassis
+  f2 Tq[2];
+  OIS_PR {
+    const f2 jv = spin[j] - wb[1];
+    Tq[j] = fma2(-K.damping, jv, tau[j]);
+    spin[j] = fma2(K.dt_over_Is, Tq[j], spin[j]);
+  }
+  const float Tsum = sum4(Tq);
+  wb[1] = __builtin_fmaf(-K.dt_over_Iy, Tsum, wb[1]);
+  // contact frame shared by the four wheels (common axle direction = body y)
+  float s2 = __builtin_fmaf(nb[2], nb[2], nb[0] * nb[0]);
+  s2 = fmaxf(s2, 1e-12f);
+  const float inv_s = EXACT ? 1.0f / sqrtf(s2) : newton_rsqrt(S.inv_s, s2);
+  S.inv_s = inv_s;
+  const float dx = -(nb[0] * inv_s), dz = -(nb[2] * inv_s);
+  const float t1x = -dz, t1z = dx;
+  const float t2x = nb[1] * t1z;
+  const float t2y = __builtin_fmaf(nb[2], t1x, -(nb[0] * t1z));
+  const float t2z = -(nb[1] * t1x);
+  const float np = __builtin_fmaf(S.n[2], S.p[2], __builtin_fmaf(S.n[1], S.p[1], S.n[0] * S.p[0]));
+  const float cz = K.cz;
+  const f2 cy = {K.wy, -K.wy};  // (left, right) wheel of each axle (urdf:112-142: left = +y)
+  const f2 ry = cy;
+  const float rz = __builtin_fmaf(K.rw, dz, cz);
+  f2 b[2], an[2][3], a1[2][3], a2[2][3], Jan[2][3], Ja1[2][3], Ja2[2][3];
+  OIS_PR {
+    const float cx = j ? -K.wx : K.wx;  // front axle +x, rear axle -x
+    const float rx = __builtin_fmaf(K.rw, dx, cx);
+    // gap = np + fma(nb2, rz, fma(nb1, ry, nb0 * rx))
+    const f2 gap = np + fma2(nb[2], (f2)(rz), fma2(nb[1], ry, nb[0] * rx));
+    f2 bb;
+    bb.x = gap.x >= 0.0f ? -(gap.x * K.inv_dt) : fminf(-(gap.x * K.beta_inv_dt), K.vdep);
+    bb.y = gap.y >= 0.0f ? -(gap.y * K.inv_dt) : fminf(-(gap.y * K.beta_inv_dt), K.vdep);
+    b[j] = bb;
+    an[j][0] = fma2(ry, nb[2], -(rz * nb[1]));
+    an[j][1] = (f2)(__builtin_fmaf(rz, nb[0], -(rx * nb[2])));
+    an[j][2] = fma2(rx, (f2)(nb[1]), -(ry * nb[0]));
+    a1[j][0] = cy * t1z;
+    a1[j][1] = (f2)(__builtin_fmaf(cz, t1x, -(cx * t1z)));
+    a1[j][2] = -(cy * t1x);
+    a2[j][0] = fma2(ry, t2z, -(rz * t2y));
+    a2[j][1] = (f2)(__builtin_fmaf(rz, t2x, -(rx * t2z)));
+    a2[j][2] = fma2(rx, (f2)(t2y), -(ry * t2x));
+    Jan[j][0] = K.J4x * an[j][0]; Jan[j][1] = K.J4y * an[j][1]; Jan[j][2] = K.J4z * an[j][2];
+    Ja1[j][0] = K.J4x * a1[j][0]; Ja1[j][1] = K.J4y * a1[j][1]; Ja1[j][2] = K.J4z * a1[j][2];
+    Ja2[j][0] = K.J4x * a2[j][0]; Ja2[j][1] = K.J4y * a2[j][1]; Ja2[j][2] = K.J4z * a2[j][2];
+    const f2 kn = fma2(an[j][2], Jan[j][2], fma2(an[j][1], Jan[j][1], fma2(an[j][0], Jan[j][0], K.im4)));
+    const f2 k1 = fma2(a1[j][2], Ja1[j][2], fma2(a1[j][1], Ja1[j][1], fma2(a1[j][0], Ja1[j][0], K.im4))) + K.rw2_over_Is;
+    const f2 k2 = fma2(a2[j][2], Ja2[j][2], fma2(a2[j][1], Ja2[j][1], fma2(a2[j][0], Ja2[j][0], K.im4)));
+    if (EXACT) {
+      mn[j].x = 1.0f / kn.x; mn[j].y = 1.0f / kn.y;
+      m1[j].x = 1.0f / k1.x; m1[j].y = 1.0f / k1.y;
+      m2[j].x = 1.0f / k2.x; m2[j].y = 1.0f / k2.y;
+    } else {
+      mn[j] = newton_rcp2(mn[j], kn);
+      m1[j] = newton_rcp2(m1[j], k1);
+      m2[j] = newton_rcp2(m2[j], k2);
+    }
+  }
+  const float vnx = K.im4 * nb[0], vny = K.im4 * nb[1], vnz = K.im4 * nb[2];
+  const float v1x = K.im4 * t1x, v1z = K.im4 * t1z;
+  const float v2x = K.im4 * t2x, v2y = K.im4 * t2y, v2z = K.im4 * t2z;
+  f2 vx[2], vy[2], vz[2], ox[2], oy[2], oz[2];
+  // warm start: one mass-split averaging pass with the cached impulses
+  OIS_PR vx[j] = fma2(l2[j], v2x, fma2(l1[j], v1x, fma2(ln[j], vnx, vb[0])));
+  OIS_PR vy[j] = fma2(l2[j], v2y, fma2(ln[j], vny, vb[1]));
+  OIS_PR vz[j] = fma2(l2[j], v2z, fma2(l1[j], v1z, fma2(ln[j], vnz, vb[2])));
+  OIS_PR ox[j] = fma2(l2[j], Ja2[j][0], fma2(l1[j], Ja1[j][0], fma2(ln[j], Jan[j][0], wb[0])));
+  OIS_PR oy[j] = fma2(l2[j], Ja2[j][1], fma2(l1[j], Ja1[j][1], fma2(ln[j], Jan[j][1], wb[1])));
+  OIS_PR oz[j] = fma2(l2[j], Ja2[j][2], fma2(l1[j], Ja1[j][2], fma2(ln[j], Jan[j][2], wb[2])));
+  OIS_PR spin[j] = fma2(-K.rw_over_Is, l1[j], spin[j]);
+  vb[0] = 0.25f * sum4(vx); vb[1] = 0.25f * sum4(vy); vb[2] = 0.25f * sum4(vz);
+  wb[0] = 0.25f * sum4(ox); wb[1] = 0.25f * sum4(oy); wb[2] = 0.25f * sum4(oz);
+  for (int it = 0; it < K.iters; ++it) {
+    f2 u[2], dl[2], nw[2], lim[2];
+    // normal row
+    const float unv = __builtin_fmaf(nb[2], vb[2], __builtin_fmaf(nb[1], vb[1], nb[0] * vb[0]));
+    OIS_PR u[j] = fma2(an[j][0], wb[0], unv);
+    OIS_PR u[j] = fma2(an[j][1], wb[1], u[j]);
+    OIS_PR u[j] = fma2(an[j][2], wb[2], u[j]);
+    OIS_PR dl[j] = (b[j] - u[j]) * mn[j];
+    OIS_PR nw[j] = max2(ln[j] + dl[j], (f2)(0.0f));
+    OIS_PR dl[j] = nw[j] - ln[j];
+    OIS_PR ln[j] = nw[j];
+    OIS_PR vx[j] = fma2(dl[j], vnx, vb[0]);
+    OIS_PR vz[j] = fma2(dl[j], vnz, vb[2]);
+    OIS_PR ox[j] = fma2(dl[j], Jan[j][0], wb[0]);
+    OIS_PR oy[j] = fma2(dl[j], Jan[j][1], wb[1]);
+    OIS_PR oz[j] = fma2(dl[j], Jan[j][2], wb[2]);
+    OIS_PR vy[j] = fma2(dl[j], vny, vb[1]);
+    OIS_PR lim[j] = S.mu * ln[j];
+    // longitudinal row (couples the wheel spin)
+    OIS_PR u[j] = t1x * vx[j];
+    OIS_PR u[j] = fma2(t1z, vz[j], u[j]);
+    OIS_PR u[j] = fma2(a1[j][0], ox[j], u[j]);
+    OIS_PR u[j] = fma2(a1[j][1], oy[j], u[j]);
+    OIS_PR u[j] = fma2(a1[j][2], oz[j], u[j]);
+    OIS_PR u[j] = fma2(-K.rw, spin[j], u[j]);
+    OIS_PR dl[j] = -(u[j] * m1[j]);
+    OIS_PR nw[j] = clamp2(l1[j] + dl[j], lim[j]);
+    OIS_PR dl[j] = nw[j] - l1[j];
+    OIS_PR l1[j] = nw[j];
+    OIS_PR vx[j] = fma2(dl[j], v1x, vx[j]);
+    OIS_PR vz[j] = fma2(dl[j], v1z, vz[j]);
+    OIS_PR ox[j] = fma2(dl[j], Ja1[j][0], ox[j]);
+    OIS_PR oy[j] = fma2(dl[j], Ja1[j][1], oy[j]);
+    OIS_PR oz[j] = fma2(dl[j], Ja1[j][2], oz[j]);
+    OIS_PR spin[j] = fma2(-K.rw_over_Is, dl[j], spin[j]);
+    // lateral row
+    OIS_PR u[j] = t2x * vx[j];
+    OIS_PR u[j] = fma2(t2y, vy[j], u[j]);
+    OIS_PR u[j] = fma2(t2z, vz[j], u[j]);
+    OIS_PR u[j] = fma2(a2[j][0], ox[j], u[j]);
+    OIS_PR u[j] = fma2(a2[j][1], oy[j], u[j]);
+    OIS_PR u[j] = fma2(a2[j][2], oz[j], u[j]);
+    OIS_PR dl[j] = -(u[j] * m2[j]);
+    OIS_PR nw[j] = clamp2(l2[j] + dl[j], lim[j]);
+    OIS_PR dl[j] = nw[j] - l2[j];
+    OIS_PR l2[j] = nw[j];
+    OIS_PR vx[j] = fma2(dl[j], v2x, vx[j]);
+    OIS_PR vy[j] = fma2(dl[j], v2y, vy[j]);
+    OIS_PR vz[j] = fma2(dl[j], v2z, vz[j]);
+    OIS_PR ox[j] = fma2(dl[j], Ja2[j][0], ox[j]);
+    OIS_PR oy[j] = fma2(dl[j], Ja2[j][1], oy[j]);
+    OIS_PR oz[j] = fma2(dl[j], Ja2[j][2], oz[j]);
+    // mass-splitting average over the 4 contacts
+    vb[0] = 0.25f * sum4(vx); vb[1] = 0.25f * sum4(vy); vb[2] = 0.25f * sum4(vz);
+    wb[0] = 0.25f * sum4(ox); wb[1] = 0.25f * sum4(oy); wb[2] = 0.25f * sum4(oz);
+  }
+  OIS_PR {
+    st2(&S.spin[j], clamp2(spin[j], (f2)(K.maxw)));
+    st2(&S.ln[j], ln[j]); st2(&S.l1[j], l1[j]); st2(&S.l2[j], l2[j]);
+    st2(&S.mn[j], mn[j]); st2(&S.m1[j], m1[j]); st2(&S.m2[j], m2[j]);
+  }
+  // linear velocity back to the world frame, velocity caps (origin_v18.py:65-70), integrate
+  rot(R, vb, S.v);
+  const float w2 = __builtin_fmaf(wb[2], wb[2], __builtin_fmaf(wb[1], wb[1], wb[0] * wb[0]));
+  if (w2 > K.maxw2) {
+    const float sc = K.maxw / sqrtf(w2);
+    wb[0] *= sc; wb[1] *= sc; wb[2] *= sc;
+  }
+  S.wb[0] = wb[0]; S.wb[1] = wb[1]; S.wb[2] = wb[2];
+  S.p[0] = __builtin_fmaf(K.dt, S.v[0], S.p[0]);
+  S.p[1] = __builtin_fmaf(K.dt, S.v[1], S.p[1]);
+  S.p[2] = __builtin_fmaf(K.dt, S.v[2], S.p[2]);
+  const float qw = S.q[0], qx = S.q[1], qy = S.q[2], qz = S.q[3], h = K.half_dt;
+  const float nqw = __builtin_fmaf(-h, __builtin_fmaf(qz, wb[2], __builtin_fmaf(qy, wb[1], qx * wb[0])), qw);
+  const float nqx = __builtin_fmaf(h, __builtin_fmaf(-qz, wb[1], __builtin_fmaf(qy, wb[2], qw * wb[0])), qx);
+  const float nqy = __builtin_fmaf(h, __builtin_fmaf(-qx, wb[2], __builtin_fmaf(qz, wb[0], qw * wb[1])), qy);
+  const float nqz = __builtin_fmaf(h, __builtin_fmaf(-qy, wb[0], __builtin_fmaf(qx, wb[1], qw * wb[2])), qz);
+  const float nn = __builtin_fmaf(nqz, nqz, __builtin_fmaf(nqy, nqy, __builtin_fmaf(nqx, nqx, nqw * nqw)));
+  float inv = __builtin_fmaf(-0.5f, nn, 1.5f);
+  if (fabsf(nn - 1.0f) > 1e-3f) inv = 1.0f / sqrtf(nn);
+  S.q[0] = nqw * inv; S.q[1] = nqx * inv; S.q[2] = nqy * inv; S.q[3] = nqz * inv;
+#undef OIS_PR
+}
+
+}  // namespace ois
