@@ -100,9 +100,12 @@ VARIANTS: Dict[str, Dict[str, Any]] = {
     # KAMMA_g1d_g21.py:628: gamma2 line commented
     "KAMMA_g1d_g21": dict(action_dim=4, action_low=0.0, mix_mode=A.MIX_SWITCH, max_sim_steps=500000.0,
                           gamma2_mode=A.GAMMA_CONST, gamma2_const=1.0),
-    # KAMMA_curr1.py:56-57, 577-598
-    "KAMMA_curr1": dict(action_dim=4, action_low=0.0, mix_mode=A.MIX_SWITCH, max_sim_steps=400000.0,
+    # KAMMA_curr1.py:56-57, 179, 577-598
+    "KAMMA_curr1": dict(action_dim=4, action_low=0.0, mix_mode=A.MIX_SWITCH, max_sim_steps=500000.0,
                         cmd_sampler=A.CMD_BOX),
+    # KAMMA_curr2.py:57-58, 179, 602-640
+    "KAMMA_curr2": dict(action_dim=4, action_low=0.0, mix_mode=A.MIX_SWITCH, max_sim_steps=500000.0,
+                        cmd_sampler=A.CMD_GRID),
     # KAMMA_eval.py:180, 193-194, 545-550, 646-647, 677-685
     "KAMMA_eval": dict(action_dim=4, action_low=0.0, mix_mode=A.MIX_SWITCH, max_sim_steps=50000.0,
                        gamma1_mode=A.GAMMA_CONST, gamma1_const=0.0,
@@ -185,6 +188,8 @@ def build_config(task_cfg: Optional[Dict[str, Any]] = None, variant: str = "KAMM
     terrain = env.get("terrain", {})
     if terrain.get("BoxSampling") and not terrain.get("RandSampling", True):
         c.cmd_sampler = _abi.CMD_BOX
+    if terrain.get("GridSampling") and not terrain.get("RandSampling", True) and not terrain.get("BoxSampling"):
+        c.cmd_sampler = _abi.CMD_GRID
     if terrain.get("EvalSampling"):
         c.cmd_sampler = _abi.CMD_EVAL
     for k, v in var.items():

@@ -79,7 +79,7 @@ OIS_DEV void philox4x32_10(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, u
   o[0] = c0; o[1] = c1; o[2] = c2; o[3] = c3;
 }
 OIS_DEV float u01(uint32_t x) { return (float)(x >> 8) * 5.9604644775390625e-08f; }
-enum { PURPOSE_MASK = 0, PURPOSE_RESET_A = 1, PURPOSE_RESET_B = 2, PURPOSE_ACTION = 3, PURPOSE_PARAMS = 4 };
+enum { PURPOSE_MASK = 0, PURPOSE_RESET_A = 1, PURPOSE_RESET_B = 2, PURPOSE_ACTION = 3, PURPOSE_PARAMS = 4, PURPOSE_RESET_C = 5 };
 OIS_DEV void draw4(const DevConsts& K, int64_t gid, uint32_t step, uint32_t purpose, float u[4]) {
   uint32_t o[4];
   philox4x32_10((uint32_t)((uint64_t)gid & 0xffffffffu), (uint32_t)((uint64_t)gid >> 32), step, purpose,
@@ -103,6 +103,37 @@ OIS_DEV void sincos_det(float x, float& s, float& c) {
   int q = k & 3;
   s = q == 0 ? sn : (q == 1 ? cs : (q == 2 ? -sn : -cs));
   c = q == 0 ? cs : (q == 1 ? -sn : (q == 2 ? -cs : sn));
+}
+
+// Deterministic natural log on (0, 1] (cephes logf: frexp by bit manipulation + degree-8
+// polynomial, mul/add/fma only) and a Box-Muller standard normal on top of it: the GridSampling
+// command sampler (KAMMA_curr2.py:602-640, torch.normal there). Mirrors the oracle bit for bit.
+OIS_DEV float log_det(float x) {
+  uint32_t u = __float_as_uint(x);
+  int e = (int)((u >> 23) & 0xffu) - 126;  // x = m * 2^e, m in [0.5, 1)
+  float m = __uint_as_float((u & 0x007fffffu) | 0x3f000000u);
+  if (m < 0.707106781186547524f) { e -= 1; m = (m + m) - 1.0f; } else { m = m - 1.0f; }
+  const float z = m * m;
+  float p = __builtin_fmaf(7.0376836292e-2f, m, -1.1514610310e-1f);
+  p = __builtin_fmaf(p, m, 1.1676998740e-1f);
+  p = __builtin_fmaf(p, m, -1.2420140846e-1f);
+  p = __builtin_fmaf(p, m, 1.4249322787e-1f);
+  p = __builtin_fmaf(p, m, -1.6668057665e-1f);
+  p = __builtin_fmaf(p, m, 2.0000714765e-1f);
+  p = __builtin_fmaf(p, m, -2.4999993993e-1f);
+  p = __builtin_fmaf(p, m, 3.3333331174e-1f);
+  float y = (p * m) * z;
+  const float ef = (float)e;
+  y = __builtin_fmaf(-2.12194440e-4f, ef, y);
+  y = __builtin_fmaf(-0.5f, z, y);
+  return __builtin_fmaf(0.693359375f, ef, m + y);
+}
+OIS_DEV float normal_det(float u1, float u2) {  // u1, u2 in [0, 1) -> N(0, 1)
+  const float r = sqrtf(-2.0f * log_det(1.0f - u1));
+  const float t = u2 < 0.5f ? u2 : 1.0f - u2;  // cos(2 pi t) is even about t = 0.5
+  float s, c;
+  sincos_det(6.28318530717958647692f * t, s, c);
+  return r * c;
 }
 
 // ---------------------------------------------------------------- quaternions ---------
@@ -276,6 +307,15 @@ OIS_DEV void reset_arena(const DevConsts& K, int64_t gid, int wheel0, float gamm
   } else if (K.cmd_sampler == OIS_CMD_EVAL) {  // KAMMA_eval.py:545-550
     const float progress = fminf(fmaxf((float)S.sim_steps / K.eval_ramp_steps, 0.0f), 1.0f);
     x_vel = 1.0f + progress * (2.0f - 1.0f);
+  } else if (K.cmd_sampler == OIS_CMD_GRID) {  // KAMMA_curr2.py:602-640 (bimodal normal, sigma 0.05)
+    const float progress = fminf(1.0f, (float)S.sim_steps / K.max_sim_steps);
+    const float xc = (K.cmd_x_lo + K.cmd_x_hi) / 2.0f;
+    const float left = xc - progress * (xc - K.cmd_x_lo);
+    const float right = xc + progress * (K.cmd_x_hi - xc);
+    float uc[4];
+    draw4(K, gid, (uint32_t)S.sim_steps, PURPOSE_RESET_C, uc);
+    const float mean = u[6] < 0.5f ? left : right;  // torch.rand(1) < 0.5 picks the side
+    x_vel = mean + 0.05f * normal_det(uc[0], uc[1]);
   }
   S.cmd[0] = x_vel > 0.0f ? x_vel : 0.0f;  // :575, :495
   S.cmd[2] = 0.0f;                         // :574, :496

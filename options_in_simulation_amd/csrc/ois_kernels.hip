@@ -481,7 +481,6 @@ int validate(const ois_config* c) {
       !(c->body_inertia[1] > 0.0f) || !(c->body_inertia[2] > 0.0f) || !(c->wheel_radius > 0.0f))
     return fail(OIS_EINVAL, "mass / inertia / radius must be positive");
   if (c->mix_mode != OIS_MIX_SWITCH && c->mix_mode != OIS_MIX_BLEND) return fail(OIS_EINVAL, "bad mix_mode");
-  if (c->cmd_sampler == OIS_CMD_GRID) return fail(OIS_EINVAL, "cmd_sampler GRID (KAMMA_curr2) is not implemented yet");
   if (c->cmd_sampler < 0 || c->cmd_sampler > OIS_CMD_EVAL) return fail(OIS_EINVAL, "bad cmd_sampler");
   if (!(c->max_sim_steps > 0.0f)) return fail(OIS_EINVAL, "max_sim_steps must be positive");
   return OIS_OK;

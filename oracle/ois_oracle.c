@@ -49,7 +49,7 @@ void orc_philox4x32_10(const uint32_t ctr[4], const uint32_t key[2], uint32_t ou
 /* 24 random bits -> [0,1), exact in float32 */
 float orc_u01(uint32_t x) { return (float)(x >> 8) * 5.9604644775390625e-08f; }
 
-enum { PURPOSE_MASK = 0, PURPOSE_RESET_A = 1, PURPOSE_RESET_B = 2, PURPOSE_ACTION = 3, PURPOSE_PARAMS = 4 };
+enum { PURPOSE_MASK = 0, PURPOSE_RESET_A = 1, PURPOSE_RESET_B = 2, PURPOSE_ACTION = 3, PURPOSE_PARAMS = 4, PURPOSE_RESET_C = 5 };
 
 static void draw4(uint64_t seed, int64_t arena, uint32_t step, uint32_t purpose, float u[4]) {
   uint32_t ctr[4] = {(uint32_t)((uint64_t)arena & 0xffffffffu), (uint32_t)((uint64_t)arena >> 32), step, purpose};
@@ -80,6 +80,39 @@ void orc_sincos(float x, float* s, float* c) {
     case 2: *s = -sn; *c = -cs; break;
     default: *s = -cs; *c = sn; break;
   }
+}
+
+/* Deterministic natural log for x in (0, 1] (cephes logf: frexp by bit manipulation + degree-8
+ * minimax polynomial, mul/add/fma only) and a Box-Muller standard normal built on it. Used by
+ * the GridSampling command sampler only (KAMMA_curr2.py:602-640, torch.normal there). */
+static float log_det(float x) {
+  union { float f; uint32_t u; } v = {x};
+  int e = (int)((v.u >> 23) & 0xffu) - 126; /* x = m * 2^e, m in [0.5, 1) */
+  v.u = (v.u & 0x007fffffu) | 0x3f000000u;
+  float m = v.f;
+  if (m < 0.707106781186547524f) { e -= 1; m = (m + m) - 1.0f; } else { m = m - 1.0f; }
+  float z = m * m;
+  float p = fmaf(7.0376836292e-2f, m, -1.1514610310e-1f);
+  p = fmaf(p, m, 1.1676998740e-1f);
+  p = fmaf(p, m, -1.2420140846e-1f);
+  p = fmaf(p, m, 1.4249322787e-1f);
+  p = fmaf(p, m, -1.6668057665e-1f);
+  p = fmaf(p, m, 2.0000714765e-1f);
+  p = fmaf(p, m, -2.4999993993e-1f);
+  p = fmaf(p, m, 3.3333331174e-1f);
+  float y = (p * m) * z;
+  float ef = (float)e;
+  y = fmaf(-2.12194440e-4f, ef, y);
+  y = fmaf(-0.5f, z, y);
+  return fmaf(0.693359375f, ef, m + y);
+}
+/* u1, u2 uniform in [0, 1) -> N(0, 1): sqrt(-2 ln(1 - u1)) * cos(2 pi u2) */
+static float normal_det(float u1, float u2) {
+  float r = sqrtf(-2.0f * log_det(1.0f - u1));
+  float t = u2 < 0.5f ? u2 : 1.0f - u2; /* cos(2 pi t) is even about t = 0.5 */
+  float s, c;
+  orc_sincos(6.28318530717958647692f * t, &s, &c);
+  return r * c;
 }
 
 /* ------------------------------------------------------------------ quaternions ------ */
@@ -712,6 +745,19 @@ static void reset_arena(orc_env* e, int i, uint32_t step_ctr, float gamma2, rese
     /* KAMMA_eval.py:545-550 */
     float progress = fminf(fmaxf((float)cnt[1] / c->eval_ramp_steps, 0.0f), 1.0f);
     float xv = 1.0f + progress * (2.0f - 1.0f);
+    cmd[0] = xv > 0.0f ? xv : 0.0f;
+  } else if (c->cmd_sampler == OIS_CMD_GRID) {
+    /* KAMMA_curr2.py:602-640: bimodal normal (sigma 0.05) whose two means move from the
+     * centre of the range to its ends with progress; u[6] picks the side (torch.rand(1) < 0.5),
+     * a third Philox block feeds the normal draw (the omega draw of :631-636 is discarded) */
+    float progress = fminf(1.0f, (float)cnt[1] / c->max_sim_steps);
+    float xc = (c->cmd_x_lo + c->cmd_x_hi) / 2.0f;
+    float left = xc - progress * (xc - c->cmd_x_lo);
+    float right = xc + progress * (c->cmd_x_hi - xc);
+    float uc[4];
+    draw4(e->seed, gid, step_ctr, PURPOSE_RESET_C, uc);
+    float mean = u[6] < 0.5f ? left : right;
+    float xv = mean + 0.05f * normal_det(uc[0], uc[1]);
     cmd[0] = xv > 0.0f ? xv : 0.0f;
   }
   /* pose: the reference sets the base-link pose (:441-443); the state stores the COM */

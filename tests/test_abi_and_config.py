@@ -52,7 +52,7 @@ def test_workspace_size_and_config_validation(lib):
     state = 15 * 65536 * 16 + 65536 * (24 + 4 + 1 + 1)
     assert state <= nbytes < state + 4 * 1024 * 1024
     for field, bad in (("num_envs", 0), ("action_dim", 3), ("solver_iterations", 0), ("sim_dt", 0.0),
-                       ("body_mass", -1.0), ("struct_bytes", 12), ("cmd_sampler", _abi.CMD_GRID)):
+                       ("body_mass", -1.0), ("struct_bytes", 12), ("cmd_sampler", 9)):
         c = build_config(variant="KAMMA_medium", num_envs=8)
         setattr(c, field, bad)
         assert lib.ois_workspace_bytes(C.byref(c)) == 0, field
@@ -101,7 +101,7 @@ def test_task_cfg_surface_and_variants():
     assert c.policy_dt == np.float32(0.1) and c.Kp == np.float32(0.035) and c.max_sim_steps == 500000.0
     raw = build_config(default_task_cfg(script_overrides=False), variant="KAMMA", num_envs=1)
     assert raw.Kp == 1.0 and raw.cmd_x_lo == raw.cmd_x_hi == 1.5 and raw.max_sim_steps == 400000.0
-    assert set(VARIANTS) >= {"KAMMA", "KAMMA_medium", "KAMMA_g11_g21", "KAMMA_g1d_g21", "KAMMA_curr1", "KAMMA_eval",
+    assert set(VARIANTS) >= {"KAMMA", "KAMMA_medium", "KAMMA_g11_g21", "KAMMA_g1d_g21", "KAMMA_curr1", "KAMMA_curr2", "KAMMA_eval",
                              "KA_DDPG_4D", "KA_DDPG_2D", "KA_DDPG_1D"}
     e = build_config(variant="KAMMA_eval", num_envs=1)
     assert (e.gamma1_mode, e.gamma1_const, e.cmd_sampler, e.eval_sums) == (_abi.GAMMA_CONST, 0.0, _abi.CMD_EVAL, 1)

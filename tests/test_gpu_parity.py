@@ -46,7 +46,7 @@ def compare(dev, orc, where="", exact_float=False):
 
 
 @pytest.mark.parametrize("variant", ["KAMMA_medium", "KA_DDPG_4D", "KA_DDPG_2D", "KA_DDPG_1D", "KAMMA_eval",
-                                     "KAMMA_curr1", "KAMMA_g1d_g21"])
+                                     "KAMMA_curr1", "KAMMA_curr2", "KAMMA_g1d_g21"])
 def test_step_parity_variants(variant):
     N = 200  # not a multiple of 16: ragged last wave
     cfg, dev, orc = make_pair(variant=variant, num_envs=N, seed=11, max_sim_steps=60.0)
@@ -159,3 +159,24 @@ def test_error_paths():
     bad.action_dim = 3
     with pytest.raises(ValueError):
         NativeEnv(bad, "cuda:0")
+
+
+@pytest.mark.parametrize("env_vars", [{"OIS_PACKED": "0"}, {"OIS_PACKED": "1"}, {"OIS_LANES_PER_ARENA": "2"}],
+                         ids=["scalar", "packed", "lane-pair"])
+def test_every_kernel_instantiation_is_bit_identical_to_the_oracle(env_vars, monkeypatch):
+    """step_kernel<1,false>, <1,true> and <2,false> share one arithmetic (docs/SPEC.md); the
+    library picks by size, the environment variables (read at ois_create) force each one."""
+    for k, v in env_vars.items():
+        monkeypatch.setenv(k, v)
+    N = 300
+    cfg, dev, orc = make_pair(variant="KAMMA_medium", num_envs=N, seed=17, max_sim_steps=150.0)
+    dev.reset(17); orc.reset(17)
+    rng = np.random.default_rng(3)
+    for t in range(105):  # crosses the timeout at step 99
+        a = rng.uniform(0, 1, size=(N, 4)).astype(np.float32)
+        dev.step(torch.from_numpy(a).cuda()); orc.step(a)
+        if t % 20 == 0 or t >= 98:
+            compare(dev, orc, f"{env_vars} step {t}", exact_float=True)
+    np.testing.assert_array_equal(dev.episode_info().cpu().numpy(), orc.episode_info())
+    dev.rollout(7, _abi.POLICY_RANDOM); orc.rollout(7, _abi.POLICY_RANDOM)
+    compare(dev, orc, f"{env_vars} fused rollout", exact_float=True)

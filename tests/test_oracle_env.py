@@ -185,3 +185,20 @@ def test_oracle_reproduces_golden_trajectories(name):
     from tests.golden_replay import replay
     d = np.load(os.path.join(G, name + ".npz"))
     replay(d, name, lambda cfg: OracleEnv(cfg), to_numpy=lambda x: x, exact=True)
+
+
+def test_grid_sampler_is_bimodal_and_follows_progress():
+    """KAMMA_curr2.py:602-640: the two modes sit at the centre of linear_x when sim_steps = 0 and at
+    the ends of the range when sim_steps >= max_sim_steps; sigma = 0.05."""
+    N = 8192
+    env = OracleEnv(build_config(variant="KAMMA_curr2", num_envs=N, seed=12, max_sim_steps=99.0))
+    env.reset(12)
+    x0 = env.buffer(_abi.BUF_COMMANDS)[:, 0].copy()      # progress 0: one mode at the centre 1.5
+    assert abs(x0.mean() - 1.5) < 0.005 and abs(x0.std() - 0.05) < 0.003
+    env.rollout(99, _abi.POLICY_ZERO)                      # every arena resets at sim_steps = 99: progress 1
+    x1 = env.buffer(_abi.BUF_COMMANDS)[:, 0]
+    lo, hi = x1[x1 < 1.5], x1[x1 >= 1.5]
+    assert 0.45 < len(lo) / N < 0.55
+    assert abs(lo.mean() - 1.0) < 0.005 and abs(hi.mean() - 2.0) < 0.005
+    assert abs(lo.std() - 0.05) < 0.004 and abs(hi.std() - 0.05) < 0.004
+    assert (env.buffer(_abi.BUF_COMMANDS)[:, 2] == 0).all()
