@@ -111,11 +111,19 @@ def main():
     if args.gpus > 1 and world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} needs a torch.distributed.run launch with {args.gpus} ranks "
                          f"(WORLD_SIZE={world})")
-    torch.cuda.set_device(local_rank)
-    device = torch.device("cuda", local_rank)
+    # one process per GPU. OIS_DIST_BACKEND=gloo + fewer GPUs than ranks is only for rehearsing the
+    # multi-process path on a 1-GPU box (ranks then share device 0; RCCL refuses duplicate GPUs).
+    backend = os.environ.get("OIS_DIST_BACKEND", "nccl")
+    dev_index = local_rank % max(1, torch.cuda.device_count()) if backend == "gloo" else local_rank
+    torch.cuda.set_device(dev_index)
+    device = torch.device("cuda", dev_index)
+    comm_device = torch.device("cpu") if backend == "gloo" else device
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
+        if backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
+        else:
+            dist.init_process_group(backend, rank=rank, world_size=world)
 
     N = args.arenas
     cfg = build_config(variant=args.variant, num_envs=N, seed=42, arena_offset=rank * N)
@@ -159,7 +167,7 @@ def main():
     barrier()
     elapsed = time.perf_counter() - t0
     if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=device)
+        t = torch.tensor([elapsed], dtype=torch.float64, device=comm_device)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
