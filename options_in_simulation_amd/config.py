@@ -119,9 +119,21 @@ VARIANTS: Dict[str, Dict[str, Any]] = {
                        guiding_mode=A.GUIDE_POLICY,
                        gamma1_mode=A.GAMMA_CONST, gamma1_const=1.0,
                        gamma2_mode=A.GAMMA_CONST, gamma2_const=1.0),
-    # KA_DDPG_1D.py:157, 600-603
+    # KA_DDPG_1D.py:157, 600-603, 629 (gamma update commented -> stays at init 1)
     "KA_DDPG_1D": dict(action_dim=1, action_low=-1.0, mix_mode=A.MIX_BLEND, max_sim_steps=700000.0,
-                       guiding_mode=A.GUIDE_POLICY),
+                       guiding_mode=A.GUIDE_POLICY,
+                       gamma1_mode=A.GAMMA_CONST, gamma1_const=1.0,
+                       gamma2_mode=A.GAMMA_CONST, gamma2_const=1.0),
+    # KA_DDPG_2D_eval.py:180, 193, 542-548, 645, 685-692, 857 (gamma init 0 and never updated)
+    "KA_DDPG_2D_eval": dict(action_dim=2, action_low=-1.0, mix_mode=A.MIX_BLEND, max_sim_steps=50000.0,
+                            guiding_mode=A.GUIDE_POLICY, cmd_sampler=A.CMD_EVAL, eval_sums=1,
+                            gamma1_mode=A.GAMMA_CONST, gamma1_const=0.0,
+                            gamma2_mode=A.GAMMA_CONST, gamma2_const=0.0),
+    # KA_DDPG_1D_eval.py:180, 193, 542-548, 647, 685-692, 857
+    "KA_DDPG_1D_eval": dict(action_dim=1, action_low=-1.0, mix_mode=A.MIX_BLEND, max_sim_steps=50000.0,
+                            guiding_mode=A.GUIDE_POLICY, cmd_sampler=A.CMD_EVAL, eval_sums=1,
+                            gamma1_mode=A.GAMMA_CONST, gamma1_const=0.0,
+                            gamma2_mode=A.GAMMA_CONST, gamma2_const=0.0),
 }
 
 # --------------------------------------------------------------------------------------
