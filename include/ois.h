@@ -252,6 +252,31 @@ int ois_stats_fetch(ois_env* env, ois_stats* host_out, int reset_after, void* st
 /* Copy the arena-0 diagnostics block to the host (synchronises `stream`). */
 int ois_env0_diag(ois_env* env, float* host_out /*[OIS_ENV0_DIAG_LEN]*/, void* stream);
 
+/* ---- device-resident FIFO transition memory written by the step kernel ----
+ * Semantics of the train scripts' FIFOMemory (train_kaddpg_4d_nofifo_random_RLIL.py:105-206:
+ * tensors [memory_size, num_envs, dim], row memory_index overwritten, index wraps) with the
+ * trainer's executed-action substitution (src/my_trainers/base_KA_DDPG.py:212:
+ * actions = task.wheel_torqs / task.action_scale). Once attached, every policy step of
+ * ois_step / ois_rollout appends one row: states = the observation before the step,
+ * actions = wheel_torqs / action_scale [4], rewards, next_states = the observation after the
+ * step, terminated. The memory is caller-owned device memory, like the workspace. */
+enum ois_replay_id {
+  OIS_RP_STATES = 0,      /* float [M, N, 6] */
+  OIS_RP_ACTIONS = 1,     /* float [M, N, 4] */
+  OIS_RP_REWARDS = 2,     /* float [M, N, 1] */
+  OIS_RP_NEXT_STATES = 3, /* float [M, N, 6] */
+  OIS_RP_TERMINATED = 4,  /* uint8 [M, N, 1] */
+  OIS_RP_COUNT_
+};
+size_t ois_replay_bytes(const ois_env* env, int memory_size);
+/* attach (memory_size >= 1) or detach (memory_device == NULL). Resets the cursor. The library
+ * never clears the memory: rows not yet written keep what the caller put there (skrl's
+ * tensors start as zeros, so the host mirror hands over a zero-filled block). */
+int ois_replay_attach(ois_env* env, int memory_size, void* memory_device, size_t bytes);
+int ois_replay_buffer(ois_env* env, int id, void** ptr_device, size_t* bytes);
+/* memory_index = next row to be written, filled = 1 once the index has wrapped */
+int ois_replay_cursor(const ois_env* env, int* memory_index, int* filled);
+
 /* Snapshot / restore the complete environment state (all persistent buffers) to/from a
  * host blob of ois_state_bytes(). Beyond reference parity (SURVEY.md §5 checkpoint). */
 size_t ois_state_bytes(const ois_env* env);

@@ -18,7 +18,7 @@ SYMBOLS = (
     "ois_abi_version", "ois_last_error", "ois_config_default", "ois_workspace_bytes", "ois_create",
     "ois_destroy", "ois_reset", "ois_step", "ois_rollout", "ois_buffer", "ois_randomize_params",
     "ois_episode_info", "ois_stats_fetch", "ois_env0_diag", "ois_state_bytes", "ois_save_state",
-    "ois_load_state",
+    "ois_load_state", "ois_replay_bytes", "ois_replay_attach", "ois_replay_buffer", "ois_replay_cursor",
 )
 
 _lib = None
@@ -69,6 +69,11 @@ def load() -> C.CDLL:
     L.ois_state_bytes.restype = C.c_size_t
     L.ois_save_state.argtypes = [vp, vp, C.c_size_t, vp]
     L.ois_load_state.argtypes = [vp, vp, C.c_size_t, vp]
+    L.ois_replay_bytes.argtypes = [vp, C.c_int]
+    L.ois_replay_bytes.restype = C.c_size_t
+    L.ois_replay_attach.argtypes = [vp, C.c_int, vp, C.c_size_t]
+    L.ois_replay_buffer.argtypes = [vp, C.c_int, C.POINTER(vp), C.POINTER(C.c_size_t)]
+    L.ois_replay_cursor.argtypes = [vp, C.POINTER(C.c_int), C.POINTER(C.c_int)]
     if L.ois_abi_version() != _abi.ABI_VERSION:
         raise NativeLibraryError(
             f"ABI mismatch: library {L.ois_abi_version()} vs python {_abi.ABI_VERSION}; rebuild the library")

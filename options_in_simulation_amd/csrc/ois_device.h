@@ -1,14 +1,13 @@
 // ois_device.h — device-side building blocks of the fused skid-steer step kernel (gfx950).
 //
-// Execution shape: ONE ARENA PER LANE. A lane owns the chassis and all four wheel contacts of
-// its arena; the four contacts are four independent instruction streams inside the lane
-// (mass-splitting Jacobi, docs/SPEC.md §3.5), which gives the in-order SIMD the
-// instruction-level parallelism a single dependent fma chain lacks. Measured on MI355X
-// (tools/valu_rate.hip, profiles/r1_valu_rate.txt): independent v_fma_f32 issue every
-// ~1.13 ns per SIMD, a dependent chain every ~1.4-1.9 ns, a quad_perm DPP add every ~2.7 ns,
-// v_pk_fma_f32 every ~1.9 ns (no gain over two scalar fmas). An earlier layout with one wheel
-// per lane (4 lanes per arena, DPP quad sums) replicated the chassis math four times and paid
-// 62 DPP adds per substep: 88 us per 65 536-arena step against this layout's.
+// Execution shape: ONE ARENA PER LANE (default). A lane owns the chassis and all four wheel
+// contacts of its arena; the four contacts are independent inside a solver iteration
+// (mass-splitting Jacobi, docs/SPEC.md §3.5). The kernel is bound by VALU issue, not by HBM
+// (DESIGN.md §4). Measured on MI355X (tools/valu_rate.hip, profiles/r1_valu_rate.txt): a
+// wave64 v_fma_f32 costs 2.0-2.4 ns per SIMD when the SIMD holds one wave and 1.1-1.3 ns with
+// two or more, v_pk_fma_f32 2.5 / 1.9 ns, a quad_perm DPP add 1.75-2.0 ns. An earlier layout
+// with one wheel per lane (4 lanes per arena, DPP quad sums) replicated the chassis math four
+// times and paid 62 DPP adds per substep: 88 us per 65 536-arena step against 35-50 us here.
 //
 // Memory: every state array in HBM is [N][4] floats, so a lane reads its arena's row with one
 // 16-byte global_load_dwordx4 and a wave-level instruction moves 1 KiB of contiguous bytes.
@@ -61,6 +60,10 @@ struct DevBuffers {
   float* stat_acc;   // [ngroups][8]
   float* episode_info;  // [32]
   float* env0_diag;     // [32]
+  // optional FIFO transition memory (include/ois.h ois_replay_*), rp_size = 0 when detached
+  float *rp_states, *rp_actions, *rp_rewards, *rp_next;  // [M][N][6|4|1|6]
+  uint8_t* rp_done;                                      // [M][N]
+  int rp_size;
 };
 
 // ---------------------------------------------------------------- RNG -----------------

@@ -88,7 +88,8 @@ OIS_DEV void store_arena(const DevConsts& K, const DevBuffers& B, int i, int h, 
 // ------------------------------------------------------------------ the step kernel ---
 template <int LPA, bool PK>
 __global__ OIS_STEP_BOUNDS void step_kernel(DevConsts K, DevBuffers B, const float* __restrict__ actions,
-                                                      float* __restrict__ reward_sum, int N, int ksteps, int policy) {
+                                                      float* __restrict__ reward_sum, int N, int ksteps, int policy,
+                                                      int rp_head) {
   constexpr int W = 4 / LPA;
   const int tid = blockIdx.x * kBlock + threadIdx.x;
   const int lane = threadIdx.x & 63;
@@ -103,6 +104,14 @@ __global__ OIS_STEP_BOUNDS void step_kernel(DevConsts K, DevBuffers B, const flo
   ArenaT<LPA> S;
   load_arena<LPA>(K, B, la, h, S);
   float rsum = 0.0f;
+  // FIFO transition memory: "states" of the first appended row = the observation the caller saw
+  float o_prev[6] = {0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f};
+  if (B.rp_size > 0) {
+    const float* o = B.obs + (size_t)la * 6;
+    const float2 t0 = *reinterpret_cast<const float2*>(o), t1 = *reinterpret_cast<const float2*>(o + 2),
+                 t2 = *reinterpret_cast<const float2*>(o + 4);
+    o_prev[0] = t0.x; o_prev[1] = t0.y; o_prev[2] = t1.x; o_prev[3] = t1.y; o_prev[4] = t2.x; o_prev[5] = t2.y;
+  }
 
   for (int s = 0; s < ksteps; ++s) {
     const bool last = s == ksteps - 1;
@@ -250,15 +259,32 @@ __global__ OIS_STEP_BOUNDS void step_kernel(DevConsts K, DevBuffers B, const flo
     const bool do_reset = reset && valid;
     if (reset) reset_arena<LPA>(K, gid, wheel0, gamma1, gamma2, S, rc);
     if (!valid) contrib_identity(rc);
+    // get_observations (:833); desired_* are views of commands -> post-reset values; clamp: rl_task.py:99
+    const float co = K.clip_obs;
+    const float ob[6] = {clipf(S.cmd[0], -co, co), clipf(S.cmd[2], -co, co), clipf(vd, -co, co),
+                         clipf(od, -co, co),       clipf(lin_acc, -co, co),  clipf(ang_acc, -co, co)};
+    // FIFO transition memory row (train_kaddpg_4d_nofifo_random_RLIL.py:147-156; executed action:
+    // base_KA_DDPG.py:212)
+    if (B.rp_size > 0 && valid) {
+      const size_t row = (size_t)((rp_head + s) % B.rp_size) * N + arena;
+#pragma unroll
+      for (int k = 0; k < W; ++k) B.rp_actions[row * 4 + wheel0 + k] = wt[k] / K.action_scale;
+      if (h == 0) {
+#pragma unroll
+        for (int k = 0; k < 6; ++k) { B.rp_states[row * 6 + k] = o_prev[k]; B.rp_next[row * 6 + k] = ob[k]; }
+        B.rp_rewards[row] = rew;
+        B.rp_done[row] = reset ? 1 : 0;
+      }
+    }
+#pragma unroll
+    for (int k = 0; k < 6; ++k) o_prev[k] = ob[k];
     // outputs (only the last step of a rollout is observable)
     if (last && valid) {
       if (h == 0) {
-        // get_observations (:833); desired_* are views of commands -> post-reset values; clamp: rl_task.py:99
         float* o = B.obs + (size_t)arena * 6;
-        const float co = K.clip_obs;
-        *reinterpret_cast<float2*>(o) = make_float2(clipf(S.cmd[0], -co, co), clipf(S.cmd[2], -co, co));
-        *reinterpret_cast<float2*>(o + 2) = make_float2(clipf(vd, -co, co), clipf(od, -co, co));
-        *reinterpret_cast<float2*>(o + 4) = make_float2(clipf(lin_acc, -co, co), clipf(ang_acc, -co, co));
+        *reinterpret_cast<float2*>(o) = make_float2(ob[0], ob[1]);
+        *reinterpret_cast<float2*>(o + 2) = make_float2(ob[2], ob[3]);
+        *reinterpret_cast<float2*>(o + 4) = make_float2(ob[4], ob[5]);
         B.rew[arena] = rew;
         B.done[arena] = reset ? 1 : 0;
         B.timeout[arena] = timeout ? 1 : 0;
@@ -546,7 +572,23 @@ struct ois_env {
   uint64_t seed;  // seed of the last ois_reset (RNG key of the episode stream)
   bool reset_done;
   double steps_done;
+  // FIFO transition memory (ois_replay_*): caller-owned device memory, cursor on the host
+  char* rp_mem;
+  size_t rp_off[OIS_RP_COUNT_], rp_bytes[OIS_RP_COUNT_];
+  int rp_head;
+  bool rp_filled;
 };
+
+namespace {
+size_t replay_layout(int N, int M, size_t off[OIS_RP_COUNT_], size_t bytes[OIS_RP_COUNT_]) {
+  const size_t rows = (size_t)M * (size_t)N;
+  const size_t sz[OIS_RP_COUNT_] = {rows * 6 * sizeof(float), rows * 4 * sizeof(float), rows * sizeof(float),
+                                    rows * 6 * sizeof(float), rows};
+  size_t o = 0;
+  for (int i = 0; i < OIS_RP_COUNT_; ++i) { off[i] = o; bytes[i] = sz[i]; o = align256(o + sz[i]); }
+  return o;
+}
+}  // namespace
 
 extern "C" {
 
@@ -658,6 +700,8 @@ int ois_create(const ois_config* cfg, int device, void* workspace_device, size_t
   B.done = (uint8_t*)(w + L.off[OIS_BUF_DONE]); B.timeout = (uint8_t*)(w + L.off[OIS_BUF_TIMEOUT]);
   B.episode_info = (float*)(w + L.off[OIS_BUF_EPISODE_INFO]); B.env0_diag = (float*)(w + L.off[OIS_BUF_ENV0_DIAG]);
   B.partials = (float*)(w + L.partials); B.stamps = (int32_t*)(w + L.stamps); B.stat_acc = (float*)(w + L.stat_acc);
+  B.rp_states = B.rp_actions = B.rp_rewards = B.rp_next = nullptr; B.rp_done = nullptr; B.rp_size = 0;
+  e->rp_mem = nullptr; e->rp_head = 0; e->rp_filled = false;
   // default per-arena parameters: mu = cfg.friction, flat plane n = +z
   hipError_t he = hipMemsetAsync(e->ws, 0, L.total, nullptr);
   if (he == hipSuccess) {
@@ -693,16 +737,20 @@ static int launch_steps(ois_env* e, int k, int policy, const float* actions, flo
   HIP_TRY(hipSetDevice(e->device));
   if (e->lpa == 2) {
     hipLaunchKernelGGL((step_kernel<2, false>), dim3((2 * e->N + kBlock - 1) / kBlock), dim3(kBlock), 0,
-                       (hipStream_t)stream, e->K, e->B, actions, reward_sum, e->N, k, policy);
+                       (hipStream_t)stream, e->K, e->B, actions, reward_sum, e->N, k, policy, e->rp_head);
   } else if (e->packed) {
     hipLaunchKernelGGL((step_kernel<1, true>), dim3(e->grid), dim3(kBlock), 0, (hipStream_t)stream, e->K, e->B, actions,
-                       reward_sum, e->N, k, policy);
+                       reward_sum, e->N, k, policy, e->rp_head);
   } else {
     hipLaunchKernelGGL((step_kernel<1, false>), dim3(e->grid), dim3(kBlock), 0, (hipStream_t)stream, e->K, e->B, actions,
-                       reward_sum, e->N, k, policy);
+                       reward_sum, e->N, k, policy, e->rp_head);
   }
   HIP_TRY(hipGetLastError());
   e->steps_done += (double)e->N * (double)k;
+  if (e->B.rp_size > 0) {  // the kernel wrote rows rp_head .. rp_head + k - 1 (mod size)
+    if (e->rp_head + k >= e->B.rp_size) e->rp_filled = true;
+    e->rp_head = (e->rp_head + k) % e->B.rp_size;
+  }
   return OIS_OK;
 }
 
@@ -777,6 +825,50 @@ int ois_env0_diag(ois_env* e, float* host_out, void* stream) {
   HIP_TRY(hipSetDevice(e->device));
   HIP_TRY(hipMemcpyAsync(host_out, e->B.env0_diag, OIS_ENV0_DIAG_LEN * sizeof(float), hipMemcpyDeviceToHost, (hipStream_t)stream));
   HIP_TRY(hipStreamSynchronize((hipStream_t)stream));
+  return OIS_OK;
+}
+
+size_t ois_replay_bytes(const ois_env* e, int memory_size) {
+  if (!e || memory_size < 1) return 0;
+  size_t off[OIS_RP_COUNT_], bytes[OIS_RP_COUNT_];
+  return replay_layout(e->N, memory_size, off, bytes);
+}
+
+int ois_replay_attach(ois_env* e, int memory_size, void* memory_device, size_t bytes) {
+  if (!e) return fail(OIS_EINVAL, "null env");
+  DevBuffers& B = e->B;
+  if (!memory_device) {  // detach
+    B.rp_states = B.rp_actions = B.rp_rewards = B.rp_next = nullptr; B.rp_done = nullptr; B.rp_size = 0;
+    e->rp_mem = nullptr; e->rp_head = 0; e->rp_filled = false;
+    return OIS_OK;
+  }
+  if (memory_size < 1 || memory_size > (1 << 24)) return fail(OIS_EINVAL, "memory_size out of range");
+  if (((uintptr_t)memory_device & 255u) != 0) return fail(OIS_EINVAL, "replay memory must be 256-byte aligned");
+  const size_t need = replay_layout(e->N, memory_size, e->rp_off, e->rp_bytes);
+  if (bytes < need) return fail(OIS_ENOMEM, "replay memory smaller than ois_replay_bytes()");
+  char* m = (char*)memory_device;
+  e->rp_mem = m;
+  B.rp_states = (float*)(m + e->rp_off[OIS_RP_STATES]); B.rp_actions = (float*)(m + e->rp_off[OIS_RP_ACTIONS]);
+  B.rp_rewards = (float*)(m + e->rp_off[OIS_RP_REWARDS]); B.rp_next = (float*)(m + e->rp_off[OIS_RP_NEXT_STATES]);
+  B.rp_done = (uint8_t*)(m + e->rp_off[OIS_RP_TERMINATED]);
+  B.rp_size = memory_size;
+  e->rp_head = 0; e->rp_filled = false;
+  return OIS_OK;
+}
+
+int ois_replay_buffer(ois_env* e, int id, void** ptr_device, size_t* bytes) {
+  if (!e || !ptr_device || !bytes) return fail(OIS_EINVAL, "null argument");
+  if (!e->rp_mem) return fail(OIS_ESTATE, "no replay memory attached");
+  if (id < 0 || id >= OIS_RP_COUNT_) return fail(OIS_EINVAL, "unknown replay buffer id");
+  *ptr_device = e->rp_mem + e->rp_off[id];
+  *bytes = e->rp_bytes[id];
+  return OIS_OK;
+}
+
+int ois_replay_cursor(const ois_env* e, int* memory_index, int* filled) {
+  if (!e || !memory_index || !filled) return fail(OIS_EINVAL, "null argument");
+  *memory_index = e->rp_head;
+  *filled = e->rp_filled ? 1 : 0;
   return OIS_OK;
 }
 

@@ -161,6 +161,37 @@ class NativeEnv:
         _native.check(self.L.ois_env0_diag(self.h, out.ctypes.data_as(C.POINTER(C.c_float)), _stream_ptr(self.device)))
         return out
 
+    def attach_replay(self, memory_size: int) -> Dict[str, torch.Tensor]:
+        """Device-resident FIFO transition memory written by the step kernel (include/ois.h
+        ois_replay_*). Returns zero-copy tensors named like skrl's memory tensors:
+        states [M,N,6], actions [M,N,4] (executed torques / action_scale, base_KA_DDPG.py:212),
+        rewards [M,N,1], next_states [M,N,6], terminated [M,N,1] (bool)."""
+        nbytes = self.L.ois_replay_bytes(self.h, int(memory_size))
+        if nbytes == 0:
+            raise ValueError("memory_size must be >= 1")
+        self._replay_mem = torch.zeros(nbytes, dtype=torch.uint8, device=self.device)  # unwritten rows read as zeros, like skrl's
+        torch.cuda.synchronize(self.device)
+        _native.check(self.L.ois_replay_attach(self.h, int(memory_size), C.c_void_p(self._replay_mem.data_ptr()), nbytes))
+        base = self._replay_mem.data_ptr()
+        out = {}
+        for rid, (name, dt, cols) in enumerate((("states", torch.float32, 6), ("actions", torch.float32, 4),
+                                                ("rewards", torch.float32, 1), ("next_states", torch.float32, 6),
+                                                ("terminated", torch.bool, 1))):
+            p, n = C.c_void_p(), C.c_size_t()
+            _native.check(self.L.ois_replay_buffer(self.h, rid, C.byref(p), C.byref(n)))
+            out[name] = self._replay_mem[p.value - base: p.value - base + n.value].view(dt).view(int(memory_size), self.N, cols)
+        return out
+
+    def detach_replay(self):
+        torch.cuda.synchronize(self.device)
+        _native.check(self.L.ois_replay_attach(self.h, 0, None, 0))
+        self._replay_mem = None
+
+    def replay_cursor(self) -> Tuple[int, bool]:
+        i, f = C.c_int(), C.c_int()
+        _native.check(self.L.ois_replay_cursor(self.h, C.byref(i), C.byref(f)))
+        return i.value, bool(f.value)
+
     def save_state(self) -> bytes:
         n = self.L.ois_state_bytes(self.h)
         buf = (C.c_uint8 * n)()

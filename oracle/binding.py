@@ -47,6 +47,9 @@ def lib() -> C.CDLL:
         L.orc_buffer.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.c_void_p), C.POINTER(C.c_size_t)]
         L.orc_episode_info.argtypes = [C.c_void_p]
         L.orc_stats_fetch.argtypes = [C.c_void_p, C.POINTER(_abi.OisStats), C.c_int]
+        L.orc_replay_attach.argtypes = [C.c_void_p, C.c_int]
+        L.orc_replay_buffer.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.c_void_p), C.POINTER(C.c_size_t)]
+        L.orc_replay_cursor.argtypes = [C.c_void_p, C.POINTER(C.c_int), C.POINTER(C.c_int)]
         L.orc_criteria.argtypes = [C.c_int, fp, fp, fp, fp] + [C.c_float] * 5 + [fp] * 4
         L.orc_criteria.restype = None
         L.orc_gamma.argtypes = [C.c_int, ip, C.c_float, fp]
@@ -163,6 +166,26 @@ class OracleEnv:
     def randomize_params(self, mu_lo, mu_hi, slopes=()):
         s = np.asarray(slopes, np.float32)
         self._check(self.L.orc_randomize_params(self.h, mu_lo, mu_hi, fptr(s) if s.size else None, int(s.size)))
+
+    def attach_replay(self, memory_size: int) -> dict:
+        """FIFO transition memory mirror; returns numpy views keyed like skrl's memory tensors."""
+        self._check(self.L.orc_replay_attach(self.h, memory_size))
+        out = {}
+        if memory_size == 0:  # detached
+            return out
+        for rid, (name, dt, cols) in enumerate((("states", np.float32, 6), ("actions", np.float32, 4),
+                                                ("rewards", np.float32, 1), ("next_states", np.float32, 6),
+                                                ("terminated", np.uint8, 1))):
+            p, n = C.c_void_p(), C.c_size_t()
+            self._check(self.L.orc_replay_buffer(self.h, rid, C.byref(p), C.byref(n)))
+            arr = np.ctypeslib.as_array(C.cast(p, C.POINTER(C.c_uint8)), shape=(n.value,)).view(dt)
+            out[name] = arr.reshape(memory_size, self.N, cols)
+        return out
+
+    def replay_cursor(self):
+        i, f = C.c_int(), C.c_int()
+        self._check(self.L.orc_replay_cursor(self.h, C.byref(i), C.byref(f)))
+        return i.value, bool(f.value)
 
     def episode_info(self) -> np.ndarray:
         self._check(self.L.orc_episode_info(self.h))

@@ -604,6 +604,10 @@ struct orc_env {
   float* partials;  /* [G][PART_STRIDE] */
   int32_t* stamps;  /* [G] */
   float* stat_acc;  /* [G][ST_STRIDE] */
+  /* FIFO transition memory (mirror of ois_replay_*) */
+  float *rp_states, *rp_actions, *rp_rewards, *rp_next;
+  uint8_t* rp_done;
+  int rp_size, rp_head, rp_filled;
 };
 
 static void* zalloc(size_t n) { return calloc(n ? n : 1, 1); }
@@ -646,7 +650,9 @@ void orc_destroy(orc_env* e) {
   free(e->obs); free(e->rew); free(e->wheel_torqs); free(e->pose); free(e->quat); free(e->linvel);
   free(e->angvel); free(e->wheel_vel); free(e->commands); free(e->sums_a); free(e->sums_b); free(e->sums_c);
   free(e->params); free(e->lam_n); free(e->lam_l); free(e->lam_t); free(e->done); free(e->timeout); free(e->counters); free(e->partials); free(e->stamps);
-  free(e->stat_acc); free(e);
+  free(e->stat_acc);
+  free(e->rp_states); free(e->rp_actions); free(e->rp_rewards); free(e->rp_next); free(e->rp_done);
+  free(e);
 }
 
 int orc_set_threads(orc_env* e, int threads) {
@@ -973,7 +979,18 @@ static float step_arena(orc_env* e, int i, const float* act /*[A]*/, uint8_t* rs
   if (reset) reset_arena(e, i, (uint32_t)cnt[1], gamma2, &rc[i]); /* :691-693 */
   /* get_observations (:825-833): desired_* are views of commands -> post-reset values */
   float o[6] = {CMD[0], CMD[2], v_delta, omega_delta, mo.lin_acc, mo.ang_acc};
-  for (int k = 0; k < 6; ++k) e->obs[6 * i + k] = clipf(o[k], -c->clip_obs, c->clip_obs); /* rl_task.py:99 clamp in the VecEnv */
+  float ob[6];
+  for (int k = 0; k < 6; ++k) ob[k] = clipf(o[k], -c->clip_obs, c->clip_obs); /* rl_task.py:99 clamp in the VecEnv */
+  if (e->rp_size > 0) {
+    /* FIFOMemory row (train_kaddpg_4d_nofifo_random_RLIL.py:147-156): states = the previous
+     * observation, actions = executed torques / action_scale (base_KA_DDPG.py:212) */
+    size_t row = (size_t)e->rp_head * e->N + i;
+    for (int k = 0; k < 6; ++k) { e->rp_states[row * 6 + k] = e->obs[6 * i + k]; e->rp_next[row * 6 + k] = ob[k]; }
+    for (int k = 0; k < 4; ++k) e->rp_actions[row * 4 + k] = wt[k] / c->action_scale;
+    e->rp_rewards[row] = mo.rew;
+    e->rp_done[row] = reset;
+  }
+  for (int k = 0; k < 6; ++k) e->obs[6 * i + k] = ob[k];
   e->rew[i] = mo.rew;
   e->done[i] = reset;
   e->timeout[i] = timeout;
@@ -1018,6 +1035,10 @@ static int step_all(orc_env* e, int policy, const float* actions, float* reward_
     group_reduce(e, g, rs, rc, stamp, lg1, lg2, 1);
   }
   e->steps_done += (double)N;
+  if (e->rp_size > 0) {
+    if (e->rp_head + 1 >= e->rp_size) e->rp_filled = 1;
+    e->rp_head = (e->rp_head + 1) % e->rp_size;
+  }
   return OIS_OK;
 }
 
@@ -1047,6 +1068,40 @@ int orc_rollout(orc_env* e, int k, int policy, const float* actions, float* rewa
     step_all(e, policy, a, reward_sum, rc, rs);
   }
   free(rc); free(rs);
+  return OIS_OK;
+}
+
+/* FIFO transition memory, mirror of ois_replay_attach / _buffer / _cursor */
+int orc_replay_attach(orc_env* e, int memory_size) {
+  if (!e || memory_size < 0) return fail(OIS_EINVAL, "bad argument");
+  free(e->rp_states); free(e->rp_actions); free(e->rp_rewards); free(e->rp_next); free(e->rp_done);
+  e->rp_states = e->rp_actions = e->rp_rewards = e->rp_next = NULL; e->rp_done = NULL;
+  e->rp_size = memory_size; e->rp_head = 0; e->rp_filled = 0;
+  if (memory_size > 0) {
+    size_t rows = (size_t)memory_size * (size_t)e->N;
+    e->rp_states = zalloc(rows * 6 * sizeof(float)); e->rp_actions = zalloc(rows * 4 * sizeof(float));
+    e->rp_rewards = zalloc(rows * sizeof(float)); e->rp_next = zalloc(rows * 6 * sizeof(float));
+    e->rp_done = zalloc(rows);
+    if (!e->rp_states || !e->rp_actions || !e->rp_rewards || !e->rp_next || !e->rp_done) return fail(OIS_ENOMEM, "host alloc");
+  }
+  return OIS_OK;
+}
+int orc_replay_buffer(orc_env* e, int id, void** ptr, size_t* bytes) {
+  if (!e || !ptr || !bytes || e->rp_size <= 0) return fail(OIS_EINVAL, "no replay memory");
+  size_t rows = (size_t)e->rp_size * (size_t)e->N;
+  switch (id) {
+    case OIS_RP_STATES: *ptr = e->rp_states; *bytes = rows * 6 * sizeof(float); break;
+    case OIS_RP_ACTIONS: *ptr = e->rp_actions; *bytes = rows * 4 * sizeof(float); break;
+    case OIS_RP_REWARDS: *ptr = e->rp_rewards; *bytes = rows * sizeof(float); break;
+    case OIS_RP_NEXT_STATES: *ptr = e->rp_next; *bytes = rows * 6 * sizeof(float); break;
+    case OIS_RP_TERMINATED: *ptr = e->rp_done; *bytes = rows; break;
+    default: return fail(OIS_EINVAL, "unknown replay buffer id");
+  }
+  return OIS_OK;
+}
+int orc_replay_cursor(const orc_env* e, int* memory_index, int* filled) {
+  if (!e || !memory_index || !filled) return fail(OIS_EINVAL, "null argument");
+  *memory_index = e->rp_head; *filled = e->rp_filled;
   return OIS_OK;
 }
 

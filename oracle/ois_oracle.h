@@ -53,6 +53,10 @@ int orc_buffer(orc_env* env, int id, void** ptr, size_t* bytes);
 int orc_episode_info(orc_env* env);               /* fills OIS_BUF_EPISODE_INFO */
 int orc_stats_fetch(orc_env* env, ois_stats* out, int reset_after);
 const char* orc_last_error(void);
+/* FIFO transition memory mirror (ois_replay_*); memory_size 0 detaches */
+int orc_replay_attach(orc_env* env, int memory_size);
+int orc_replay_buffer(orc_env* env, int id, void** ptr, size_t* bytes);
+int orc_replay_cursor(const orc_env* env, int* memory_index, int* filled);
 
 /* ---- unit-level API: the reference-followed formulas, one call per SURVEY §8a row,
  *      array-in / array-out so the golden fixtures can be replayed ---- */

@@ -1,0 +1,164 @@
+"""FIFO transition memory written by the step path (include/ois.h ois_replay_*).
+
+Semantics follow the train scripts' FIFOMemory (train/train_kaddpg_4d_nofifo_random_RLIL.py:
+105-206: overwrite the row at memory_index, wrap, `filled` once the last row was written) and
+the trainer's record call (src/my_trainers/base_KA_DDPG.py:205-224: states = observation the
+action was computed from, actions = env.wheel_torqs / action_scale, next_states = observation
+returned by step()). CPU tests cover the oracle mirror; the gpu tests compare the rows the
+step kernel wrote with the oracle's, bit for bit.
+"""
+import numpy as np
+import pytest
+
+from options_in_simulation_amd import _abi, build_config
+from oracle.binding import OracleEnv
+
+NAMES = ("states", "actions", "rewards", "next_states", "terminated")
+
+
+def test_oracle_ring_rows_are_the_step_transitions():
+    N, M = 7, 5
+    cfg = build_config(variant="KA_DDPG_4D", num_envs=N, seed=4)
+    env = OracleEnv(cfg)
+    env.reset(4)
+    mem = env.attach_replay(M)
+    assert env.replay_cursor() == (0, False)
+    assert [mem[n].shape for n in NAMES] == [(M, N, 6), (M, N, 4), (M, N, 1), (M, N, 6), (M, N, 1)]
+    rng = np.random.default_rng(0)
+    log = []
+    for t in range(12):
+        prev = env.obs.copy()
+        a = rng.uniform(-1, 1, size=(N, 4)).astype(np.float32)
+        env.step(a)
+        row = t % M
+        log.append((prev, env.obs.copy(), env.rew.copy(), env.done.copy(),
+                    env.buffer(_abi.BUF_WHEEL_TORQS).copy()))
+        np.testing.assert_array_equal(mem["states"][row], prev)
+        np.testing.assert_array_equal(mem["next_states"][row], env.obs)
+        np.testing.assert_array_equal(mem["rewards"][row, :, 0], env.rew)
+        np.testing.assert_array_equal(mem["terminated"][row, :, 0], env.done)
+        # executed (mixed + clipped) torques, not the policy output (base_KA_DDPG.py:212)
+        np.testing.assert_array_equal(mem["actions"][row], env.buffer(_abi.BUF_WHEEL_TORQS) / np.float32(cfg.action_scale))
+        assert env.replay_cursor() == ((t + 1) % M, t + 1 >= M)
+    # after wrapping, rows hold the LAST M transitions in ring order
+    for t in range(12 - M, 12):
+        np.testing.assert_array_equal(mem["states"][t % M], log[t][0])
+    # the chain property: next_states of row r is states of row r+1
+    idx, _ = env.replay_cursor()
+    order = [(idx + k) % M for k in range(M)]
+    for r0, r1 in zip(order[:-1], order[1:]):
+        np.testing.assert_array_equal(mem["next_states"][r0], mem["states"][r1])
+
+
+def test_oracle_rollout_appends_one_row_per_step_and_detach_stops():
+    N, M = 33, 8
+    cfg = build_config(variant="KAMMA_medium", num_envs=N, seed=6)
+    a_env, b_env = OracleEnv(cfg), OracleEnv(cfg)
+    a_env.reset(6); b_env.reset(6)
+    ma, mb = a_env.attach_replay(M), b_env.attach_replay(M)
+    a_env.rollout(11, _abi.POLICY_RANDOM)
+    for _ in range(11):
+        b_env.rollout(1, _abi.POLICY_RANDOM)
+    assert a_env.replay_cursor() == b_env.replay_cursor() == (3, True)
+    for n in NAMES:
+        np.testing.assert_array_equal(ma[n], mb[n])
+    # the memory never influences the simulation
+    c_env = OracleEnv(cfg); c_env.reset(6); c_env.rollout(11, _abi.POLICY_RANDOM)
+    np.testing.assert_array_equal(c_env.obs, a_env.obs)
+    assert a_env.attach_replay(0) == {}
+    a_env.rollout(2, _abi.POLICY_RANDOM)
+    assert a_env.replay_cursor() == (0, False)
+    c_env.rollout(2, _abi.POLICY_RANDOM)
+    np.testing.assert_array_equal(c_env.obs, a_env.obs)
+
+
+def test_terminated_rows_carry_post_reset_observation():
+    """Isaac-style auto reset: the transition stored at a reset step has terminated=1 and
+    next_states = the observation of the NEW episode (what VecEnvBase.step returns,
+    SURVEY.md §8a note 3)."""
+    N, M = 4, 128
+    env = OracleEnv(build_config(variant="KAMMA_medium", num_envs=N, seed=2))
+    env.reset(2)
+    mem = env.attach_replay(M)
+    z = np.zeros((N, 4), np.float32)
+    for _ in range(100):
+        env.step(z)
+    term = mem["terminated"][:100, :, 0]
+    assert term[98].all() and term.sum() == N
+    np.testing.assert_array_equal(mem["next_states"][98][:, 0], mem["states"][99][:, 0])
+    assert not np.array_equal(mem["states"][98][:, 0:2], mem["next_states"][98][:, 0:2])
+
+
+# ------------------------------------------------------------------------------------- gpu
+torch = pytest.importorskip("torch")
+
+
+def _pair(**kw):
+    from options_in_simulation_amd.vecenv import NativeEnv
+    cfg = build_config(**kw)
+    return cfg, NativeEnv(cfg, "cuda:0"), OracleEnv(cfg)
+
+
+def _same(dmem, omem, where):
+    torch.cuda.synchronize()
+    for n in NAMES:
+        got = dmem[n].cpu().numpy()
+        if got.dtype == np.bool_:
+            got = got.astype(np.uint8)
+        assert np.array_equal(got, omem[n], equal_nan=True), f"{where}: replay tensor {n} differs"
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("env_vars", [{"OIS_PACKED": "0"}, {"OIS_PACKED": "1"}, {"OIS_LANES_PER_ARENA": "2"}],
+                         ids=["scalar", "packed", "lane-pair"])
+def test_kernel_written_rows_match_the_oracle(env_vars, monkeypatch):
+    for k, v in env_vars.items():
+        monkeypatch.setenv(k, v)
+    N, M = 203, 16
+    cfg, dev, orc = _pair(variant="KA_DDPG_4D", num_envs=N, seed=8, max_sim_steps=90.0)
+    dev.reset(8); orc.reset(8)
+    dmem, omem = dev.attach_replay(M), orc.attach_replay(M)
+    assert dev.replay_cursor() == (0, False)
+    rng = np.random.default_rng(2)
+    for t in range(10):
+        a = rng.uniform(-1, 1, size=(N, 4)).astype(np.float32)
+        dev.step(torch.from_numpy(a).cuda()); orc.step(a)
+    assert dev.replay_cursor() == orc.replay_cursor() == (10, False)
+    _same(dmem, omem, "10 single steps")
+    dev.rollout(9, _abi.POLICY_RANDOM); orc.rollout(9, _abi.POLICY_RANDOM)  # wraps inside one launch
+    assert dev.replay_cursor() == orc.replay_cursor() == (3, True)
+    _same(dmem, omem, "fused rollout across the wrap")
+    dev.rollout(95, _abi.POLICY_RANDOM); orc.rollout(95, _abi.POLICY_RANDOM)  # k > M; the timeout row (step 99 of 114) survives
+    assert dev.replay_cursor() == orc.replay_cursor()
+    _same(dmem, omem, "rollout longer than the memory")
+    assert dmem["terminated"].any()
+
+
+@pytest.mark.gpu
+def test_device_fifo_memory_surface():
+    from options_in_simulation_amd import VecEnv
+    from options_in_simulation_amd.replay import DeviceFIFOMemory
+    env = VecEnv(num_envs=64, device="cuda:0", variant="KA_DDPG_4D", seed=1)
+    obs, _ = env.reset()
+    mem = DeviceFIFOMemory(env, memory_size=6)
+    assert len(mem) == 0 and not mem.filled
+    with pytest.raises(RuntimeError):
+        mem.sample(["states"], 4)
+    first = obs.clone()
+    for t in range(4):
+        obs, rew, term, trunc, _ = env.step(torch.rand((64, 4), device="cuda") * 2 - 1)
+    assert len(mem) == 4 * 64 and mem.memory_index == 4
+    assert torch.equal(mem.get_tensor_by_name("states")[0], first)
+    assert torch.equal(mem.get_tensor_by_name("next_states")[3], obs)
+    assert torch.equal(mem.get_tensor_by_name("rewards")[3], rew.view(-1, 1))
+    (s, a, r, ns, d), = mem.sample(["states", "actions", "rewards", "next_states", "terminated"], batch_size=100)
+    assert s.shape == (100, 6) and a.shape == (100, 4) and r.shape == (100, 1) and d.dtype == torch.bool
+    assert len(torch.unique(mem.sampling_indexes)) == 100 and int(mem.sampling_indexes.max()) < 4 * 64
+    # executed torques are clipped to +-4 N m (KAMMA.py:649) -> |actions| <= 4 / action_scale
+    assert (a.abs() <= 4.0 / env.task.action_scale + 1e-6).all()
+    for t in range(5):
+        env.step(torch.zeros((64, 4), device="cuda"))
+    assert mem.filled and len(mem) == 6 * 64 and mem.memory_index == 3
+    mem.close()
+    env.step(torch.zeros((64, 4), device="cuda"))
+    torch.cuda.synchronize()
