@@ -277,6 +277,29 @@ int ois_replay_buffer(ois_env* env, int id, void** ptr_device, size_t* bytes);
 /* memory_index = next row to be written, filled = 1 once the index has wrapped */
 int ois_replay_cursor(const ois_env* env, int* memory_index, int* filled);
 
+/* ---- generalized advantage estimation over a rollout ----
+ * The backward recurrence the on-policy agents run in a Python loop over the rollout memory,
+ * one thread per arena here. All pointers are device memory, row-major [T, N] (the memory
+ * tensors [T, N, 1] as they are), terminated is uint8/bool, last_values is [N].
+ *   OIS_GAE_PPO  (src/my_agents/ppo.py:345-358):
+ *       adv_t = r_t - v_t + gamma*(1-term_t) * (v_{t+1} + lambda*adv_{t+1}),  v_T = last_values
+ *       returns = adv + values; then, if normalize, adv = (adv - mean(adv)) / (std(adv) + 1e-8)
+ *       with the unbiased std over all T*N entries (torch.std).
+ *   OIS_GAE_PPOC (src/my_agents/ppoc.py:325-336):
+ *       delta_t = r_t + gamma*(1-term_t)*v_{t+1} - v_t;  adv_t = delta_t + (gamma*lambda)*(1-term_t)*adv_{t+1}
+ *       returns = adv + values; the reference never normalises here (normalize may still be set).
+ * Each float operation is rounded separately, in the order the reference's expression
+ * evaluates, so the un-normalised outputs are bit-identical to the torch loop; gamma and lambda
+ * are the Python doubles (torch rounds a scalar operand to float32 when it meets a float32
+ * tensor: ppo uses f32(gamma) and f32(lambda), ppoc f32(gamma) and f32(gamma*lambda)).
+ * scratch_device: ois_gae_scratch_bytes(N) bytes, only needed when normalize != 0. */
+enum ois_gae_mode { OIS_GAE_PPO = 0, OIS_GAE_PPOC = 1 };
+size_t ois_gae_scratch_bytes(int num_envs);
+int ois_gae(int mode, int T, int num_envs, const float* rewards, const uint8_t* terminated,
+            const float* values, const float* last_values, double gamma, double lambda, int normalize,
+            float* returns_out, float* advantages_out, void* scratch_device, size_t scratch_bytes,
+            void* stream);
+
 /* Snapshot / restore the complete environment state (all persistent buffers) to/from a
  * host blob of ois_state_bytes(). Beyond reference parity (SURVEY.md §5 checkpoint). */
 size_t ois_state_bytes(const ois_env* env);

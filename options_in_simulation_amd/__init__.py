@@ -8,11 +8,17 @@ from . import _abi
 from .config import TASK_CFG, VARIANTS, build_config, default_task_cfg
 
 __all__ = ["TASK_CFG", "VARIANTS", "build_config", "default_task_cfg", "VecEnv", "TorqueDistributionTask",
-           "NativeEnv", "_abi"]
+           "NativeEnv", "DeviceFIFOMemory", "compute_gae", "compute_advantages_and_returns", "_abi"]
 
 
 def __getattr__(name):  # torch / the native library are only needed for the env classes
     if name in ("VecEnv", "TorqueDistributionTask", "NativeEnv"):
         from . import vecenv
         return getattr(vecenv, name)
+    if name == "DeviceFIFOMemory":
+        from .replay import DeviceFIFOMemory
+        return DeviceFIFOMemory
+    if name in ("compute_gae", "compute_advantages_and_returns"):
+        from . import gae
+        return getattr(gae, name)
     raise AttributeError(name)

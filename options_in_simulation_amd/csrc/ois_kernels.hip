@@ -590,6 +590,9 @@ size_t replay_layout(int N, int M, size_t off[OIS_RP_COUNT_], size_t bytes[OIS_R
 }
 }  // namespace
 
+// error sink shared with the other translation units of the library (ois_gae.hip); not exported
+extern "C" __attribute__((visibility("hidden"))) int ois_fail_(int code, const char* msg) { return fail(code, "%s", msg); }
+
 extern "C" {
 
 int ois_abi_version(void) { return OIS_ABI_VERSION; }

@@ -50,6 +50,7 @@ def lib() -> C.CDLL:
         L.orc_replay_attach.argtypes = [C.c_void_p, C.c_int]
         L.orc_replay_buffer.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.c_void_p), C.POINTER(C.c_size_t)]
         L.orc_replay_cursor.argtypes = [C.c_void_p, C.POINTER(C.c_int), C.POINTER(C.c_int)]
+        L.orc_gae.argtypes = [C.c_int, C.c_int, C.c_int, fp, u8p, fp, fp, C.c_double, C.c_double, C.c_int, fp, fp]
         L.orc_criteria.argtypes = [C.c_int, fp, fp, fp, fp] + [C.c_float] * 5 + [fp] * 4
         L.orc_criteria.restype = None
         L.orc_gamma.argtypes = [C.c_int, ip, C.c_float, fp]
@@ -106,6 +107,22 @@ _BUF_META = {
     _abi.BUF_ENV0_DIAG: (np.float32, None),
     _abi.BUF_LAMBDA_N: (np.float32, 4), _abi.BUF_LAMBDA_L: (np.float32, 4), _abi.BUF_LAMBDA_T: (np.float32, 4),
 }
+
+
+def gae(mode: int, rewards, terminated, values, last_values, gamma: float, lam: float, normalize: bool):
+    """orc_gae on numpy tensors [T, N] (or [T, N, 1]); returns (returns, advantages) shaped like rewards."""
+    shape = np.shape(rewards)
+    T = shape[0]
+    r = np.ascontiguousarray(rewards, np.float32).reshape(T, -1)
+    N = r.shape[1]
+    d = np.ascontiguousarray(np.asarray(terminated).astype(np.uint8)).reshape(T, N)
+    v = np.ascontiguousarray(values, np.float32).reshape(T, N)
+    lv = np.ascontiguousarray(last_values, np.float32).reshape(N)
+    ret, adv = np.empty_like(r), np.empty_like(r)
+    rc = lib().orc_gae(mode, T, N, fptr(r), u8ptr(d), fptr(v), fptr(lv), gamma, lam, int(normalize), fptr(ret), fptr(adv))
+    if rc != 0:
+        raise RuntimeError(f"orc_gae failed ({rc}): {lib().orc_last_error().decode()}")
+    return ret.reshape(shape), adv.reshape(shape)
 
 
 class OracleEnv:

@@ -1173,3 +1173,50 @@ int orc_randomize_params(orc_env* e, float mu_lo, float mu_hi, const float* slop
   }
   return OIS_OK;
 }
+
+/* ---- generalized advantage estimation (mirror of ois_gae) ----
+ * mode OIS_GAE_PPO:  src/my_agents/ppo.py:345-358 (compute_gae incl. the normalisation);
+ * mode OIS_GAE_PPOC: src/my_agents/ppoc.py:325-336 (compute_advantages_and_returns).
+ * Tensors are row-major [T, N]; the loops run in the reference's order (t descending, one
+ * rounding per torch op). Pinned by tests/golden/gae.npz (a torch loop transcription). */
+int orc_gae(int mode, int T, int N, const float* rew, const uint8_t* term, const float* val,
+            const float* last, double gamma, double lambda, int normalize, float* ret, float* adv) {
+  if ((mode != OIS_GAE_PPO && mode != OIS_GAE_PPOC) || T <= 0 || N <= 0) return fail(OIS_EINVAL, "bad gae argument");
+  if (!rew || !term || !val || !last || !ret || !adv) return fail(OIS_EINVAL, "null gae tensor");
+  const float g = (float)gamma;
+  const float lam = (float)lambda;           /* ppo: f32(lambda_coefficient) */
+  const float gl = (float)(gamma * lambda);  /* ppoc: the Python double product meets the tensor */
+  double s1 = 0.0, s2 = 0.0;
+  for (int i = 0; i < N; ++i) {
+    float nv = last[i];
+    float a = 0.0f;
+    for (int t = T - 1; t >= 0; --t) {
+      size_t o = (size_t)t * (size_t)N + (size_t)i;
+      float nd = term[o] ? 0.0f : 1.0f;
+      if (mode == OIS_GAE_PPO) {
+        float gi = g * nd;            /* discount_factor * not_dones[i] */
+        float inner = nv + lam * a;   /* next_values + lambda_coefficient * advantage */
+        a = (rew[o] - val[o]) + gi * inner;
+      } else {
+        float delta = (rew[o] + (g * nd) * nv) - val[o];
+        a = delta + (gl * nd) * a;
+      }
+      adv[o] = a;
+      ret[o] = a + val[o];            /* returns = advantages + values */
+      nv = val[o];
+      s1 += (double)a;
+      s2 += (double)a * (double)a;
+    }
+  }
+  if (normalize) {
+    /* (advantages - advantages.mean()) / (advantages.std() + 1e-8), unbiased std */
+    double n = (double)T * (double)N;
+    double mean = s1 / n;
+    double var = (s2 - n * mean * mean) / (n - 1.0);
+    if (var < 0.0) var = 0.0;
+    float mean_f = (float)mean;
+    float den = (float)sqrt(var) + 1e-8f;
+    for (size_t o = 0; o < (size_t)T * (size_t)N; ++o) adv[o] = (adv[o] - mean_f) / den;
+  }
+  return OIS_OK;
+}

@@ -58,6 +58,11 @@ int orc_replay_attach(orc_env* env, int memory_size);
 int orc_replay_buffer(orc_env* env, int id, void** ptr, size_t* bytes);
 int orc_replay_cursor(const orc_env* env, int* memory_index, int* filled);
 
+/* mirror of ois_gae on host tensors [T, N] (ppo.py:345-358 / ppoc.py:325-336) */
+int orc_gae(int mode, int T, int N, const float* rewards, const uint8_t* terminated, const float* values,
+            const float* last_values, double gamma, double lambda, int normalize, float* returns_out,
+            float* advantages_out);
+
 /* ---- unit-level API: the reference-followed formulas, one call per SURVEY §8a row,
  *      array-in / array-out so the golden fixtures can be replayed ---- */
 

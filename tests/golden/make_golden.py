@@ -215,6 +215,48 @@ def refmath_extras(seed=2, n=64):
 
 
 # ----------------------------------------------------------------------------------------
+def refmath_gae(seed=3, T=24, n=41, discount_factor=0.99, lambda_coefficient=0.95):
+    """Advantage estimation of the on-policy agents as torch loops over the rollout memory
+    tensors [T, N, 1]: src/my_agents/ppo.py:345-358 (with the normalisation) and
+    src/my_agents/ppoc.py:325-336. Python-double hyperparameters meet float32 tensors exactly
+    as they do there."""
+    g = torch.Generator().manual_seed(seed)
+    rewards = torch.randn((T, n, 1), generator=g) * 0.5 - 0.3
+    values = torch.randn((T, n, 1), generator=g)
+    last_values = torch.randn((n, 1), generator=g)
+    terminated = torch.rand((T, n, 1), generator=g) < 0.08
+    terminated[-1, :5] = True  # a rollout that ends on a terminal step
+    # --- ppo.py:345-358
+    advantage = 0
+    advantages = torch.zeros_like(rewards)
+    not_dones = terminated.logical_not()
+    for i in reversed(range(T)):
+        next_values = values[i + 1] if i < T - 1 else last_values
+        advantage = rewards[i] - values[i] + discount_factor * not_dones[i] * (next_values + lambda_coefficient * advantage)
+        advantages[i] = advantage
+    ppo_returns = advantages + values
+    ppo_adv_raw = advantages.clone()
+    ppo_adv = (advantages - advantages.mean()) / (advantages.std() + 1e-8)
+    # --- ppoc.py:308-336
+    term_f = terminated.float()
+    next_vals = torch.zeros_like(values)
+    next_vals[-1] = last_values
+    adv2 = torch.zeros_like(rewards)
+    gae = 0.0
+    for t in reversed(range(T)):
+        next_val = next_vals[t] if t == T - 1 else values[t + 1]
+        delta = rewards[t] + discount_factor * (1.0 - term_f[t]) * next_val - values[t]
+        gae = delta + discount_factor * lambda_coefficient * (1.0 - term_f[t]) * gae
+        adv2[t] = gae
+    ppoc_returns = adv2 + values
+    return {"rewards": rewards.numpy(), "values": values.numpy(), "last_values": last_values.numpy(),
+            "terminated": terminated.numpy(), "discount_factor": np.float64(discount_factor),
+            "lambda_coefficient": np.float64(lambda_coefficient), "ppo_returns": ppo_returns.numpy(),
+            "ppo_advantages_raw": ppo_adv_raw.numpy(), "ppo_advantages": ppo_adv.numpy(),
+            "ppoc_returns": ppoc_returns.numpy(), "ppoc_advantages": adv2.numpy()}
+
+
+# ----------------------------------------------------------------------------------------
 def trajectories():
     from oracle.binding import OracleEnv
     from tests.golden_replay import TRAJ_SPECS, run_spec
@@ -222,6 +264,9 @@ def trajectories():
 
 
 def main():
+    np.savez_compressed(os.path.join(HERE, "refmath_gae.npz"), **refmath_gae())
+    if "--gae-only" in sys.argv:
+        return
     np.savez_compressed(os.path.join(HERE, "refmath_step.npz"), **refmath_step())
     np.savez_compressed(os.path.join(HERE, "refmath_reset.npz"), **refmath_reset())
     np.savez_compressed(os.path.join(HERE, "refmath_reset_small_cmd.npz"), **refmath_reset(seed=5, n=257, cmd_x=(0.0, 0.4)))
