@@ -170,6 +170,8 @@ enum ois_buffer_id {
   OIS_BUF_LAMBDA_N = 18,   /* float [N,4]  cached normal contact impulses per wheel (solver warm start) */
   OIS_BUF_LAMBDA_L = 19,   /* float [N,4]  cached longitudinal friction impulses */
   OIS_BUF_LAMBDA_T = 20,   /* float [N,4]  cached lateral friction impulses */
+  OIS_BUF_ENV_ORIGINS = 21, /* float [N,4] env_origins xyz of the arena's terrain tile (KAMMA.py:397, 529); 0 = no terrain */
+  OIS_BUF_TERRAIN_IDX = 22, /* int32 [N,4] terrain_levels, terrain_types (KAMMA.py:342-347), -, - */
   OIS_BUF_COUNT_
 };
 
@@ -299,6 +301,42 @@ int ois_gae(int mode, int T, int num_envs, const float* rewards, const uint8_t* 
             const float* values, const float* last_values, double gamma, double lambda, int normalize,
             float* returns_out, float* advantages_out, void* scratch_device, size_t scratch_bytes,
             void* stream);
+
+/* ---- height-field terrain ----
+ * The reference builds ONE int16 height field for all robots (my_utils/origin_terrain_generator.py
+ * Terrain: tiles of mapLength x mapWidth metres, numLevels x numTerrains of them, a border
+ * around; height = raw * vertical_scale, pixel = horizontal_scale) and places robot i on the
+ * tile terrain_origins[terrain_levels[i], terrain_types[i]] (KAMMA.py:338-349, 397; every call
+ * is commented out there, the runs are on the flat plane). With a terrain attached:
+ *   - physics: each substep samples the field under the 4 wheel centres (the get_heights rule:
+ *     min of the pixel and its +1,+1 neighbour) and the wheels stand on the plane through those
+ *     4 footprints (docs/SPEC.md §3.8); OIS_BUF_PARAMS keeps mu, its plane normal is ignored;
+ *   - pose buffers stay relative to the arena's env_origin (bounds check KAMMA.py:758-759);
+ *   - curriculum != 0: update_SI_level (KAMMA.py:502-529) moves a resetting arena one level
+ *     down / up when its finished episode's r1 sum is < threshold_low / > threshold_high and
+ *     re-reads its origin from the table;
+ *   - ois_height_scan = get_heights (KAMMA.py:872-893): 140 heights per arena around the base
+ *     (grid KAMMA.py:278-292), the optional observation block of KAMMA.py:826-828.
+ * The field and the table are caller-owned device memory and must outlive the attachment. */
+#define OIS_HEIGHT_POINTS 140
+typedef struct ois_terrain {
+  uint32_t struct_bytes;     /* = sizeof(ois_terrain) */
+  int32_t rows, cols;        /* Terrain.tot_rows, tot_cols (origin_terrain_generator.py:56-58) */
+  float horizontal_scale;    /* 0.02  :39 */
+  float vertical_scale;      /* 0.006 :40 */
+  float border_size;         /* 20    :41; the field's pixel (0,0) sits at world (-border, -border) KAMMA.py:300 */
+  int32_t num_levels, num_types; /* shape of the terrain_origins table (env_rows, env_cols :48-49) */
+  int32_t curriculum;        /* terrain.curriculum KAMMA.py:265 */
+  float threshold_low, threshold_high; /* 0.3, 5.0 KAMMA.py:509-510 */
+  int32_t max_level;         /* 5 KAMMA.py:525 */
+} ois_terrain;
+/* heights_device: int16 [rows, cols]; terrain_origins_device: float [num_levels, num_types, 3];
+ * levels_types_host: int32 [N, 2] initial terrain_levels / terrain_types (host memory, copied).
+ * Call before ois_reset. terrain == NULL detaches (back to the per-arena plane). */
+int ois_terrain_attach(ois_env* env, const ois_terrain* terrain, const int16_t* heights_device,
+                       const float* terrain_origins_device, const int32_t* levels_types_host, void* stream);
+/* heights_out_device: float [N, OIS_HEIGHT_POINTS] measured_heights of the current state */
+int ois_height_scan(ois_env* env, float* heights_out_device, void* stream);
 
 /* Snapshot / restore the complete environment state (all persistent buffers) to/from a
  * host blob of ois_state_bytes(). Beyond reference parity (SURVEY.md §5 checkpoint). */

@@ -14,7 +14,8 @@ POLICY_ZERO, POLICY_RANDOM, POLICY_EXTERNAL = 0, 1, 2
 (BUF_OBS, BUF_REW, BUF_DONE, BUF_TIMEOUT, BUF_WHEEL_TORQS, BUF_POSE, BUF_QUAT, BUF_LINVEL,
  BUF_ANGVEL, BUF_WHEEL_VEL, BUF_COMMANDS, BUF_COUNTERS, BUF_SUMS_A, BUF_SUMS_B, BUF_PARAMS,
  BUF_EPISODE_INFO, BUF_ENV0_DIAG, BUF_SUMS_C, BUF_LAMBDA_N, BUF_LAMBDA_L, BUF_LAMBDA_T,
- BUF_COUNT) = range(22)
+ BUF_ENV_ORIGINS, BUF_TERRAIN_IDX, BUF_COUNT) = range(24)
+HEIGHT_POINTS = 140
 
 EPISODE_INFO_LEN = 32
 ENV0_DIAG_LEN = 32
@@ -22,6 +23,7 @@ ENV0_DIAG_LEN = 32
 # slot index inside BUF_EPISODE_INFO -> key of extras["episode"] (KAMMA.py:205-221, 470-488)
 EI_COUNT = 0
 EI_STEP = 19
+EI_TERRAIN_LEVEL = 18
 EPISODE_INFO_KEYS = {
     1: "rew_r1: Tracking error reward (squared errors)",
     2: "rew_r2: Convergence reward (squared accelerations)",
@@ -119,6 +121,16 @@ class OisConfig(C.Structure):
         ("max_angular_velocity", C.c_float),
         ("solver_iterations", C.c_int32),
         ("reserved_", C.c_int32 * 8),
+    ]
+
+
+class OisTerrain(C.Structure):
+    """mirror of `ois_terrain` (include/ois.h)"""
+    _fields_ = [
+        ("struct_bytes", C.c_uint32), ("rows", C.c_int32), ("cols", C.c_int32),
+        ("horizontal_scale", C.c_float), ("vertical_scale", C.c_float), ("border_size", C.c_float),
+        ("num_levels", C.c_int32), ("num_types", C.c_int32), ("curriculum", C.c_int32),
+        ("threshold_low", C.c_float), ("threshold_high", C.c_float), ("max_level", C.c_int32),
     ]
 
 

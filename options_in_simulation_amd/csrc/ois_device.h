@@ -32,6 +32,7 @@ struct DevConsts {
   // physics (docs/SPEC.md §3)
   float dt, inv_dt, gdt, half_dt, im4, J4x, J4y, J4z, dt_over_Is, dt_over_Iy, rw, rw_over_Is,
       rw2_over_Is, beta_inv_dt, vdep, maxw, maxw2, damping, wx, wy, cz, com_height;
+  float inv4wx, inv4wy;  // 1 / (4 wx), 1 / (4 wy): footprint-plane fit of the terrain contact (SPEC §3.8)
   int iters, nsub;
   // task (KAMMA.py constants, see include/ois.h)
   float Kp, Kp_omega, vehicle_mass, vehicle_inertia, policy_dt, action_scale, torque_clip, w1, w2,
@@ -44,6 +45,14 @@ struct DevConsts {
       max_episode_length;
   uint32_t seed_lo, seed_hi;
   int64_t arena_offset;
+};
+
+// height-field terrain (include/ois.h ois_terrain_attach); on == 0: the per-arena plane of `params`
+struct DevTerrain {
+  const int16_t* h;        // [rows][cols] raw heights (caller-owned)
+  const float* origins;    // [levels][types][3] terrain_origins table (caller-owned)
+  int rows, cols, ntypes, max_level, curriculum, on;
+  float inv_hs, hs, vs, border, thr_lo, thr_hi;
 };
 
 // device pointers of one environment ([N][4] unless noted)
@@ -64,6 +73,10 @@ struct DevBuffers {
   float *rp_states, *rp_actions, *rp_rewards, *rp_next;  // [M][N][6|4|1|6]
   uint8_t* rp_done;                                      // [M][N]
   int rp_size;
+  // terrain: per-arena tile origin (xyz) and (level, type) index
+  float4* env_origins;
+  int4* terrain_idx;
+  DevTerrain ter;
 };
 
 // ---------------------------------------------------------------- RNG -----------------

@@ -13,6 +13,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <vector>
 #include <new>
 
 #include "ois_physics_pk.h"
@@ -86,7 +87,7 @@ OIS_DEV void store_arena(const DevConsts& K, const DevBuffers& B, int i, int h, 
 }
 
 // ------------------------------------------------------------------ the step kernel ---
-template <int LPA, bool PK>
+template <int LPA, bool PK, bool TER>
 __global__ OIS_STEP_BOUNDS void step_kernel(DevConsts K, DevBuffers B, const float* __restrict__ actions,
                                                       float* __restrict__ reward_sum, int N, int ksteps, int policy,
                                                       int rp_head) {
@@ -104,6 +105,15 @@ __global__ OIS_STEP_BOUNDS void step_kernel(DevConsts K, DevBuffers B, const flo
   ArenaT<LPA> S;
   load_arena<LPA>(K, B, la, h, S);
   float rsum = 0.0f;
+  // terrain tile of this arena (origin xyz; level / type for the curriculum)
+  float tor[3] = {0.0f, 0.0f, 0.0f};
+  int tlevel = 0, ttype = 0;
+  if constexpr (TER) {
+    const float4 eo = B.env_origins[la];
+    const int4 ti = B.terrain_idx[la];
+    tor[0] = eo.x; tor[1] = eo.y; tor[2] = eo.z;
+    tlevel = ti.x; ttype = ti.y;
+  }
   // FIFO transition memory: "states" of the first appended row = the observation the caller saw
   float o_prev[6] = {0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f};
   if (B.rp_size > 0) {
@@ -202,12 +212,14 @@ __global__ OIS_STEP_BOUNDS void step_kernel(DevConsts K, DevBuffers B, const flo
         X.ln[k] = S.ln[k]; X.l1[k] = S.l1[k]; X.l2[k] = S.l2[k];
       }
       X.mu = S.mu;
+#pragma unroll
+      for (int k = 0; k < 3; ++k) X.to[k] = tor[k];
       if constexpr (PK && LPA == 1) {  // packed fp32 over wheel pairs (ois_physics_pk.h)
-        substep_pk<true>(K, X);
-        for (int i = 1; i < K.nsub; ++i) substep_pk<false>(K, X);
+        substep_pk<true, TER>(K, B.ter, X);
+        for (int i = 1; i < K.nsub; ++i) substep_pk<false, TER>(K, B.ter, X);
       } else {
-        substep<true, LPA>(K, wheel0, X);
-        for (int i = 1; i < K.nsub; ++i) substep<false, LPA>(K, wheel0, X);
+        substep<true, LPA, TER>(K, B.ter, wheel0, X);
+        for (int i = 1; i < K.nsub; ++i) substep<false, LPA, TER>(K, B.ter, wheel0, X);
       }
       rotmat(X.q, R);
       rot(R, X.wb, S.w);  // body -> world with the final orientation
@@ -257,6 +269,15 @@ __global__ OIS_STEP_BOUNDS void step_kernel(DevConsts K, DevBuffers B, const flo
     ResetContrib rc;
     contrib_identity(rc);
     const bool do_reset = reset && valid;
+    if constexpr (TER) {
+      if (reset && B.ter.curriculum) {
+        // update_SI_level (KAMMA.py:502-529) on the finished episode's r1 sum, then the new tile origin
+        if (S.sa[0] < B.ter.thr_lo) tlevel = tlevel - 1 < 0 ? 0 : tlevel - 1;
+        if (S.sa[0] > B.ter.thr_hi) tlevel = tlevel + 1 > B.ter.max_level ? B.ter.max_level : tlevel + 1;
+        const float* o = B.ter.origins + ((size_t)tlevel * B.ter.ntypes + ttype) * 3;
+        tor[0] = o[0]; tor[1] = o[1]; tor[2] = o[2];  // :529
+      }
+    }
     if (reset) reset_arena<LPA>(K, gid, wheel0, gamma1, gamma2, S, rc);
     if (!valid) contrib_identity(rc);
     // get_observations (:833); desired_* are views of commands -> post-reset values; clamp: rl_task.py:99
@@ -315,7 +336,47 @@ __global__ OIS_STEP_BOUNDS void step_kernel(DevConsts K, DevBuffers B, const flo
   if (valid) {
     store_arena<LPA>(K, B, arena, h, S);
     if (reward_sum != nullptr && h == 0) reward_sum[arena] = rsum;
+    if constexpr (TER) {
+      if (B.ter.curriculum) {
+        B.env_origins[arena] = make_float4(tor[0], tor[1], tor[2], 0.0f);
+        B.terrain_idx[arena] = make_int4(tlevel, ttype, 0, 0);
+      }
+    }
   }
+}
+
+// ------------------------------------------------------------------ get_heights -------
+// KAMMA.py:872-893: one thread per (arena, point); the 140 points of an arena are consecutive
+// threads, so the output rows are written coalesced. Mirrors oracle orc_get_heights.
+__global__ __launch_bounds__(256) void height_scan_kernel(DevConsts K, DevBuffers B, int N, float* __restrict__ out) {
+  const size_t t = (size_t)blockIdx.x * 256 + threadIdx.x;
+  if (t >= (size_t)N * OIS_HEIGHT_POINTS) return;
+  const int i = (int)(t / OIS_HEIGHT_POINTS), pt = (int)(t % OIS_HEIGHT_POINTS);
+  const int a = pt / 10, b = pt % 10;
+  const int gx = a < 7 ? a - 8 : a - 5;   // -8..-2, 2..8   (KAMMA.py:283-285)
+  const int gy = b < 5 ? b - 5 : b - 4;   // -5..-1, 1..5   (KAMMA.py:280-282)
+  const float4 po = B.pose[i], qu = B.quat[i], eo = B.env_origins[i];
+  const float q[4] = {qu.x, qu.y, qu.z, qu.w};
+  float R[9];
+  rotmat(q, R);
+  // base-link position in the world = arena-local COM - R com + tile origin
+  const float pwx = __builtin_fmaf(-R[2], K.com_height, po.x) + eo.x;
+  const float pwy = __builtin_fmaf(-R[5], K.com_height, po.y) + eo.y;
+  float nrm = sqrtf(qu.x * qu.x + qu.w * qu.w);  // quat_apply_yaw: x, y zeroed, then normalize (:895-899)
+  nrm = fmaxf(nrm, 1e-9f);
+  const float qw = qu.x / nrm, qz = qu.w / nrm;
+  const float bx = 0.1f * (float)gx, by = 0.1f * (float)gy;
+  const float tx = -(qz * by) * 2.0f, ty = (qz * bx) * 2.0f;
+  const float cx = -(qz * ty), cy = qz * tx;
+  float X = (bx + qw * tx) + cx, Y = (by + qw * ty) + cy;
+  X += pwx; Y += pwy;                       // :878
+  X += B.ter.border; Y += B.ter.border;     // :882
+  float fx = X / B.ter.hs, fy = Y / B.ter.hs;  // :883
+  fx = fminf(fmaxf(fx, 0.0f), (float)(B.ter.rows - 2));  // :886-887
+  fy = fminf(fmaxf(fy, 0.0f), (float)(B.ter.cols - 2));
+  const int px = (int)fx, py = (int)fy;
+  const int16_t h1 = B.ter.h[(size_t)px * B.ter.cols + py], h2 = B.ter.h[(size_t)(px + 1) * B.ter.cols + (py + 1)];
+  out[t] = (float)(h1 < h2 ? h1 : h2) * B.ter.vs;  // :889-893
 }
 
 // ------------------------------------------------------------------ post_reset --------
@@ -390,9 +451,14 @@ __global__ void randomize_params_kernel(DevConsts K, DevBuffers B, int N, float 
 
 // extras["episode"] (KAMMA.py:480-488): deterministic in-order sum of the per-wave records
 // of the most recent reset event. One block of 64 threads; thread t owns record slot t.
-__global__ __launch_bounds__(64) void episode_info_kernel(DevConsts K, DevBuffers B, int nwaves) {
+__global__ __launch_bounds__(64) void episode_info_kernel(DevConsts K, DevBuffers B, int nwaves, int N) {
   __shared__ float acc[32];
+  __shared__ long long lsum[64];
   const int t = threadIdx.x;
+  // :488 torch.mean(terrain_levels.float()) over ALL arenas (integer sum: exact and order-free)
+  long long ls = 0;
+  if (B.ter.on) for (int i = t; i < N; i += 64) ls += B.terrain_idx[i].x;
+  lsum[t] = ls;
   int smax = -1;
   for (int w = 0; w < nwaves; ++w) smax = max(smax, B.stamps[w]);
   if (t < 32) {
@@ -424,7 +490,9 @@ __global__ __launch_bounds__(64) void episode_info_kernel(DevConsts K, DevBuffer
     }
     I[OIS_EI_GAMMA1] = acc[24];       // :486
     I[OIS_EI_GAMMA2] = acc[25];       // :487
-    I[OIS_EI_TERRAIN_LEVEL] = 0.0f;   // :488 (terrain_levels are zeros, :223)
+    long long tot = 0;
+    for (int k = 0; k < 64; ++k) tot += lsum[k];
+    I[OIS_EI_TERRAIN_LEVEL] = (float)tot / (float)N;  // :488 (zeros without a terrain, :223)
     I[OIS_EI_STEP] = (float)smax;
   }
 }
@@ -479,6 +547,7 @@ Layout make_layout(int N) {
   put(OIS_BUF_SUMS_A, f4); put(OIS_BUF_SUMS_B, f4); put(OIS_BUF_SUMS_C, f4); put(OIS_BUF_PARAMS, f4);
   put(OIS_BUF_LAMBDA_N, f4); put(OIS_BUF_LAMBDA_L, f4); put(OIS_BUF_LAMBDA_T, f4);
   put(OIS_BUF_WHEEL_TORQS, f4);
+  put(OIS_BUF_ENV_ORIGINS, f4); put(OIS_BUF_TERRAIN_IDX, f4);
   put(OIS_BUF_OBS, (size_t)N * 6 * sizeof(float));
   put(OIS_BUF_REW, (size_t)N * sizeof(float));
   put(OIS_BUF_DONE, (size_t)N);
@@ -537,6 +606,8 @@ void derive(const ois_config* c, DevConsts* K) {
   K->wy = c->wheel_pos[1];
   K->cz = c->wheel_pos[2] - c->com_height;
   K->com_height = c->com_height;
+  K->inv4wx = 1.0f / (4.0f * c->wheel_pos[0]);
+  K->inv4wy = 1.0f / (4.0f * c->wheel_pos[1]);
   K->iters = c->solver_iterations;
   K->nsub = c->decimation + c->extra_substeps;
   K->Kp = c->Kp; K->Kp_omega = c->Kp_omega; K->vehicle_mass = c->vehicle_mass; K->vehicle_inertia = c->vehicle_inertia;
@@ -704,6 +775,8 @@ int ois_create(const ois_config* cfg, int device, void* workspace_device, size_t
   B.episode_info = (float*)(w + L.off[OIS_BUF_EPISODE_INFO]); B.env0_diag = (float*)(w + L.off[OIS_BUF_ENV0_DIAG]);
   B.partials = (float*)(w + L.partials); B.stamps = (int32_t*)(w + L.stamps); B.stat_acc = (float*)(w + L.stat_acc);
   B.rp_states = B.rp_actions = B.rp_rewards = B.rp_next = nullptr; B.rp_done = nullptr; B.rp_size = 0;
+  B.env_origins = (float4*)(w + L.off[OIS_BUF_ENV_ORIGINS]); B.terrain_idx = (int4*)(w + L.off[OIS_BUF_TERRAIN_IDX]);
+  std::memset(&B.ter, 0, sizeof B.ter);
   e->rp_mem = nullptr; e->rp_head = 0; e->rp_filled = false;
   // default per-arena parameters: mu = cfg.friction, flat plane n = +z
   hipError_t he = hipMemsetAsync(e->ws, 0, L.total, nullptr);
@@ -738,14 +811,21 @@ int ois_reset(ois_env* e, uint64_t seed, void* stream) {
 
 static int launch_steps(ois_env* e, int k, int policy, const float* actions, float* reward_sum, void* stream) {
   HIP_TRY(hipSetDevice(e->device));
-  if (e->lpa == 2) {
-    hipLaunchKernelGGL((step_kernel<2, false>), dim3((2 * e->N + kBlock - 1) / kBlock), dim3(kBlock), 0,
+  if (e->B.ter.on) {  // height-field terrain: the one-lane-per-arena instantiations (ois_terrain_attach refuses LPA = 2)
+    if (e->packed)
+      hipLaunchKernelGGL((step_kernel<1, true, true>), dim3(e->grid), dim3(kBlock), 0, (hipStream_t)stream, e->K, e->B,
+                         actions, reward_sum, e->N, k, policy, e->rp_head);
+    else
+      hipLaunchKernelGGL((step_kernel<1, false, true>), dim3(e->grid), dim3(kBlock), 0, (hipStream_t)stream, e->K, e->B,
+                         actions, reward_sum, e->N, k, policy, e->rp_head);
+  } else if (e->lpa == 2) {
+    hipLaunchKernelGGL((step_kernel<2, false, false>), dim3((2 * e->N + kBlock - 1) / kBlock), dim3(kBlock), 0,
                        (hipStream_t)stream, e->K, e->B, actions, reward_sum, e->N, k, policy, e->rp_head);
   } else if (e->packed) {
-    hipLaunchKernelGGL((step_kernel<1, true>), dim3(e->grid), dim3(kBlock), 0, (hipStream_t)stream, e->K, e->B, actions,
+    hipLaunchKernelGGL((step_kernel<1, true, false>), dim3(e->grid), dim3(kBlock), 0, (hipStream_t)stream, e->K, e->B, actions,
                        reward_sum, e->N, k, policy, e->rp_head);
   } else {
-    hipLaunchKernelGGL((step_kernel<1, false>), dim3(e->grid), dim3(kBlock), 0, (hipStream_t)stream, e->K, e->B, actions,
+    hipLaunchKernelGGL((step_kernel<1, false, false>), dim3(e->grid), dim3(kBlock), 0, (hipStream_t)stream, e->K, e->B, actions,
                        reward_sum, e->N, k, policy, e->rp_head);
   }
   HIP_TRY(hipGetLastError());
@@ -797,11 +877,65 @@ int ois_randomize_params(ois_env* e, float mu_lo, float mu_hi, const float* slop
   return OIS_OK;
 }
 
+int ois_terrain_attach(ois_env* e, const ois_terrain* t, const int16_t* heights_device,
+                       const float* terrain_origins_device, const int32_t* levels_types_host, void* stream) {
+  if (!e) return fail(OIS_EINVAL, "null env");
+  HIP_TRY(hipSetDevice(e->device));
+  hipStream_t s = (hipStream_t)stream;
+  const size_t f4 = (size_t)e->N * 4 * sizeof(float);
+  if (!t) {  // detach: back to the per-arena plane, origins and indices cleared
+    std::memset(&e->B.ter, 0, sizeof e->B.ter);
+    HIP_TRY(hipMemsetAsync(e->B.env_origins, 0, f4, s));
+    HIP_TRY(hipMemsetAsync(e->B.terrain_idx, 0, f4, s));
+    return OIS_OK;
+  }
+  if (t->struct_bytes != sizeof(ois_terrain)) return fail(OIS_EINVAL, "ois_terrain.struct_bytes does not match this library");
+  if (t->rows < 2 || t->cols < 2 || !(t->horizontal_scale > 0.0f) || t->num_levels < 1 || t->num_types < 1 ||
+      t->max_level < 0 || t->max_level >= t->num_levels || !heights_device || !terrain_origins_device || !levels_types_host)
+    return fail(OIS_EINVAL, "bad terrain description");
+  if (e->lpa != 1) return fail(OIS_EINVAL, "the terrain contact needs one lane per arena (unset OIS_LANES_PER_ARENA)");
+  // per-arena origin = terrain_origins[level, type] (KAMMA.py:397): built on the host from the
+  // caller's table, so the table is read back once
+  const size_t no = (size_t)t->num_levels * t->num_types * 3;
+  std::vector<float> tab(no), org((size_t)e->N * 4, 0.0f);
+  std::vector<int32_t> idx((size_t)e->N * 4, 0);
+  HIP_TRY(hipMemcpyAsync(tab.data(), terrain_origins_device, no * sizeof(float), hipMemcpyDeviceToHost, s));
+  HIP_TRY(hipStreamSynchronize(s));
+  for (int i = 0; i < e->N; ++i) {
+    const int lvl = levels_types_host[2 * i], typ = levels_types_host[2 * i + 1];
+    if (lvl < 0 || lvl >= t->num_levels || typ < 0 || typ >= t->num_types) return fail(OIS_EINVAL, "terrain level / type out of range");
+    idx[(size_t)4 * i] = lvl; idx[(size_t)4 * i + 1] = typ;
+    for (int k = 0; k < 3; ++k) org[(size_t)4 * i + k] = tab[((size_t)lvl * t->num_types + typ) * 3 + k];
+  }
+  HIP_TRY(hipMemcpyAsync(e->B.env_origins, org.data(), f4, hipMemcpyHostToDevice, s));
+  HIP_TRY(hipMemcpyAsync(e->B.terrain_idx, idx.data(), f4, hipMemcpyHostToDevice, s));
+  HIP_TRY(hipStreamSynchronize(s));
+  DevTerrain& T = e->B.ter;
+  T.h = heights_device; T.origins = terrain_origins_device;
+  T.rows = t->rows; T.cols = t->cols; T.ntypes = t->num_types; T.max_level = t->max_level;
+  T.curriculum = t->curriculum; T.on = 1;
+  T.hs = t->horizontal_scale; T.inv_hs = 1.0f / t->horizontal_scale; T.vs = t->vertical_scale; T.border = t->border_size;
+  T.thr_lo = t->threshold_low; T.thr_hi = t->threshold_high;
+  return OIS_OK;
+}
+
+int ois_height_scan(ois_env* e, float* heights_out_device, void* stream) {
+  if (!e || !heights_out_device) return fail(OIS_EINVAL, "null argument");
+  if (!e->B.ter.on) return fail(OIS_ESTATE, "ois_height_scan needs an attached terrain");
+  if (!e->reset_done) return fail(OIS_ESTATE, "ois_height_scan called before ois_reset");
+  HIP_TRY(hipSetDevice(e->device));
+  const size_t pts = (size_t)e->N * OIS_HEIGHT_POINTS;
+  hipLaunchKernelGGL(height_scan_kernel, dim3((unsigned)((pts + 255) / 256)), dim3(256), 0, (hipStream_t)stream, e->K, e->B,
+                     e->N, heights_out_device);
+  HIP_TRY(hipGetLastError());
+  return OIS_OK;
+}
+
 int ois_episode_info(ois_env* e, void* stream) {
   if (!e) return fail(OIS_EINVAL, "null env");
   if (!e->reset_done) return fail(OIS_ESTATE, "ois_episode_info called before ois_reset");
   HIP_TRY(hipSetDevice(e->device));
-  hipLaunchKernelGGL(episode_info_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, e->K, e->B, e->L.nwaves);
+  hipLaunchKernelGGL(episode_info_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, e->K, e->B, e->L.nwaves, e->N);
   HIP_TRY(hipGetLastError());
   return OIS_OK;
 }

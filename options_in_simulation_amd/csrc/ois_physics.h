@@ -27,17 +27,74 @@ struct PhysT {
   float spin[WPL];         // absolute wheel spins about the body y axis
   float ln[WPL], l1[WPL], l2[WPL];         // accumulated normal / longitudinal / lateral impulses
   float mn[WPL], m1[WPL], m2[WPL], inv_s;  // reciprocal cache (SPEC §3.6), valid inside one policy step
+  float to[3];             // origin of the arena's terrain tile (only read by the TER instantiations)
+  // wheel footprints sampled at the start of the previous substep (TER only, SPEC §3.8)
+  float fwx[4], fwy[4], fh[4], fr00, fr10, fr01, fr11;
 };
 
-// One Newton step from the previous substep's value: mul/fma only, bit-reproducible.
+// One Newton step from the previous substep's value: mul/fma only, bit-reproducible. The
+// correction is clamped (one v_med3_f32): inside the band it is the Newton step, outside (the
+// contact geometry jumped between two substeps, e.g. a tumbling robot) the cached value moves
+// at most 50 % and stays positive instead of overshooting to a negative gain.
 OIS_DEV float newton_rcp(float m, float k) {  // m ~ 1/k -> m (2 - k m)
-  const float e = __builtin_fmaf(-k, m, 1.0f);
+  const float e = __builtin_amdgcn_fmed3f(__builtin_fmaf(-k, m, 1.0f), -0.5f, 0.5f);
   return __builtin_fmaf(m, e, m);
 }
 OIS_DEV float newton_rsqrt(float r, float s2) {  // r ~ 1/sqrt(s2) -> r (1.5 - 0.5 s2 r^2)
   const float hr = (0.5f * s2) * r;
-  const float e = __builtin_fmaf(-hr, r, 1.5f);
+  const float e = __builtin_amdgcn_fmed3f(__builtin_fmaf(-hr, r, 1.5f), 0.5f, 1.5f);
   return r * e;
+}
+
+// ---- height-field terrain (docs/SPEC.md §3.8), mirrors oracle/ois_oracle.c terrain_height / terrain_plane ----
+// ground height at world (x, y): get_heights' sampling rule (KAMMA.py:882-893) with the division
+// by horizontal_scale replaced by a multiplication; positions are clamped before the int
+// conversion, so no index can leave the field whatever the state (NaN clamps to 0)
+OIS_DEV float terrain_height(const DevTerrain& T, float x, float y) {
+  float fx = (x + T.border) * T.inv_hs, fy = (y + T.border) * T.inv_hs;
+  fx = fminf(fmaxf(fx, 0.0f), (float)(T.rows - 2));
+  fy = fminf(fmaxf(fy, 0.0f), (float)(T.cols - 2));
+  const int px = (int)fx, py = (int)fy;
+  const int16_t h1 = T.h[(size_t)px * T.cols + py], h2 = T.h[(size_t)(px + 1) * T.cols + (py + 1)];
+  return (float)(h1 < h2 ? h1 : h2) * T.vs;
+}
+// footprints of the 4 wheels at the current pose: world xy under the wheel centres and the field
+// height there (8 gathers, issued here, consumed one substep later)
+struct Footprints {
+  float wx[4], wy[4], h[4], r00, r10, r01, r11;
+};
+OIS_DEV void terrain_footprints(const DevConsts& K, const DevTerrain& T, const float* origin, const float* p,
+                                const float* R, Footprints& F) {
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    const float cx = (k & 1) ? -K.wx : K.wx, cy = (k & 2) ? -K.wy : K.wy;
+    F.wx[k] = __builtin_fmaf(R[2], K.cz, __builtin_fmaf(R[1], cy, __builtin_fmaf(R[0], cx, p[0])));
+    F.wy[k] = __builtin_fmaf(R[5], K.cz, __builtin_fmaf(R[4], cy, __builtin_fmaf(R[3], cx, p[1])));
+    F.h[k] = terrain_height(T, F.wx[k] + origin[0], F.wy[k] + origin[1]) - origin[2];
+  }
+  F.r00 = R[0]; F.r10 = R[3]; F.r01 = R[1]; F.r11 = R[4];
+}
+template <int LPA>
+OIS_DEV void footprints_store(PhysT<LPA>& S, const Footprints& F) {
+#pragma unroll
+  for (int k = 0; k < 4; ++k) { S.fwx[k] = F.wx[k]; S.fwy[k] = F.wy[k]; S.fh[k] = F.h[k]; }
+  S.fr00 = F.r00; S.fr10 = F.r10; S.fr01 = F.r01; S.fr11 = F.r11;
+}
+// plane through the stored footprints: unit normal n (world), off[k] = n . footprint_k
+template <int LPA>
+OIS_DEV void terrain_plane(const DevConsts& K, const PhysT<LPA>& S, float* n, float* off) {
+  const float* h = S.fh;
+  const float g1 = ((h[0] + h[2]) - (h[1] + h[3])) * K.inv4wx;  // front - rear (order fl, rl, fr, rr)
+  const float g2 = ((h[0] + h[1]) - (h[2] + h[3])) * K.inv4wy;  // left - right
+  const float nx = __builtin_fmaf(S.fr10, g2, -(g1 * S.fr11));
+  const float ny = __builtin_fmaf(g1, S.fr01, -(S.fr00 * g2));
+  const float nz = __builtin_fmaf(S.fr00, S.fr11, -(S.fr10 * S.fr01));
+  const float nn = fmaxf(__builtin_fmaf(nz, nz, __builtin_fmaf(ny, ny, nx * nx)), 1e-12f);
+  float inv = 1.0f / sqrtf(nn);
+  if (nz < 0.0f) inv = -inv;  // rolled over (body z points down): the ground's normal still points up
+  n[0] = nx * inv; n[1] = ny * inv; n[2] = nz * inv;
+#pragma unroll
+  for (int k = 0; k < 4; ++k) off[k] = __builtin_fmaf(n[2], h[k], __builtin_fmaf(n[1], S.fwy[k], n[0] * S.fwx[k]));
 }
 
 // 0.25 * ((c0 + c1) + (c2 + c3)) over the per-contact copies of one velocity component
@@ -47,15 +104,25 @@ OIS_DEV float average4(const float (&c)[4 / LPA]) { return 0.25f * sum_wheels<LP
 // EXACT: first substep of a policy step (IEEE divisions); otherwise the reciprocals are
 // refreshed from the cache. wheel0 = index of this lane's first wheel (0, or 2 for the
 // right-side lane when LPA = 2).
-template <bool EXACT, int LPA>
-OIS_DEV void substep(const DevConsts& K, int wheel0, PhysT<LPA>& S) {
+template <bool EXACT, int LPA, bool TER = false>
+OIS_DEV void substep(const DevConsts& K, const DevTerrain& T, int wheel0, PhysT<LPA>& S) {
+  static_assert(!TER || LPA == 1, "the terrain contact needs all 4 wheels in one lane");
   constexpr int W = 4 / LPA;
 #define OIS_WH _Pragma("unroll") for (int k = 0; k < W; ++k)
   float R[9];
   rotmat(S.q, R);
   float vb[3], nb[3], wb[3] = {S.wb[0], S.wb[1], S.wb[2]};
+  float n[3] = {S.n[0], S.n[1], S.n[2]}, off[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+  Footprints cur;
+  if constexpr (TER) {
+    // fit the plane to the footprints sampled one substep earlier (the first substep of a policy
+    // step samples its own): this substep's 8 gathers stay in flight during the whole solve
+    terrain_footprints(K, T, S.to, S.p, R, cur);
+    if (EXACT) footprints_store(S, cur);
+    terrain_plane(K, S, n, off);
+  }
   rotT(R, S.v, vb);
-  rotT(R, S.n, nb);
+  rotT(R, n, nb);
   // gravity (world -z) in the body frame
   vb[0] = __builtin_fmaf(-K.gdt, R[6], vb[0]);
   vb[1] = __builtin_fmaf(-K.gdt, R[7], vb[1]);
@@ -72,14 +139,15 @@ OIS_DEV void substep(const DevConsts& K, int wheel0, PhysT<LPA>& S) {
   // contact frame shared by the four wheels (common axle direction = body y)
   float s2 = __builtin_fmaf(nb[2], nb[2], nb[0] * nb[0]);
   s2 = fmaxf(s2, 1e-12f);
-  const float inv_s = EXACT ? 1.0f / sqrtf(s2) : newton_rsqrt(S.inv_s, s2);
+  constexpr bool REX = EXACT || TER;  // on a height field the geometry may jump: exact reciprocals every substep
+  const float inv_s = REX ? 1.0f / sqrtf(s2) : newton_rsqrt(S.inv_s, s2);
   S.inv_s = inv_s;
   const float dx = -(nb[0] * inv_s), dz = -(nb[2] * inv_s);
   const float t1x = -dz, t1z = dx;
   const float t2x = nb[1] * t1z;
   const float t2y = __builtin_fmaf(nb[2], t1x, -(nb[0] * t1z));
   const float t2z = -(nb[1] * t1x);
-  const float np = __builtin_fmaf(S.n[2], S.p[2], __builtin_fmaf(S.n[1], S.p[1], S.n[0] * S.p[0]));
+  const float np = __builtin_fmaf(n[2], S.p[2], __builtin_fmaf(n[1], S.p[1], n[0] * S.p[0]));
   const float cz = K.cz;
   float b[W], an[W][3], a1[W][3], a2[W][3], Jan[W][3], Ja1[W][3], Ja2[W][3];
   float (&mn)[W] = S.mn, (&m1)[W] = S.m1, (&m2)[W] = S.m2;
@@ -89,7 +157,7 @@ OIS_DEV void substep(const DevConsts& K, int wheel0, PhysT<LPA>& S) {
     const float cx = (k & 1) ? -K.wx : K.wx;  // wheel0 is even: parity of gk = parity of k
     const float cy = (gk & 2) ? -K.wy : K.wy;
     const float rx = __builtin_fmaf(K.rw, dx, cx), ry = cy, rz = __builtin_fmaf(K.rw, dz, cz);
-    const float gap = np + __builtin_fmaf(nb[2], rz, __builtin_fmaf(nb[1], ry, nb[0] * rx));
+    const float gap = (TER ? np - off[k] : np) + __builtin_fmaf(nb[2], rz, __builtin_fmaf(nb[1], ry, nb[0] * rx));
     b[k] = gap >= 0.0f ? -(gap * K.inv_dt) : fminf(-(gap * K.beta_inv_dt), K.vdep);
     an[k][0] = __builtin_fmaf(ry, nb[2], -(rz * nb[1]));
     an[k][1] = __builtin_fmaf(rz, nb[0], -(rx * nb[2]));
@@ -106,9 +174,9 @@ OIS_DEV void substep(const DevConsts& K, int wheel0, PhysT<LPA>& S) {
     const float kn = __builtin_fmaf(an[k][2], Jan[k][2], __builtin_fmaf(an[k][1], Jan[k][1], __builtin_fmaf(an[k][0], Jan[k][0], K.im4)));
     const float k1 = __builtin_fmaf(a1[k][2], Ja1[k][2], __builtin_fmaf(a1[k][1], Ja1[k][1], __builtin_fmaf(a1[k][0], Ja1[k][0], K.im4))) + K.rw2_over_Is;
     const float k2 = __builtin_fmaf(a2[k][2], Ja2[k][2], __builtin_fmaf(a2[k][1], Ja2[k][1], __builtin_fmaf(a2[k][0], Ja2[k][0], K.im4)));
-    mn[k] = EXACT ? 1.0f / kn : newton_rcp(mn[k], kn);
-    m1[k] = EXACT ? 1.0f / k1 : newton_rcp(m1[k], k1);
-    m2[k] = EXACT ? 1.0f / k2 : newton_rcp(m2[k], k2);
+    mn[k] = REX ? 1.0f / kn : newton_rcp(mn[k], kn);
+    m1[k] = REX ? 1.0f / k1 : newton_rcp(m1[k], k1);
+    m2[k] = REX ? 1.0f / k2 : newton_rcp(m2[k], k2);
   }
   const float vnx = K.im4 * nb[0], vny = K.im4 * nb[1], vnz = K.im4 * nb[2];
   const float v1x = K.im4 * t1x, v1z = K.im4 * t1z;
@@ -204,6 +272,7 @@ OIS_DEV void substep(const DevConsts& K, int wheel0, PhysT<LPA>& S) {
   float inv = __builtin_fmaf(-0.5f, nn, 1.5f);
   if (fabsf(nn - 1.0f) > 1e-3f) inv = 1.0f / sqrtf(nn);
   S.q[0] = nqw * inv; S.q[1] = nqx * inv; S.q[2] = nqy * inv; S.q[3] = nqz * inv;
+  if constexpr (TER) footprints_store(S, cur);
 #undef OIS_WH
 }
 

@@ -37,19 +37,28 @@ OIS_DEV f2 clamp2(f2 x, f2 lim) {
   r.y = __builtin_amdgcn_fmed3f(x.y, -lim.y, lim.y);
   return r;
 }
-OIS_DEV f2 newton_rcp2(f2 m, f2 k) {
-  const f2 e = fma2(-k, m, 1.0f);
+OIS_DEV f2 newton_rcp2(f2 m, f2 k) {  // newton_rcp per element (clamped correction, see ois_physics.h)
+  f2 e = fma2(-k, m, 1.0f);
+  e.x = __builtin_amdgcn_fmed3f(e.x, -0.5f, 0.5f);
+  e.y = __builtin_amdgcn_fmed3f(e.y, -0.5f, 0.5f);
   return fma2(m, e, m);
 }
 
-template <bool EXACT>
-OIS_DEV void substep_pk(const DevConsts& K, PhysT<1>& S) {
+template <bool EXACT, bool TER = false>
+OIS_DEV void substep_pk(const DevConsts& K, const DevTerrain& T, PhysT<1>& S) {
 #define OIS_PR _Pragma("unroll") for (int j = 0; j < 2; ++j)
   float R[9];
   rotmat(S.q, R);
   float vb[3], nb[3], wb[3] = {S.wb[0], S.wb[1], S.wb[2]};
+  float n[3] = {S.n[0], S.n[1], S.n[2]}, off[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+  Footprints cur;
+  if constexpr (TER) {  // one-substep-lagged footprints, see substep<> in ois_physics.h
+    terrain_footprints(K, T, S.to, S.p, R, cur);
+    if (EXACT) footprints_store(S, cur);
+    terrain_plane(K, S, n, off);
+  }
   rotT(R, S.v, vb);
-  rotT(R, S.n, nb);
+  rotT(R, n, nb);
   vb[0] = __builtin_fmaf(-K.gdt, R[6], vb[0]);
   vb[1] = __builtin_fmaf(-K.gdt, R[7], vb[1]);
   vb[2] = __builtin_fmaf(-K.gdt, R[8], vb[2]);
@@ -71,14 +80,15 @@ OIS_DEV void substep_pk(const DevConsts& K, PhysT<1>& S) {
   // contact frame shared by the four wheels (common axle direction = body y)
   float s2 = __builtin_fmaf(nb[2], nb[2], nb[0] * nb[0]);
   s2 = fmaxf(s2, 1e-12f);
-  const float inv_s = EXACT ? 1.0f / sqrtf(s2) : newton_rsqrt(S.inv_s, s2);
+  constexpr bool REX = EXACT || TER;
+  const float inv_s = REX ? 1.0f / sqrtf(s2) : newton_rsqrt(S.inv_s, s2);
   S.inv_s = inv_s;
   const float dx = -(nb[0] * inv_s), dz = -(nb[2] * inv_s);
   const float t1x = -dz, t1z = dx;
   const float t2x = nb[1] * t1z;
   const float t2y = __builtin_fmaf(nb[2], t1x, -(nb[0] * t1z));
   const float t2z = -(nb[1] * t1x);
-  const float np = __builtin_fmaf(S.n[2], S.p[2], __builtin_fmaf(S.n[1], S.p[1], S.n[0] * S.p[0]));
+  const float np = __builtin_fmaf(n[2], S.p[2], __builtin_fmaf(n[1], S.p[1], n[0] * S.p[0]));
   const float cz = K.cz;
   const f2 cy = {K.wy, -K.wy};  // (left, right) wheel of each axle (urdf:112-142: left = +y)
   const f2 ry = cy;
@@ -88,7 +98,7 @@ OIS_DEV void substep_pk(const DevConsts& K, PhysT<1>& S) {
     const float cx = j ? -K.wx : K.wx;  // front axle +x, rear axle -x
     const float rx = __builtin_fmaf(K.rw, dx, cx);
     // gap = np + fma(nb2, rz, fma(nb1, ry, nb0 * rx))
-    const f2 gap = np + fma2(nb[2], (f2)(rz), fma2(nb[1], ry, nb[0] * rx));
+    const f2 gap = (TER ? np - ld2(&off[j]) : (f2)(np)) + fma2(nb[2], (f2)(rz), fma2(nb[1], ry, nb[0] * rx));
     f2 bb;
     bb.x = gap.x >= 0.0f ? -(gap.x * K.inv_dt) : fminf(-(gap.x * K.beta_inv_dt), K.vdep);
     bb.y = gap.y >= 0.0f ? -(gap.y * K.inv_dt) : fminf(-(gap.y * K.beta_inv_dt), K.vdep);
@@ -108,7 +118,7 @@ OIS_DEV void substep_pk(const DevConsts& K, PhysT<1>& S) {
     const f2 kn = fma2(an[j][2], Jan[j][2], fma2(an[j][1], Jan[j][1], fma2(an[j][0], Jan[j][0], K.im4)));
     const f2 k1 = fma2(a1[j][2], Ja1[j][2], fma2(a1[j][1], Ja1[j][1], fma2(a1[j][0], Ja1[j][0], K.im4))) + K.rw2_over_Is;
     const f2 k2 = fma2(a2[j][2], Ja2[j][2], fma2(a2[j][1], Ja2[j][1], fma2(a2[j][0], Ja2[j][0], K.im4)));
-    if (EXACT) {
+    if (REX) {
       mn[j].x = 1.0f / kn.x; mn[j].y = 1.0f / kn.y;
       m1[j].x = 1.0f / k1.x; m1[j].y = 1.0f / k1.y;
       m2[j].x = 1.0f / k2.x; m2[j].y = 1.0f / k2.y;
@@ -213,6 +223,7 @@ OIS_DEV void substep_pk(const DevConsts& K, PhysT<1>& S) {
   float inv = __builtin_fmaf(-0.5f, nn, 1.5f);
   if (fabsf(nn - 1.0f) > 1e-3f) inv = 1.0f / sqrtf(nn);
   S.q[0] = nqw * inv; S.q[1] = nqx * inv; S.q[2] = nqy * inv; S.q[3] = nqz * inv;
+  if constexpr (TER) footprints_store(S, cur);
 #undef OIS_PR
 }
 

@@ -38,6 +38,7 @@ _DTYPES = {
     _abi.BUF_PARAMS: (torch.float32, 4), _abi.BUF_EPISODE_INFO: (torch.float32, None),
     _abi.BUF_ENV0_DIAG: (torch.float32, None), _abi.BUF_LAMBDA_N: (torch.float32, 4),
     _abi.BUF_LAMBDA_L: (torch.float32, 4), _abi.BUF_LAMBDA_T: (torch.float32, 4),
+    _abi.BUF_ENV_ORIGINS: (torch.float32, 4), _abi.BUF_TERRAIN_IDX: (torch.int32, 4),
 }
 
 
@@ -159,6 +160,43 @@ class NativeEnv:
     def env0_diag(self) -> np.ndarray:
         out = np.zeros(_abi.ENV0_DIAG_LEN, np.float32)
         _native.check(self.L.ois_env0_diag(self.h, out.ctypes.data_as(C.POINTER(C.c_float)), _stream_ptr(self.device)))
+        return out
+
+    def attach_terrain(self, terrain, levels_types: np.ndarray, curriculum: Optional[bool] = None,
+                       threshold_low: float = 0.3, threshold_high: float = 5.0, max_level: Optional[int] = None):
+        """Put the arenas on a height field (include/ois.h ois_terrain_attach). ``terrain`` is a
+        ``terrain.Terrain`` (or anything with heightsamples / env_origins / horizontal_scale /
+        vertical_scale / border_size), ``levels_types`` int [N, 2] = terrain_levels, terrain_types
+        (KAMMA.py:340-347). Call before ``reset``."""
+        field = torch.from_numpy(np.ascontiguousarray(terrain.heightsamples, dtype=np.int16)).to(self.device)
+        origins = torch.from_numpy(np.ascontiguousarray(terrain.env_origins, dtype=np.float32)).to(self.device)
+        lt = np.ascontiguousarray(levels_types, dtype=np.int32).reshape(self.N, 2)
+        t = _abi.OisTerrain()
+        t.struct_bytes = C.sizeof(_abi.OisTerrain)
+        t.rows, t.cols = int(field.shape[0]), int(field.shape[1])
+        t.horizontal_scale, t.vertical_scale = float(terrain.horizontal_scale), float(terrain.vertical_scale)
+        t.border_size = float(terrain.border_size)
+        t.num_levels, t.num_types = int(origins.shape[0]), int(origins.shape[1])
+        cur = getattr(terrain, "cfg", {}).get("curriculum", False) if curriculum is None else curriculum
+        t.curriculum = int(bool(cur))
+        t.threshold_low, t.threshold_high = float(threshold_low), float(threshold_high)
+        t.max_level = int(min(5, t.num_levels - 1) if max_level is None else max_level)  # KAMMA.py:525
+        torch.cuda.synchronize(self.device)
+        _native.check(self.L.ois_terrain_attach(self.h, C.byref(t), C.c_void_p(field.data_ptr()),
+                                                C.c_void_p(origins.data_ptr()),
+                                                lt.ctypes.data_as(C.POINTER(C.c_int32)), _stream_ptr(self.device)))
+        self._terrain = (field, origins, t)  # the library reads them on every step: keep them alive
+
+    def detach_terrain(self):
+        torch.cuda.synchronize(self.device)
+        _native.check(self.L.ois_terrain_attach(self.h, None, None, None, None, _stream_ptr(self.device)))
+        self._terrain = None
+
+    def height_scan(self, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+        """get_heights (KAMMA.py:872-893): measured_heights [N, 140] of the current state."""
+        if out is None:
+            out = torch.empty((self.N, _abi.HEIGHT_POINTS), dtype=torch.float32, device=self.device)
+        _native.check(self.L.ois_height_scan(self.h, C.c_void_p(out.data_ptr()), _stream_ptr(self.device)))
         return out
 
     def attach_replay(self, memory_size: int) -> Dict[str, torch.Tensor]:
@@ -359,6 +397,51 @@ class TorqueDistributionTask:
             self._diag_cache = {k: (v if isinstance(v, int) else float(v)) for k, v in self._diag_cache.items()}
             self._diag_step = self.native.policy_steps
         return self._diag_cache
+
+    # ---- terrain (KAMMA.py:296-349, 872-893; commented out in the reference's task) ----
+    def get_terrain(self, terrain=None, levels_types=None, seed: Optional[int] = None, **attach_kw):
+        """``get_terrain`` + ``_create_trimesh`` (KAMMA.py:296-305, 338-349): build the height
+        field from ``TASK_CFG["task"]["env"]["terrain"]`` (or take a ready ``terrain.Terrain``),
+        draw terrain_levels / terrain_types, put every arena on its tile. Call before reset()."""
+        from . import terrain as tg
+        if terrain is None:
+            tcfg = dict(self._task_cfg.get("env", {}).get("terrain", {}))
+            terrain = tg.Terrain(tcfg, num_robots=self.num_envs, seed=self.cfg_native.seed if seed is None else seed)
+        if levels_types is None:
+            levels_types = terrain.sample_levels_types(self.num_envs)
+        self.terrain = terrain
+        self.native.attach_terrain(terrain, levels_types, **attach_kw)
+        self.terrain_origins = torch.from_numpy(np.asarray(terrain.env_origins, np.float32)).to(self.device)
+        self.height_samples = self.native._terrain[0]
+        self.num_height_points = _abi.HEIGHT_POINTS
+        return terrain
+
+    @property
+    def env_origins(self) -> torch.Tensor:
+        return self.native.buffer(_abi.BUF_ENV_ORIGINS)[:, :3]
+
+    @property
+    def terrain_levels(self) -> torch.Tensor:
+        return self.native.buffer(_abi.BUF_TERRAIN_IDX)[:, 0]
+
+    @property
+    def terrain_types(self) -> torch.Tensor:
+        return self.native.buffer(_abi.BUF_TERRAIN_IDX)[:, 1]
+
+    def get_heights(self, env_ids=None) -> torch.Tensor:
+        """KAMMA.py:872-893: measured_heights [N, 140] (rows ``env_ids`` if given)."""
+        h = self.native.height_scan()
+        return h if env_ids is None else h[env_ids]
+
+    def height_observation(self, height_meas_scale: float = 1.0) -> torch.Tensor:
+        """the observation block of KAMMA.py:826-828:
+        clip(base_pos.z - measured_heights - 0.0622, -1, 1) * height_meas_scale, with the world z
+        of the base link = arena-local z + origin z."""
+        n = self.native
+        q = n.buffer(_abi.BUF_QUAT)
+        up_z = 1.0 - 2.0 * (q[:, 1] * q[:, 1] + q[:, 2] * q[:, 2])  # R[2][2]
+        z = self._pose[:, 2] - up_z * float(self.cfg_native.com_height) + n.buffer(_abi.BUF_ENV_ORIGINS)[:, 2]
+        return torch.clip(z.unsqueeze(1) - self.get_heights() - 0.0622, -1.0, 1.0) * height_meas_scale
 
     # ---- reference call sequence ----
     def post_reset(self, seed: Optional[int] = None):

@@ -50,6 +50,10 @@ def lib() -> C.CDLL:
         L.orc_replay_attach.argtypes = [C.c_void_p, C.c_int]
         L.orc_replay_buffer.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.c_void_p), C.POINTER(C.c_size_t)]
         L.orc_replay_cursor.argtypes = [C.c_void_p, C.POINTER(C.c_int), C.POINTER(C.c_int)]
+        L.orc_terrain_attach.argtypes = [C.c_void_p, C.POINTER(_abi.OisTerrain), C.POINTER(C.c_int16), fp, ip]
+        L.orc_height_scan.argtypes = [C.c_void_p, fp]
+        L.orc_get_heights.argtypes = [C.c_int, fp, fp, C.POINTER(C.c_int16), C.c_int, C.c_int, C.c_float, C.c_float, C.c_float, fp]
+        L.orc_get_heights.restype = None
         L.orc_gae.argtypes = [C.c_int, C.c_int, C.c_int, fp, u8p, fp, fp, C.c_double, C.c_double, C.c_int, fp, fp]
         L.orc_criteria.argtypes = [C.c_int, fp, fp, fp, fp] + [C.c_float] * 5 + [fp] * 4
         L.orc_criteria.restype = None
@@ -106,7 +110,19 @@ _BUF_META = {
     _abi.BUF_PARAMS: (np.float32, 4), _abi.BUF_EPISODE_INFO: (np.float32, None),
     _abi.BUF_ENV0_DIAG: (np.float32, None),
     _abi.BUF_LAMBDA_N: (np.float32, 4), _abi.BUF_LAMBDA_L: (np.float32, 4), _abi.BUF_LAMBDA_T: (np.float32, 4),
+    _abi.BUF_ENV_ORIGINS: (np.float32, 4), _abi.BUF_TERRAIN_IDX: (np.int32, 4),
 }
+
+
+def get_heights(pos_world, quat, field, horizontal_scale=0.02, vertical_scale=0.006, border_size=20.0):
+    """orc_get_heights: [n, 140] heights for world base positions [n, 3] and quaternions [n, 4] (w,x,y,z)"""
+    p = np.ascontiguousarray(pos_world, np.float32).reshape(-1, 3)
+    q = np.ascontiguousarray(quat, np.float32).reshape(-1, 4)
+    f = np.ascontiguousarray(field, np.int16)
+    out = np.empty((p.shape[0], _abi.HEIGHT_POINTS), np.float32)
+    lib().orc_get_heights(p.shape[0], fptr(p), fptr(q), f.ctypes.data_as(C.POINTER(C.c_int16)), f.shape[0], f.shape[1],
+                          horizontal_scale, vertical_scale, border_size, fptr(out))
+    return out
 
 
 def gae(mode: int, rewards, terminated, values, last_values, gamma: float, lam: float, normalize: bool):
@@ -183,6 +199,29 @@ class OracleEnv:
     def randomize_params(self, mu_lo, mu_hi, slopes=()):
         s = np.asarray(slopes, np.float32)
         self._check(self.L.orc_randomize_params(self.h, mu_lo, mu_hi, fptr(s) if s.size else None, int(s.size)))
+
+    def attach_terrain(self, terrain, levels_types, curriculum=None, threshold_low=0.3, threshold_high=5.0, max_level=None):
+        f = np.ascontiguousarray(terrain.heightsamples, np.int16)
+        o = np.ascontiguousarray(terrain.env_origins, np.float32)
+        lt = np.ascontiguousarray(levels_types, np.int32).reshape(self.N, 2)
+        t = _abi.OisTerrain()
+        t.struct_bytes = C.sizeof(_abi.OisTerrain)
+        t.rows, t.cols = f.shape
+        t.horizontal_scale, t.vertical_scale, t.border_size = terrain.horizontal_scale, terrain.vertical_scale, terrain.border_size
+        t.num_levels, t.num_types = o.shape[0], o.shape[1]
+        cur = getattr(terrain, "cfg", {}).get("curriculum", False) if curriculum is None else curriculum
+        t.curriculum = int(bool(cur))
+        t.threshold_low, t.threshold_high = threshold_low, threshold_high
+        t.max_level = int(min(5, t.num_levels - 1) if max_level is None else max_level)
+        self._check(self.L.orc_terrain_attach(self.h, C.byref(t), f.ctypes.data_as(C.POINTER(C.c_int16)), fptr(o), iptr(lt)))
+
+    def detach_terrain(self):
+        self._check(self.L.orc_terrain_attach(self.h, None, None, None, None))
+
+    def height_scan(self) -> np.ndarray:
+        out = np.empty((self.N, _abi.HEIGHT_POINTS), np.float32)
+        self._check(self.L.orc_height_scan(self.h, fptr(out)))
+        return out
 
     def attach_replay(self, memory_size: int) -> dict:
         """FIFO transition memory mirror; returns numpy views keyed like skrl's memory tensors."""

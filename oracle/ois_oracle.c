@@ -338,6 +338,7 @@ typedef struct {
   float dt_over_Is, dt_over_Iy, rw, rw_over_Is, rw2_over_Is;
   float beta_inv_dt, vdep, maxw, maxw2, damping;
   float cx[4], cy[4], cz; /* wheel centres relative to the composite COM, order fl, rl, fr, rr */
+  float inv4wx, inv4wy;   /* 1 / (4 |x|), 1 / (4 |y|) of the wheel centres: footprint-plane fit (SPEC §3.8) */
   int iters;
 } derived;
 
@@ -366,6 +367,8 @@ static void derive(const ois_config* c, derived* D) {
     D->cy[w] = sy[w] * c->wheel_pos[1];
   }
   D->cz = c->wheel_pos[2] - c->com_height;
+  D->inv4wx = 1.0f / (4.0f * c->wheel_pos[0]);
+  D->inv4wy = 1.0f / (4.0f * c->wheel_pos[1]);
   D->iters = c->solver_iterations;
 }
 
@@ -408,22 +411,90 @@ typedef struct {
   float mn[4], m1[4], m2[4], inv_s;
 } rcache;
 
+/* The corrections are clamped (|1 - k m| <= 0.5, 0.5 <= 1.5 - 0.5 s2 r^2 <= 1.5): inside that
+ * band — always, for a robot that is not tumbling — this IS the Newton step; outside (the
+ * geometry jumped between two substeps) the cached value moves at most 50 % towards the new
+ * one and stays positive, instead of overshooting to a negative gain and diverging. */
+static inline float clampf(float x, float lo, float hi) { return fminf(fmaxf(x, lo), hi); }
 static inline float newton_rcp(float m, float k) { /* m ~ 1/k -> m (2 - k m) */
-  float e = fmaf(-k, m, 1.0f);
+  float e = clampf(fmaf(-k, m, 1.0f), -0.5f, 0.5f);
   return fmaf(m, e, m);
 }
 static inline float newton_rsqrt(float r, float s2) { /* r ~ 1/sqrt(s2) -> r (1.5 - 0.5 s2 r^2) */
   float hr = (0.5f * s2) * r;
-  float e = fmaf(-hr, r, 1.5f);
+  float e = clampf(fmaf(-hr, r, 1.5f), 0.5f, 1.5f);
   return r * e;
 }
 
-static void substep(const derived* D, float mu, const float n[3], const float tau[4], float p[3],
+/* ---- height-field terrain (docs/SPEC.md §3.8; build-defined like the rest of the physics) ---- */
+typedef struct {
+  const int16_t* h; /* [rows, cols] raw heights */
+  int rows, cols;
+  float inv_hs, hs, vs, border;
+} terrain_ctx;
+
+/* ground height at world (x, y): the sampling rule of get_heights (KAMMA.py:882-893: pixel =
+ * trunc((x + border) / horizontal_scale) clipped to [0, size-2], min of the pixel and its
+ * (+1,+1) neighbour) with the division replaced by a multiplication with 1/horizontal_scale */
+static inline float terrain_height(const terrain_ctx* T, float x, float y) {
+  float fx = (x + T->border) * T->inv_hs, fy = (y + T->border) * T->inv_hs;
+  fx = fminf(fmaxf(fx, 0.0f), (float)(T->rows - 2));
+  fy = fminf(fmaxf(fy, 0.0f), (float)(T->cols - 2));
+  int px = (int)fx, py = (int)fy;
+  int16_t h1 = T->h[(size_t)px * T->cols + py], h2 = T->h[(size_t)(px + 1) * T->cols + (py + 1)];
+  return (float)(h1 < h2 ? h1 : h2) * T->vs;
+}
+
+/* Footprints of the 4 wheels: world xy under the wheel centres (arena-local), the field height
+ * there (tile origin subtracted) and the xy part of the body x / y axes at sampling time. */
+typedef struct {
+  float wx[4], wy[4], h[4];
+  float r00, r10, r01, r11;
+} footprints;
+
+static void terrain_footprints(const derived* D, const terrain_ctx* T, const float origin[3], const float p[3],
+                               const float R[9], footprints* F) {
+  for (int k = 0; k < 4; ++k) {
+    F->wx[k] = fmaf(R[2], D->cz, fmaf(R[1], D->cy[k], fmaf(R[0], D->cx[k], p[0])));
+    F->wy[k] = fmaf(R[5], D->cz, fmaf(R[4], D->cy[k], fmaf(R[3], D->cx[k], p[1])));
+    F->h[k] = terrain_height(T, F->wx[k] + origin[0], F->wy[k] + origin[1]) - origin[2];
+  }
+  F->r00 = R[0]; F->r10 = R[3]; F->r01 = R[1]; F->r11 = R[4];
+}
+
+/* The wheels stand on the plane through their 4 footprints: unit normal n from the front-rear
+ * and left-right footprint differences, off[k] = n . footprint_k (plane offset seen by wheel k). */
+static void terrain_plane(const derived* D, const footprints* F, float n[3], float off[4]) {
+  const float* h = F->h;
+  float g1 = ((h[0] + h[2]) - (h[1] + h[3])) * D->inv4wx; /* front - rear (order fl, rl, fr, rr) */
+  float g2 = ((h[0] + h[1]) - (h[2] + h[3])) * D->inv4wy; /* left - right */
+  /* e1 = (R00, R10, g1), e2 = (R01, R11, g2): n ~ e1 x e2 */
+  float nx = fmaf(F->r10, g2, -(g1 * F->r11));
+  float ny = fmaf(g1, F->r01, -(F->r00 * g2));
+  float nz = fmaf(F->r00, F->r11, -(F->r10 * F->r01));
+  float nn = fmaxf(fmaf(nz, nz, fmaf(ny, ny, nx * nx)), 1e-12f);
+  float inv = 1.0f / sqrtf(nn);
+  if (nz < 0.0f) inv = -inv; /* rolled over (body z points down): the ground's normal still points up */
+  n[0] = nx * inv; n[1] = ny * inv; n[2] = nz * inv;
+  for (int k = 0; k < 4; ++k) off[k] = fmaf(n[2], h[k], fmaf(n[1], F->wy[k], n[0] * F->wx[k]));
+}
+
+static void substep(const derived* D, float mu, const float n_in[3], const float tau[4], float p[3],
                     float q[4], float v[3], float wb[3], float spin[4], float ln[4], float l1[4],
-                    float l2[4], rcache* C, int exact) {
+                    float l2[4], rcache* C, int exact, const terrain_ctx* TR, const float* origin, footprints* FP) {
   float R[9];
   rotmat(q, R);
   float vb[3], nb[3];
+  float n[3] = {n_in[0], n_in[1], n_in[2]}, off[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+  footprints cur;
+  if (TR) {
+    /* the plane is fitted to the footprints sampled one substep EARLIER (the first substep of a
+     * policy step samples its own): on the GPU the 8 gathers of this substep are then in flight
+     * during the whole solve instead of stalling it (SPEC §3.8). A wheel moves <= 2 cm per substep. */
+    terrain_footprints(D, TR, origin, p, R, &cur);
+    if (exact) *FP = cur;
+    terrain_plane(D, FP, n, off);
+  }
   rotT(R, v, vb);
   rotT(R, n, nb);
   /* gravity (world -z) in the body frame */
@@ -443,7 +514,8 @@ static void substep(const derived* D, float mu, const float n[3], const float ta
   /* contact frame shared by the four wheels (common axle direction = body y) */
   float s2 = fmaf(nb[2], nb[2], nb[0] * nb[0]);
   s2 = fmaxf(s2, 1e-12f);
-  float inv_s = exact ? 1.0f / sqrtf(s2) : newton_rsqrt(C->inv_s, s2);
+  const int rex = exact || TR != NULL; /* on a height field the geometry may jump: exact reciprocals every substep */
+  float inv_s = rex ? 1.0f / sqrtf(s2) : newton_rsqrt(C->inv_s, s2);
   C->inv_s = inv_s;
   float dx = -(nb[0] * inv_s), dz = -(nb[2] * inv_s);
   float t1x = -dz, t1z = dx;
@@ -457,7 +529,7 @@ static void substep(const derived* D, float mu, const float n[3], const float ta
   for (int k = 0; k < 4; ++k) {
     float cx = D->cx[k], cy = D->cy[k], cz = D->cz;
     float rx = fmaf(D->rw, dx, cx), ry = cy, rz = fmaf(D->rw, dz, cz);
-    float gap = np + fmaf(nb[2], rz, fmaf(nb[1], ry, nb[0] * rx));
+    float gap = (TR ? np - off[k] : np) + fmaf(nb[2], rz, fmaf(nb[1], ry, nb[0] * rx));
     b[k] = gap >= 0.0f ? -(gap * D->inv_dt) : fminf(-(gap * D->beta_inv_dt), D->vdep);
     an[k][0] = fmaf(ry, nb[2], -(rz * nb[1]));
     an[k][1] = fmaf(rz, nb[0], -(rx * nb[2]));
@@ -476,9 +548,9 @@ static void substep(const derived* D, float mu, const float n[3], const float ta
     float kn = fmaf(an[k][2], Jan[k][2], fmaf(an[k][1], Jan[k][1], fmaf(an[k][0], Jan[k][0], D->im4)));
     float k1 = fmaf(a1[k][2], Ja1[k][2], fmaf(a1[k][1], Ja1[k][1], fmaf(a1[k][0], Ja1[k][0], D->im4))) + D->rw2_over_Is;
     float k2 = fmaf(a2[k][2], Ja2[k][2], fmaf(a2[k][1], Ja2[k][1], fmaf(a2[k][0], Ja2[k][0], D->im4)));
-    mn[k] = exact ? 1.0f / kn : newton_rcp(mn[k], kn);
-    m1[k] = exact ? 1.0f / k1 : newton_rcp(m1[k], k1);
-    m2[k] = exact ? 1.0f / k2 : newton_rcp(m2[k], k2);
+    mn[k] = rex ? 1.0f / kn : newton_rcp(mn[k], kn);
+    m1[k] = rex ? 1.0f / k1 : newton_rcp(m1[k], k1);
+    m2[k] = rex ? 1.0f / k2 : newton_rcp(m2[k], k2);
   }
   float vnx = D->im4 * nb[0], vny = D->im4 * nb[1], vnz = D->im4 * nb[2];
   float v1x = D->im4 * t1x, v1z = D->im4 * t1z;
@@ -561,6 +633,7 @@ static void substep(const derived* D, float mu, const float n[3], const float ta
   float inv = fmaf(-0.5f, nn, 1.5f);
   if (fabsf(nn - 1.0f) > 1e-3f) inv = 1.0f / sqrtf(nn);
   q[0] = nqw * inv; q[1] = nqx * inv; q[2] = nqy * inv; q[3] = nqz * inv;
+  if (TR) *FP = cur;
 }
 
 /* w is the WORLD angular velocity here (converted to the body frame and back) */
@@ -573,7 +646,7 @@ void orc_substep(const ois_config* cfg, float mu, const float n_world[3], const 
   rotmat(q, R);
   rotT(R, w, wb);
   rcache C;
-  substep(&D, mu, n_world, tau, p, q, v, wb, spin, lam_n, lam_l, lam_t, &C, 1);
+  substep(&D, mu, n_world, tau, p, q, v, wb, spin, lam_n, lam_l, lam_t, &C, 1, NULL, NULL, NULL);
   rotmat(q, R);
   rot(R, wb, w);
 }
@@ -604,6 +677,14 @@ struct orc_env {
   float* partials;  /* [G][PART_STRIDE] */
   int32_t* stamps;  /* [G] */
   float* stat_acc;  /* [G][ST_STRIDE] */
+  /* height-field terrain (mirror of ois_terrain_attach): own copies of the field and the table */
+  int terrain_on;
+  ois_terrain tcfg;
+  terrain_ctx terrain;
+  int16_t* theights;
+  float* terrain_origins; /* [levels, types, 3] */
+  float* env_origins;     /* [N,4] */
+  int32_t* terrain_idx;   /* [N,4] level, type */
   /* FIFO transition memory (mirror of ois_replay_*) */
   float *rp_states, *rp_actions, *rp_rewards, *rp_next;
   uint8_t* rp_done;
@@ -634,6 +715,8 @@ int orc_create(const ois_config* cfg, orc_env** out) {
   e->lam_n = zalloc(f4); e->lam_l = zalloc(f4); e->lam_t = zalloc(f4);
   e->done = zalloc((size_t)N); e->timeout = zalloc((size_t)N);
   e->counters = zalloc((size_t)N * 4 * sizeof(int32_t));
+  e->env_origins = zalloc(f4);
+  e->terrain_idx = zalloc((size_t)N * 4 * sizeof(int32_t));
   e->partials = zalloc((size_t)G * PART_STRIDE * sizeof(float));
   e->stamps = zalloc((size_t)G * sizeof(int32_t));
   e->stat_acc = zalloc((size_t)G * ST_STRIDE * sizeof(float));
@@ -652,6 +735,7 @@ void orc_destroy(orc_env* e) {
   free(e->params); free(e->lam_n); free(e->lam_l); free(e->lam_t); free(e->done); free(e->timeout); free(e->counters); free(e->partials); free(e->stamps);
   free(e->stat_acc);
   free(e->rp_states); free(e->rp_actions); free(e->rp_rewards); free(e->rp_next); free(e->rp_done);
+  free(e->theights); free(e->terrain_origins); free(e->env_origins); free(e->terrain_idx);
   free(e);
 }
 
@@ -687,6 +771,8 @@ int orc_buffer(orc_env* e, int id, void** ptr, size_t* bytes) {
     case OIS_BUF_LAMBDA_N: *ptr = e->lam_n; *bytes = f4; break;
     case OIS_BUF_LAMBDA_L: *ptr = e->lam_l; *bytes = f4; break;
     case OIS_BUF_LAMBDA_T: *ptr = e->lam_t; *bytes = f4; break;
+    case OIS_BUF_ENV_ORIGINS: *ptr = e->env_origins; *bytes = f4; break;
+    case OIS_BUF_TERRAIN_IDX: *ptr = e->terrain_idx; *bytes = N * 4 * sizeof(int32_t); break;
     case OIS_BUF_EPISODE_INFO: *ptr = e->episode_info; *bytes = sizeof e->episode_info; break;
     case OIS_BUF_ENV0_DIAG: *ptr = e->env0_diag; *bytes = sizeof e->env0_diag; break;
     default: return fail(OIS_EINVAL, "unknown buffer id");
@@ -727,6 +813,20 @@ static void reset_arena(orc_env* e, int i, uint32_t step_ctr, float gamma2, rese
   rc->sm = sc[0]; rc->te = sc[1]; rc->dv = sc[2];
   rc->ret = Sf;
   rc->len = (float)cnt[0];
+  if (e->terrain_on && e->tcfg.curriculum && step_ctr != 0u) {
+    /* update_SI_level (KAMMA.py:502-529; skipped while not init_done, :504): one level down
+     * when the finished episode's r1 sum is below threshold_low, one up above threshold_high.
+     * (The reference writes through a chained index, terrain_levels[env_ids][mask] = ..., which
+     * assigns to a temporary; the evident intent is implemented.) */
+    int32_t* ti = &e->terrain_idx[4 * i];
+    int lvl = ti[0];
+    if (S[0] < e->tcfg.threshold_low) lvl = lvl - 1 < 0 ? 0 : lvl - 1;
+    if (S[0] > e->tcfg.threshold_high) lvl = lvl + 1 > e->tcfg.max_level ? e->tcfg.max_level : lvl + 1;
+    ti[0] = lvl;
+    const float* o = &e->terrain_origins[((size_t)lvl * e->tcfg.num_types + ti[1]) * 3];
+    float* eo = &e->env_origins[4 * i];
+    eo[0] = o[0]; eo[1] = o[1]; eo[2] = o[2]; /* :529 */
+  }
   /* :485 zero the sums of the reset arena */
   for (int k = 0; k < 4; ++k) { sa[k] = 0.0f; sb[k] = 0.0f; }
   sc[0] = sc[1] = sc[2] = 0.0f;
@@ -949,7 +1049,9 @@ static float step_arena(orc_env* e, int i, const float* act /*[A]*/, uint8_t* rs
   float* LL = &e->lam_l[4 * i];
   float* LT = &e->lam_t[4 * i];
   rcache C;
-  for (int s = 0; s < nsub; ++s) substep(D, mu, n, wt, p, q, v, wb, spin, LN, LL, LT, &C, s == 0);
+  const terrain_ctx* T = e->terrain_on ? &e->terrain : NULL;
+  footprints FP;
+  for (int s = 0; s < nsub; ++s) substep(D, mu, n, wt, p, q, v, wb, spin, LN, LL, LT, &C, s == 0, T, &e->env_origins[4 * i], &FP);
   rotmat(q, R);
   rot(R, wb, w); /* body -> world with the final orientation */
   float jv[4];
@@ -1105,6 +1207,92 @@ int orc_replay_cursor(const orc_env* e, int* memory_index, int* filled) {
   return OIS_OK;
 }
 
+/* ---- height-field terrain: attach + get_heights ---- */
+int orc_terrain_attach(orc_env* e, const ois_terrain* t, const int16_t* heights, const float* terrain_origins,
+                       const int32_t* levels_types) {
+  if (!e) return fail(OIS_EINVAL, "null env");
+  free(e->theights); free(e->terrain_origins);
+  e->theights = NULL; e->terrain_origins = NULL; e->terrain_on = 0;
+  memset(e->env_origins, 0, (size_t)e->N * 4 * sizeof(float));
+  memset(e->terrain_idx, 0, (size_t)e->N * 4 * sizeof(int32_t));
+  if (!t) return OIS_OK;
+  if (t->struct_bytes != sizeof(ois_terrain)) return fail(OIS_EINVAL, "ois_terrain.struct_bytes mismatch");
+  if (t->rows < 2 || t->cols < 2 || !(t->horizontal_scale > 0.0f) || t->num_levels < 1 || t->num_types < 1 ||
+      t->max_level < 0 || t->max_level >= t->num_levels || !heights || !terrain_origins || !levels_types)
+    return fail(OIS_EINVAL, "bad terrain description");
+  for (int i = 0; i < e->N; ++i)
+    if (levels_types[2 * i] < 0 || levels_types[2 * i] >= t->num_levels || levels_types[2 * i + 1] < 0 ||
+        levels_types[2 * i + 1] >= t->num_types)
+      return fail(OIS_EINVAL, "terrain level / type out of range");
+  size_t cells = (size_t)t->rows * (size_t)t->cols, no = (size_t)t->num_levels * t->num_types * 3;
+  e->theights = (int16_t*)malloc(cells * sizeof(int16_t));
+  e->terrain_origins = (float*)malloc(no * sizeof(float));
+  if (!e->theights || !e->terrain_origins) return fail(OIS_ENOMEM, "host alloc");
+  memcpy(e->theights, heights, cells * sizeof(int16_t));
+  memcpy(e->terrain_origins, terrain_origins, no * sizeof(float));
+  e->tcfg = *t;
+  e->terrain.h = e->theights; e->terrain.rows = t->rows; e->terrain.cols = t->cols;
+  e->terrain.hs = t->horizontal_scale; e->terrain.inv_hs = 1.0f / t->horizontal_scale;
+  e->terrain.vs = t->vertical_scale; e->terrain.border = t->border_size;
+  for (int i = 0; i < e->N; ++i) {
+    int lvl = levels_types[2 * i], typ = levels_types[2 * i + 1];
+    e->terrain_idx[4 * i] = lvl; e->terrain_idx[4 * i + 1] = typ;
+    const float* o = &e->terrain_origins[((size_t)lvl * t->num_types + typ) * 3];
+    e->env_origins[4 * i] = o[0]; e->env_origins[4 * i + 1] = o[1]; e->env_origins[4 * i + 2] = o[2]; /* KAMMA.py:397 */
+  }
+  e->terrain_on = 1;
+  return OIS_OK;
+}
+
+/* get_heights (KAMMA.py:872-893) for n robots given WORLD base positions and orientations.
+ * Grid KAMMA.py:278-292 (14 x 10 points, meshgrid 'ij'); quat_apply_yaw KAMMA.py:895-899 with
+ * normalize() = x / max(|x|, 1e-9) and quat_apply(a, b) = b + w t + xyz x t, t = 2 xyz x b
+ * (omni.isaac.core.utils.torch, third-party, published formulas). out: [n, 140] metres. */
+void orc_get_heights(int n, const float* pos3, const float* quat4, const int16_t* heights, int rows, int cols,
+                     float horizontal_scale, float vertical_scale, float border_size, float* out) {
+  static const int GX[14] = {-8, -7, -6, -5, -4, -3, -2, 2, 3, 4, 5, 6, 7, 8};
+  static const int GY[10] = {-5, -4, -3, -2, -1, 1, 2, 3, 4, 5};
+  for (int i = 0; i < n; ++i) {
+    float w = quat4[4 * i], z = quat4[4 * i + 3];
+    float nrm = sqrtf(w * w + z * z); /* x, y are zeroed first (:897) */
+    nrm = fmaxf(nrm, 1e-9f);
+    float qw = w / nrm, qz = z / nrm;
+    for (int a = 0; a < 14; ++a)
+      for (int b = 0; b < 10; ++b) {
+        float bx = 0.1f * (float)GX[a], by = 0.1f * (float)GY[b];
+        float tx = -(qz * by) * 2.0f, ty = (qz * bx) * 2.0f; /* t = cross(xyz, b) * 2, xyz = (0, 0, qz) */
+        float cx = -(qz * ty), cy = qz * tx;                 /* cross(xyz, t) */
+        float X = (bx + qw * tx) + cx, Y = (by + qw * ty) + cy;
+        X += pos3[3 * i]; Y += pos3[3 * i + 1];             /* + base_pos :878 */
+        X += border_size; Y += border_size;                  /* :882 */
+        float fx = X / horizontal_scale, fy = Y / horizontal_scale; /* :883, .long() truncates */
+        fx = fminf(fmaxf(fx, 0.0f), (float)(rows - 2));      /* :886-887 clip after truncation == clamp before */
+        fy = fminf(fmaxf(fy, 0.0f), (float)(cols - 2));
+        int px = (int)fx, py = (int)fy;
+        int16_t h1 = heights[(size_t)px * cols + py], h2 = heights[(size_t)(px + 1) * cols + (py + 1)]; /* :889-890 */
+        out[(size_t)i * OIS_HEIGHT_POINTS + a * 10 + b] = (float)(h1 < h2 ? h1 : h2) * vertical_scale; /* :891-893 */
+      }
+  }
+}
+
+/* measured_heights of the current state: base-link position in the world = arena-local + env_origin */
+int orc_height_scan(orc_env* e, float* out) {
+  if (!e || !out) return fail(OIS_EINVAL, "null argument");
+  if (!e->terrain_on) return fail(OIS_ESTATE, "no terrain attached");
+  const ois_config* c = &e->cfg;
+  for (int i = 0; i < e->N; ++i) {
+    const float* P = &e->pose[4 * i];
+    const float* Q = &e->quat[4 * i];
+    const float* O = &e->env_origins[4 * i];
+    float R[9];
+    rotmat(Q, R);
+    float pw[3] = {fmaf(-R[2], c->com_height, P[0]) + O[0], fmaf(-R[5], c->com_height, P[1]) + O[1], 0.0f};
+    orc_get_heights(1, pw, Q, e->theights, e->terrain.rows, e->terrain.cols, e->terrain.hs, e->terrain.vs,
+                    e->terrain.border, &out[(size_t)i * OIS_HEIGHT_POINTS]);
+  }
+  return OIS_OK;
+}
+
 /* extras["episode"] (KAMMA.py:480-488) from the most recent reset event */
 int orc_episode_info(orc_env* e) {
   if (!e) return fail(OIS_EINVAL, "null env");
@@ -1128,7 +1316,10 @@ int orc_episode_info(orc_env* e) {
   for (int k = OIS_EI_R1; k <= OIS_EI_OBSERVED_OVER_FINAL; ++k) I[k] = (acc[k] / cntf) / L; /* :482-484 */
   I[OIS_EI_GAMMA1] = acc[P_G1];   /* :486 mean of N identical values */
   I[OIS_EI_GAMMA2] = acc[P_G2];   /* :487 */
-  I[OIS_EI_TERRAIN_LEVEL] = 0.0f; /* :488 terrain_levels are zeros (:223) */
+  /* :488 torch.mean(terrain_levels.float()) over ALL arenas; zeros without a terrain (:223) */
+  int64_t lsum = 0;
+  if (e->terrain_on) for (int i = 0; i < e->N; ++i) lsum += e->terrain_idx[4 * i];
+  I[OIS_EI_TERRAIN_LEVEL] = (float)lsum / (float)e->N;
   I[OIS_EI_STEP] = (float)smax;
   I[OIS_EI_SMOOTHNESS] = (acc[P_SM] / cntf) / L;
   I[OIS_EI_TRACKING_ERROR] = (acc[P_TE] / cntf) / L;

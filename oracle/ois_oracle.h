@@ -58,6 +58,14 @@ int orc_replay_attach(orc_env* env, int memory_size);
 int orc_replay_buffer(orc_env* env, int id, void** ptr, size_t* bytes);
 int orc_replay_cursor(const orc_env* env, int* memory_index, int* filled);
 
+/* height-field terrain mirror (ois_terrain_attach / ois_height_scan); all pointers are host memory */
+int orc_terrain_attach(orc_env* env, const ois_terrain* terrain, const int16_t* heights,
+                       const float* terrain_origins, const int32_t* levels_types);
+int orc_height_scan(orc_env* env, float* heights_out /*[N,140]*/);
+/* get_heights (KAMMA.py:872-893) on explicit world poses: pos3 [n,3], quat4 [n,4] (w,x,y,z) */
+void orc_get_heights(int n, const float* pos3, const float* quat4, const int16_t* heights, int rows, int cols,
+                     float horizontal_scale, float vertical_scale, float border_size, float* out);
+
 /* mirror of ois_gae on host tensors [T, N] (ppo.py:345-358 / ppoc.py:325-336) */
 int orc_gae(int mode, int T, int N, const float* rewards, const uint8_t* terminated, const float* values,
             const float* last_values, double gamma, double lambda, int normalize, float* returns_out,

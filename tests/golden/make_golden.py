@@ -257,6 +257,57 @@ def refmath_gae(seed=3, T=24, n=41, discount_factor=0.99, lambda_coefficient=0.9
 
 
 # ----------------------------------------------------------------------------------------
+def refmath_heights(seed=4, n=96):
+    """get_heights (KAMMA.py:872-893) with the height-point grid of KAMMA.py:278-292 and
+    quat_apply_yaw (KAMMA.py:895-899; normalize(x, eps=1e-9) = x / x.norm(p=2, dim=-1).clamp(min=eps)
+    and quat_apply as published in omni.isaac.core.utils.torch), on a random int16 height field
+    and random world poses, some of them outside the field (index clipping :886-887)."""
+    g = torch.Generator().manual_seed(seed)
+    rows, cols = 240, 180
+    horizontal_scale, vertical_scale, border_size = 0.02, 0.006, 2
+    height_samples = torch.randint(-300, 300, (rows, cols), generator=g, dtype=torch.int16)
+    base_pos = torch.rand((n, 3), generator=g) * torch.tensor([3.0, 2.0, 1.0]) - torch.tensor([0.5, 0.5, 0.0])
+    base_pos[:6] = torch.tensor([[-5.0, 1.0, 0], [30.0, 1.0, 0], [1.0, -9.0, 0], [1.0, 40.0, 0], [-2.1, -2.1, 0], [2.7, 1.5, 0]])
+    base_quat = torch.nn.functional.normalize(torch.randn((n, 4), generator=g), dim=1)
+    base_quat[::3, 1:3] *= 0.05  # mostly-upright robots
+    base_quat = torch.nn.functional.normalize(base_quat, dim=1)
+    # --- init_height_points :278-292
+    y = 0.1 * torch.tensor([-5, -4, -3, -2, -1, 1, 2, 3, 4, 5])
+    x = 0.1 * torch.tensor([-8, -7, -6, -5, -4, -3, -2, 2, 3, 4, 5, 6, 7, 8])
+    grid_x, grid_y = torch.meshgrid(x, y, indexing="ij")
+    num_height_points = grid_x.numel()
+    height_points = torch.zeros(n, num_height_points, 3)
+    height_points[:, :, 0] = grid_x.flatten()
+    height_points[:, :, 1] = grid_y.flatten()
+    # --- quat_apply_yaw :895-899
+    quat = base_quat.repeat(1, num_height_points)
+    quat_yaw = quat.clone().view(-1, 4)
+    quat_yaw[:, 1:3] = 0.0
+    quat_yaw = quat_yaw / quat_yaw.norm(p=2, dim=-1).clamp(min=1e-9, max=None).unsqueeze(-1)
+    vec = height_points
+    shape = vec.shape
+    a, b = quat_yaw.reshape(-1, 4), vec.reshape(-1, 3)
+    xyz = a[:, 1:]
+    t = xyz.cross(b, dim=-1) * 2
+    rotated = (b + a[:, :1] * t + xyz.cross(t, dim=-1)).view(shape)
+    # --- get_heights :878-893
+    points = rotated + (base_pos[:, 0:3]).unsqueeze(1)
+    points += border_size
+    points = (points / horizontal_scale).long()
+    px = points[:, :, 0].view(-1)
+    py = points[:, :, 1].view(-1)
+    px = torch.clip(px, 0, height_samples.shape[0] - 2)
+    py = torch.clip(py, 0, height_samples.shape[1] - 2)
+    heights1 = height_samples[px, py]
+    heights2 = height_samples[px + 1, py + 1]
+    heights = torch.min(heights1, heights2)
+    measured = heights.view(n, -1) * vertical_scale
+    return {"height_samples": height_samples.numpy(), "base_pos": base_pos.numpy(), "base_quat": base_quat.numpy(),
+            "horizontal_scale": np.float32(horizontal_scale), "vertical_scale": np.float32(vertical_scale),
+            "border_size": np.float32(border_size), "measured_heights": measured.numpy()}
+
+
+# ----------------------------------------------------------------------------------------
 def trajectories():
     from oracle.binding import OracleEnv
     from tests.golden_replay import TRAJ_SPECS, run_spec
@@ -265,7 +316,8 @@ def trajectories():
 
 def main():
     np.savez_compressed(os.path.join(HERE, "refmath_gae.npz"), **refmath_gae())
-    if "--gae-only" in sys.argv:
+    np.savez_compressed(os.path.join(HERE, "refmath_heights.npz"), **refmath_heights())
+    if "--gae-only" in sys.argv or "--unit-only" in sys.argv:
         return
     np.savez_compressed(os.path.join(HERE, "refmath_step.npz"), **refmath_step())
     np.savez_compressed(os.path.join(HERE, "refmath_reset.npz"), **refmath_reset())

@@ -1,0 +1,399 @@
+"""Height-field terrain: generator families, get_heights, the wheel contact
+on the field, the terrain curriculum; oracle on CPU, HIP kernel vs oracle under -m gpu.
+
+Pinned: get_heights against tests/golden/refmath_heights.npz (torch transcription of
+KAMMA.py:872-899 + grid :278-292), bit-exact. The generator families are checked against
+brute-force pixel loops written here from the reference's description
+(src/my_utils/origin_terrain_utils.py) — the reference functions themselves cannot be imported
+(module-level omni / pxr imports) and use numpy's unseeded global RNG. The contact model on
+the field is build-defined like the rest of the physics: PARITY UNPINNED, oracle <-> kernel only.
+"""
+import os
+
+import numpy as np
+import pytest
+
+from options_in_simulation_amd import _abi, build_config
+from options_in_simulation_amd import terrain as tg
+from oracle import binding as ob
+from oracle.binding import OracleEnv
+
+G = os.path.join(os.path.dirname(__file__), "golden")
+HS, VS = 0.02, 0.006
+
+
+def tile(n=200):
+    return tg.SubTerrain("t", width=n, length=n, vertical_scale=VS, horizontal_scale=HS)
+
+
+# ------------------------------------------------------------------ generator families -----
+def test_pyramid_stairs_matches_ring_drawing():
+    for sw_m, sh_m, plat in [(0.31, 0.15, 3.0), (1.0, -0.047, 3.0), (0.5, 0.1, 1.0)]:
+        t = tg.pyramid_stairs_terrain(tile(400), step_width=sw_m, step_height=sh_m, platform_size=plat)
+        ref = np.zeros((400, 400), np.int16)
+        sw, sh, pf = int(sw_m / HS), int(sh_m / VS), int(plat / HS)
+        a, b, c, d, h = 0, 400, 0, 400, 0
+        while (b - a) > pf and (d - c) > pf:  # the ring-by-ring drawing described at :274-286
+            a += sw; b -= sw; c += sw; d -= sw; h += sh
+            ref[a:b, c:d] = h
+        assert np.array_equal(t.height_field_raw, ref)
+        assert t.height_field_raw.dtype == np.int16
+
+
+def test_slope_stairs_flat_closed_forms():
+    t = tg.sloped_terrain(tile(100), slope=0.25)
+    mh = int(0.25 * (HS / VS) * 100)
+    for ix in (0, 1, 37, 99):
+        assert (t.height_field_raw[ix] == int(mh * ix / 100)).all()
+    t = tg.stairs_terrain(tile(100), step_width=0.3, step_height=0.05)
+    sw, sh = int(0.3 / HS), int(0.05 / VS)
+    for ix in range(100):
+        assert (t.height_field_raw[ix] == ((ix // sw + 1) * sh if ix // sw < 100 // sw else 0)).all()
+    t = tg.flat_terrain(tile(50), height=0.3)
+    assert (t.height_field_raw == int(0.3 / VS)).all()
+    # pyramid slope: symmetric, peak clipped at the platform corner height, sign follows the slope
+    for slope in (0.3, -0.2):
+        t = tg.pyramid_sloped_terrain(tile(200), slope=slope, platform_size=1.0)
+        f = t.height_field_raw.astype(int)
+        assert np.array_equal(f[1:], f[1:][::-1]) or np.array_equal(f[1:, 1:], f[1:, 1:][::-1, ::-1])
+        half = int(1.0 / HS / 2)
+        corner = f[100 - half, 100 - half]
+        assert f.max() == max(corner, 0) and f.min() == min(corner, 0) and np.sign(corner) == np.sign(slope)
+        assert f[0].max() == 0 and f[:, 0].max() == 0 and f[100, 100] == corner
+
+
+def test_random_families_are_seed_reproducible_and_bounded():
+    a = tg.discrete_obstacles_terrain(tile(400), 0.15, 1.0, 2.0, 40, platform_size=3.0, rng=np.random.RandomState(3))
+    b = tg.discrete_obstacles_terrain(tile(400), 0.15, 1.0, 2.0, 40, platform_size=3.0, rng=np.random.RandomState(3))
+    assert np.array_equal(a.height_field_raw, b.height_field_raw)
+    H = int(0.15 / VS)
+    assert set(np.unique(a.height_field_raw)) <= {-H, -H // 2, 0, H // 2, H}
+    assert (a.height_field_raw[125:275, 125:275] == 0).all()  # the 3 m platform
+    r = tg.random_uniform_terrain(tile(100), -0.1, 0.1, step=0.05, downsampled_scale=0.2, rng=np.random.RandomState(1))
+    assert np.abs(r.height_field_raw).max() <= 3 * int(0.1 / VS) and r.height_field_raw.std() > 0  # cubic spline overshoot
+    s = tg.stepping_stones_terrain(tile(200), 0.5, 0.1, 0.05, platform_size=1.0, rng=np.random.RandomState(2))
+    assert s.height_field_raw.min() == int(-10 / VS) and (s.height_field_raw[75:125, 75:125] == 0).all()
+    w = tg.wave_terrain(tile(100), num_waves=2, amplitude=0.2)
+    assert np.abs(w.height_field_raw).max() <= 2 * int(0.5 * 0.2 / VS)
+
+
+def test_terrain_layout_and_origins():
+    T = tg.Terrain({"curriculum": True, "numLevels": 4, "numTerrains": 2, "mapLength": 8.0, "mapWidth": 8.0}, 64, seed=0)
+    assert T.heightsamples.shape == (4 * 400 + 2000, 2 * 400 + 2000) and T.heightsamples.dtype == np.int16
+    assert (T.heightsamples[:1000] == 0).all() and (T.heightsamples[:, :1000] == 0).all()  # border
+    assert np.allclose(T.env_origins[2, 1, :2], [(2 + 0.5) * 8.0, (1 + 0.5) * 8.0])
+    assert (T.env_origins[0, :, 2] == 0).all() and (np.diff(T.env_origins[:, 0, 2]) < 0).all()  # descending stairs
+    # the origin height is the field height at the tile centre (platform)
+    for i in range(4):
+        for j in range(2):
+            x, y, z = T.env_origins[i, j]
+            assert tg.height_at(T.heightsamples, x, y) == pytest.approx(z, abs=1e-6)
+    R1 = tg.Terrain({"numLevels": 2, "numTerrains": 3, "mapLength": 8.0, "mapWidth": 8.0}, 64, seed=5)
+    R2 = tg.Terrain({"numLevels": 2, "numTerrains": 3, "mapLength": 8.0, "mapWidth": 8.0}, 64, seed=5)
+    assert np.array_equal(R1.heightsamples, R2.heightsamples) and R1.heightsamples.any()
+    lt = R1.sample_levels_types(100)
+    assert lt.shape == (100, 2) and lt[:, 0].max() <= 1 and lt[:, 1].max() <= 2 and lt.dtype == np.int32
+
+
+# ------------------------------------------------------------------ get_heights ------------
+def test_oracle_get_heights_matches_torch_fixture():
+    d = np.load(os.path.join(G, "refmath_heights.npz"))
+    out = ob.get_heights(d["base_pos"], d["base_quat"], d["height_samples"], float(d["horizontal_scale"]),
+                         float(d["vertical_scale"]), float(d["border_size"]))
+    assert np.array_equal(out, d["measured_heights"])  # bit-exact: indices are integers, heights raw * scale
+
+
+# ------------------------------------------------------------------ contact on the field ---
+def big_tile_terrain(fill, n=1500, border=2.0):
+    """a single-tile 'Terrain' stand-in: field = fill(SubTerrain) with its centre as the origin"""
+    class T:
+        pass
+    t = tg.SubTerrain("t", width=n, length=n, vertical_scale=VS, horizontal_scale=HS)
+    fill(t)
+    T.heightsamples = t.height_field_raw
+    T.horizontal_scale, T.vertical_scale, T.border_size = HS, VS, border
+    c = n * HS / 2 - border
+    T.env_origins = np.array([[[c, c, tg.height_at(t.height_field_raw, c, c, border_size=border)]]], np.float32)
+    T.cfg = {"curriculum": False}
+    return T
+
+
+def run(env, steps, act=None):
+    z = np.zeros((env.N, env.A), np.float32) if act is None else act
+    for _ in range(steps):
+        env.step(z)
+
+
+def test_flat_field_reproduces_the_plane():
+    N = 6
+    cfg = build_config(variant="KAMMA_medium", num_envs=N, seed=3)
+    a, b = OracleEnv(cfg), OracleEnv(cfg)
+    b.attach_terrain(big_tile_terrain(lambda t: tg.flat_terrain(t, 0.0)), np.zeros((N, 2), np.int32))
+    a.reset(3); b.reset(3)
+    run(a, 30); run(b, 30)
+    for bid in (_abi.BUF_POSE, _abi.BUF_QUAT, _abi.BUF_LINVEL, _abi.BUF_OBS, _abi.BUF_REW):
+        np.testing.assert_allclose(b.buffer(bid), a.buffer(bid), rtol=1e-4, atol=1e-5)
+    assert np.array_equal(a.done, b.done)
+    # a raised flat field: same motion, z shifted... in arena-local coordinates not even that
+    c = OracleEnv(cfg)
+    c.attach_terrain(big_tile_terrain(lambda t: tg.flat_terrain(t, 0.3)), np.zeros((N, 2), np.int32))
+    c.reset(3); run(c, 30)
+    np.testing.assert_allclose(c.buffer(_abi.BUF_POSE), b.buffer(_abi.BUF_POSE), rtol=1e-4, atol=1e-5)
+    assert c.buffer(_abi.BUF_ENV_ORIGINS)[0, 2] == pytest.approx(0.3, abs=VS)
+
+
+def test_ramp_field_behaves_like_the_tilted_plane():
+    """uniform ramp (sloped_terrain) vs the per-arena plane parameter of the same incline: the
+    robot rolls downhill with the same acceleration (expert off: gamma = 0, zero torque)."""
+    N = 2
+    slope = 0.2
+    cfg = build_config(variant="KAMMA_eval", num_envs=N, seed=1)
+    a, b = OracleEnv(cfg), OracleEnv(cfg)
+    T = big_tile_terrain(lambda t: tg.sloped_terrain(t, slope))
+    b.attach_terrain(T, np.zeros((N, 2), np.int32))
+    a.reset(1); b.reset(1)
+    inv = 1.0 / np.sqrt(1 + slope * slope)
+    prm = a.buffer(_abi.BUF_PARAMS)
+    prm[:, 1], prm[:, 2], prm[:, 3] = -slope * inv, 0.0, inv
+    # the plane of `params` passes through the arena origin; so does the field relative to its
+    # origin. The field is quantised (6 mm heights over a 0.41 m wheelbase: +-7 % slope noise)
+    # and sampled with the min-of-two rule, so the comparison is a physical one, not bitwise.
+    p0 = a.buffer(_abi.BUF_POSE)[:, :3].copy()
+    run(a, 50); run(b, 50)
+    da, db = a.buffer(_abi.BUF_POSE)[:, :3] - p0, b.buffer(_abi.BUF_POSE)[:, :3] - p0
+    na, nb = np.linalg.norm(da, axis=1), np.linalg.norm(db, axis=1)
+    assert (na > 1.0).all()  # it does roll downhill
+    assert ((nb / na > 0.8) & (nb / na < 1.3)).all(), nb / na
+    assert ((da * db).sum(1) / (na * nb) > 0.99).all()  # same direction
+    assert (da[:, 2] < -0.1).all() and (db[:, 2] < -0.1).all()
+
+
+def test_driving_over_pyramid_stairs():
+    """Level-2 curriculum stairs (1 m wide, 7.8 cm high; the tile centre is the bottom of the
+    inverted pyramid): with the expert controller (gamma = 1) the robot leaves the platform and
+    climbs step after step, stays upright, its height follows the field, the scan sees steps."""
+    N = 4
+    cfg = build_config(variant="KAMMA_medium", num_envs=N, seed=2, max_sim_steps=1e9)
+    env = OracleEnv(cfg)
+    T = tg.Terrain({"curriculum": True, "numLevels": 4, "numTerrains": 2, "mapLength": 16.0, "mapWidth": 16.0}, N, seed=0)
+    lt = np.array([[2, 0]] * N, np.int32)  # level 2, stairs
+    env.attach_terrain(T, lt, curriculum=False)
+    env.reset(2)
+    org = env.buffer(_abi.BUF_ENV_ORIGINS)[:, :3].copy()
+    assert np.allclose(org, T.env_origins[2, 0])
+    gmax = np.zeros(N)
+    scans = []
+    for t in range(36):
+        env.step(np.zeros((N, 4), np.float32))
+        assert not env.done.any()
+        p, q = env.buffer(_abi.BUF_POSE), env.buffer(_abi.BUF_QUAT)
+        assert np.isfinite(p).all() and (1 - 2 * (q[:, 1] ** 2 + q[:, 2] ** 2) > 0.9).all()  # cos(tilt)
+        g = tg.height_at(T.heightsamples, p[:, 0] + org[:, 0], p[:, 1] + org[:, 1]) - org[:, 2]
+        clearance = p[:, 2] - g  # COM above the ground under it: 0.07 at rest, +- one step while straddling an edge
+        assert (clearance > -0.03).all() and (clearance < 0.17).all(), (t, clearance)
+        gmax = np.maximum(gmax, g)
+        if t == 20:
+            scans.append(env.height_scan())
+    assert (gmax > 0.35).all(), gmax                       # climbed at least 5 steps
+    assert (env.buffer(_abi.BUF_POSE)[:, 3] > 0.8).all()   # still making headway (v_forward_projected)
+    hs = scans[0]
+    assert hs.shape == (N, 140) and all(len(np.unique(np.round(h / VS))) >= 2 for h in hs)
+
+
+def test_random_terrain_soak_stays_finite_and_on_the_ground():
+    """0.15 m steps on 0.31 m treads exceed the wheel radius: robots get launched, tip over, are
+    reset by has_fallen. Whatever happens, the state stays finite (a NaN arena would never
+    reset: every comparison of is_done is false on NaN) and nobody sinks through the field."""
+    N = 600
+    cfg = build_config(variant="KAMMA_medium", num_envs=N, seed=11)
+    T = tg.Terrain({"numLevels": 3, "numTerrains": 2, "mapLength": 8.0, "mapWidth": 8.0}, N, seed=11)
+    lt = T.sample_levels_types(N, rng=np.random.RandomState(1))
+    env = OracleEnv(cfg, threads=4)
+    env.attach_terrain(T, lt)
+    env.reset(11)
+    worst, falls = 0.0, 0
+    for t in range(120):
+        env.step(np.zeros((N, 4), np.float32))
+        p, o = env.buffer(_abi.BUF_POSE), env.buffer(_abi.BUF_ENV_ORIGINS)
+        for bid in (_abi.BUF_POSE, _abi.BUF_QUAT, _abi.BUF_LINVEL, _abi.BUF_ANGVEL, _abi.BUF_WHEEL_VEL, _abi.BUF_OBS,
+                    _abi.BUF_REW, _abi.BUF_LAMBDA_N):
+            assert np.isfinite(env.buffer(bid)).all(), (t, bid)
+        g = tg.height_at(T.heightsamples, p[:, 0] + o[:, 0], p[:, 1] + o[:, 1])
+        worst = min(worst, float((p[:, 2] + o[:, 2] - g).min()))
+        falls += int((env.done & ~env.timeout.astype(bool)).sum())
+    assert worst > -0.35, worst   # at most two 0.15 m steps under the COM while straddling
+    assert falls > 0              # the has_fallen / bounds resets do fire on this terrain
+
+
+def test_terrain_curriculum_levels_and_extras():
+    N = 40
+    cfg = build_config(variant="KAMMA_medium", num_envs=N, seed=6)
+    env = OracleEnv(cfg)
+    T = tg.Terrain({"curriculum": True, "numLevels": 4, "numTerrains": 2, "mapLength": 8.0, "mapWidth": 8.0}, N, seed=0)
+    lt = np.stack([np.arange(N) % 4, np.arange(N) % 2], 1).astype(np.int32)
+    # r1 sums are <= 0 (w1 = -25): threshold_low = -1e9 never fires, threshold_high = -1e9 always does
+    env.attach_terrain(T, lt, curriculum=True, threshold_low=-1e9, threshold_high=-1e9, max_level=3)
+    env.reset(6)
+    assert np.array_equal(env.buffer(_abi.BUF_TERRAIN_IDX)[:, :2], lt)  # post_reset does not move levels (:504)
+    run(env, 99)  # every arena times out once
+    assert env.done.all()
+    idx = env.buffer(_abi.BUF_TERRAIN_IDX)
+    assert np.array_equal(idx[:, 0], np.minimum(lt[:, 0] + 1, 3)) and np.array_equal(idx[:, 1], lt[:, 1])
+    np.testing.assert_allclose(env.buffer(_abi.BUF_ENV_ORIGINS)[:, :3], T.env_origins[idx[:, 0], idx[:, 1]], rtol=1e-6)
+    info = env.episode_info()
+    assert info[_abi.EI_TERRAIN_LEVEL] == pytest.approx(idx[:, 0].mean(), rel=1e-6)
+    # the other direction, and detaching
+    env.attach_terrain(T, lt, curriculum=True, threshold_low=1e9, threshold_high=1e9, max_level=3)
+    env.reset(6); run(env, 99)
+    assert np.array_equal(env.buffer(_abi.BUF_TERRAIN_IDX)[:, 0], np.maximum(lt[:, 0] - 1, 0))
+    env.detach_terrain()
+    assert not env.buffer(_abi.BUF_ENV_ORIGINS).any()
+    with pytest.raises(RuntimeError):
+        env.height_scan()
+    bad = lt.copy(); bad[0, 0] = 9
+    with pytest.raises(RuntimeError):
+        env.attach_terrain(T, bad)
+
+
+# ------------------------------------------------------------------------------------- gpu
+torch = pytest.importorskip("torch")
+
+STATE = [_abi.BUF_POSE, _abi.BUF_QUAT, _abi.BUF_LINVEL, _abi.BUF_ANGVEL, _abi.BUF_WHEEL_VEL, _abi.BUF_COMMANDS,
+         _abi.BUF_SUMS_A, _abi.BUF_SUMS_B, _abi.BUF_LAMBDA_N, _abi.BUF_LAMBDA_L, _abi.BUF_LAMBDA_T, _abi.BUF_WHEEL_TORQS,
+         _abi.BUF_OBS, _abi.BUF_REW, _abi.BUF_ENV_ORIGINS, _abi.BUF_COUNTERS, _abi.BUF_DONE, _abi.BUF_TIMEOUT,
+         _abi.BUF_TERRAIN_IDX]
+
+
+def same_state(dev, orc, where):
+    torch.cuda.synchronize()
+    for bid in STATE:
+        got = dev.buffer(bid).cpu().numpy()
+        if got.dtype == np.bool_:
+            got = got.astype(np.uint8)
+        assert np.array_equal(got, orc.buffer(bid)), f"{where}: buffer {bid} not bit-identical"  # NaN fails too
+
+
+@pytest.mark.gpu
+def test_height_scan_kernel_matches_fixture_through_the_env():
+    """the fixture's world poses are fed through the env state (arena-local pose + origin 0)"""
+    from options_in_simulation_amd.vecenv import NativeEnv
+    d = np.load(os.path.join(G, "refmath_heights.npz"))
+    n = d["base_pos"].shape[0]
+    cfg = build_config(variant="KAMMA_medium", num_envs=n, seed=1)
+    cfg.com_height = 0.0  # base link == COM: the fixture positions are base positions
+    dev, orc = NativeEnv(cfg, "cuda:0"), OracleEnv(cfg)
+
+    class T:
+        heightsamples = d["height_samples"]
+        env_origins = np.zeros((1, 1, 3), np.float32)
+        horizontal_scale, vertical_scale, border_size = float(d["horizontal_scale"]), float(d["vertical_scale"]), float(d["border_size"])
+        cfg = {"curriculum": False}
+    lt = np.zeros((n, 2), np.int32)
+    dev.attach_terrain(T, lt); orc.attach_terrain(T, lt)
+    dev.reset(1); orc.reset(1)
+    pose = np.zeros((n, 4), np.float32); pose[:, :3] = d["base_pos"]
+    dev.buffer(_abi.BUF_POSE).copy_(torch.from_numpy(pose)); orc.buffer(_abi.BUF_POSE)[:] = pose
+    dev.buffer(_abi.BUF_QUAT).copy_(torch.from_numpy(d["base_quat"])); orc.buffer(_abi.BUF_QUAT)[:] = d["base_quat"]
+    got = dev.height_scan().cpu().numpy()
+    assert np.array_equal(got, orc.height_scan())
+    assert np.array_equal(got, d["measured_heights"])
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("env_vars", [{"OIS_PACKED": "0"}, {"OIS_PACKED": "1"}], ids=["scalar", "packed"])
+def test_terrain_step_parity(env_vars, monkeypatch):
+    from options_in_simulation_amd.vecenv import NativeEnv
+    for k, v in env_vars.items():
+        monkeypatch.setenv(k, v)
+    N = 203
+    cfg = build_config(variant="KAMMA_medium", num_envs=N, seed=12, max_sim_steps=150.0)
+    dev, orc = NativeEnv(cfg, "cuda:0"), OracleEnv(cfg)
+    T = tg.Terrain({"numLevels": 2, "numTerrains": 3, "mapLength": 8.0, "mapWidth": 8.0}, N, seed=4)  # random families
+    lt = T.sample_levels_types(N, rng=np.random.RandomState(0))
+    dev.attach_terrain(T, lt); orc.attach_terrain(T, lt)
+    dev.randomize_params(0.5, 1.0); orc.randomize_params(0.5, 1.0)
+    dev.reset(12); orc.reset(12)
+    same_state(dev, orc, "after reset")
+    rng = np.random.default_rng(1)
+    for t in range(110):  # crosses the timeout at 99; obstacles tip some robots over before
+        a = rng.uniform(0, 1, size=(N, 4)).astype(np.float32)
+        dev.step(torch.from_numpy(a).cuda()); orc.step(a)
+        if t % 10 == 0 or t > 96:
+            same_state(dev, orc, f"{env_vars} step {t}")
+    assert np.array_equal(dev.height_scan().cpu().numpy(), orc.height_scan())
+    dev.rollout(25, _abi.POLICY_RANDOM); orc.rollout(25, _abi.POLICY_RANDOM)
+    same_state(dev, orc, "fused rollout on the field")
+    # the field matters: the same run on the plane ends elsewhere
+    flat = OracleEnv(cfg); flat.reset(12)
+    assert not np.allclose(flat.buffer(_abi.BUF_POSE), orc.buffer(_abi.BUF_POSE))
+
+
+@pytest.mark.gpu
+def test_terrain_curriculum_parity_and_errors(monkeypatch):
+    from options_in_simulation_amd.vecenv import NativeEnv
+    N = 150
+    cfg = build_config(variant="KAMMA_medium", num_envs=N, seed=7)
+    dev, orc = NativeEnv(cfg, "cuda:0"), OracleEnv(cfg)
+    T = tg.Terrain({"curriculum": True, "numLevels": 4, "numTerrains": 2, "mapLength": 8.0, "mapWidth": 8.0}, N, seed=0)
+    lt = np.stack([np.arange(N) % 4, np.arange(N) % 2], 1).astype(np.int32)
+    # r1 sums of a 99-step expert episode lie in about [-2200, -100] (median -380)
+    kw = dict(curriculum=True, threshold_low=-500.0, threshold_high=-260.0, max_level=3)
+    dev.attach_terrain(T, lt, **kw); orc.attach_terrain(T, lt, **kw)
+    dev.reset(7); orc.reset(7)
+    z = np.zeros((N, 4), np.float32)
+    for t in range(200):
+        dev.step(torch.from_numpy(z).cuda()); orc.step(z)
+        if t in (98, 99, 197, 199):
+            same_state(dev, orc, f"curriculum step {t}")
+    moved = orc.buffer(_abi.BUF_TERRAIN_IDX)[:, 0] - lt[:, 0]
+    assert (moved > 0).any() and (moved < 0).any()
+    np.testing.assert_array_equal(dev.episode_info().cpu().numpy(), orc.episode_info())
+    assert float(dev.episode_info()[_abi.EI_TERRAIN_LEVEL]) == pytest.approx(orc.buffer(_abi.BUF_TERRAIN_IDX)[:, 0].mean(), rel=1e-6)
+    dev.detach_terrain(); orc.detach_terrain()
+    dev.step(torch.from_numpy(z).cuda()); orc.step(z)
+    same_state(dev, orc, "after detaching")
+    with pytest.raises(RuntimeError):
+        dev.height_scan()
+    bad = lt.copy(); bad[3, 1] = 7
+    with pytest.raises(RuntimeError):
+        dev.attach_terrain(T, bad)
+    monkeypatch.setenv("OIS_LANES_PER_ARENA", "2")
+    pair = NativeEnv(cfg, "cuda:0")
+    with pytest.raises(RuntimeError, match="one lane per arena"):
+        pair.attach_terrain(T, lt)
+
+
+@pytest.mark.gpu
+def test_task_terrain_surface():
+    """what a KAMMA.py with its terrain lines un-commented would touch: get_terrain, env_origins,
+    terrain_levels / types, height_samples, get_heights, the height observation block"""
+    from options_in_simulation_amd import VecEnv, default_task_cfg
+    N = 96
+    cfg = default_task_cfg()
+    cfg["task"]["env"]["numEnvs"] = N
+    cfg["task"]["env"]["terrain"].update({"mapLength": 8.0, "mapWidth": 8.0, "numLevels": 3, "numTerrains": 2})
+    env = VecEnv(cfg, device="cuda:0", variant="KAMMA_medium", seed=11)
+    T = env.task.get_terrain()
+    assert env.task.height_samples.shape == T.heightsamples.shape and env.task.height_samples.dtype == torch.int16
+    lv, ty = env.task.terrain_levels.cpu().numpy(), env.task.terrain_types.cpu().numpy()
+    assert lv.max() <= 2 and ty.max() <= 1 and len(np.unique(lv)) > 1
+    np.testing.assert_allclose(env.task.env_origins.cpu().numpy(), T.env_origins[lv, ty].astype(np.float32))
+    obs, _ = env.reset()
+    for _ in range(5):
+        obs, rew, term, trunc, info = env.step(torch.rand((N, 4), device="cuda"))
+    h = env.task.get_heights()
+    assert h.shape == (N, 140) and torch.isfinite(h).all()
+    assert torch.equal(env.task.get_heights(env_ids=[1, 5]), h[[1, 5]])
+    # heights are field values: every one is a multiple of vertical_scale present in the field
+    raw = torch.round(h / T.vertical_scale).to(torch.int64)
+    assert torch.isin(raw, torch.unique(env.task.height_samples).to(torch.int64)).all()
+    ho = env.task.height_observation(height_meas_scale=2.0)
+    assert ho.shape == (N, 140) and float(ho.abs().max()) <= 2.0
+    # COM height over the ground under it: 0.07 at rest; on the 0.31 m x 0.15 m stairs the 0.41 m
+    # wheelbase spans up to two steps, so single arenas may sit two step heights off
+    p = env.task.base_pos.cpu().numpy(); o = env.task.env_origins.cpu().numpy()
+    g = tg.height_at(T.heightsamples, p[:, 0] + o[:, 0], p[:, 1] + o[:, 1])
+    cl = p[:, 2] + o[:, 2] - g
+    assert np.median(cl) == pytest.approx(0.0705, abs=0.03) and (cl > -0.35).all() and (cl < 0.6).all()
+    assert float(info["episode"]["terrain_level"]) == pytest.approx(lv.mean(), rel=1e-6)
+    env.close()
