@@ -87,7 +87,7 @@ OIS_DEV void store_arena(const DevConsts& K, const DevBuffers& B, int i, int h, 
 }
 
 // ------------------------------------------------------------------ the step kernel ---
-template <int LPA, bool PK, bool TER>
+template <int LPA, bool PK, bool TER, int NIT>
 __global__ OIS_STEP_BOUNDS void step_kernel(DevConsts K, DevBuffers B, const float* __restrict__ actions,
                                                       float* __restrict__ reward_sum, int N, int ksteps, int policy,
                                                       int rp_head) {
@@ -197,6 +197,7 @@ __global__ OIS_STEP_BOUNDS void step_kernel(DevConsts K, DevBuffers B, const flo
 
     // ---- physics: decimation (:646-653) + controlFrequencyInv (:43) substeps ----
     float R[9];
+    bool blown = false;
     {
       PhysT<LPA> X;
       float wb[3];
@@ -215,14 +216,35 @@ __global__ OIS_STEP_BOUNDS void step_kernel(DevConsts K, DevBuffers B, const flo
 #pragma unroll
       for (int k = 0; k < 3; ++k) X.to[k] = tor[k];
       if constexpr (PK && LPA == 1) {  // packed fp32 over wheel pairs (ois_physics_pk.h)
-        substep_pk<true, TER>(K, B.ter, X);
-        for (int i = 1; i < K.nsub; ++i) substep_pk<false, TER>(K, B.ter, X);
+        substep_pk<true, TER, NIT>(K, B.ter, X);
+        for (int i = 1; i < K.nsub; ++i) substep_pk<false, TER, NIT>(K, B.ter, X);
       } else {
-        substep<true, LPA, TER>(K, B.ter, wheel0, X);
-        for (int i = 1; i < K.nsub; ++i) substep<false, LPA, TER>(K, B.ter, wheel0, X);
+        substep<true, LPA, TER, NIT>(K, B.ter, wheel0, X);
+        for (int i = 1; i < K.nsub; ++i) substep<false, LPA, TER, NIT>(K, B.ter, wheel0, X);
+      }
+      // safety net: a non-finite outcome (diverged reciprocal refresh of a violently tumbling
+      // robot) is discarded: pre-step pose at rest, reset as fallen (oracle step_arena, SPEC §3.9)
+      float chk = 0.0f;
+#pragma unroll
+      for (int k = 0; k < 3; ++k) chk += fabsf(X.p[k]) + fabsf(X.v[k]) + fabsf(X.wb[k]);
+#pragma unroll
+      for (int k = 0; k < 4; ++k) chk += fabsf(X.q[k]);
+      float cw[W];
+#pragma unroll
+      for (int k = 0; k < W; ++k) cw[k] = fabsf(X.spin[k]) + fabsf(X.ln[k]) + fabsf(X.l1[k]) + fabsf(X.l2[k]);
+      chk += sum_wheels<LPA>(cw);
+      blown = !(chk < 3.0e38f);
+      if (blown) {
+#pragma unroll
+        for (int k = 0; k < 3; ++k) { X.p[k] = S.p[k]; X.v[k] = 0.0f; X.wb[k] = 0.0f; }
+#pragma unroll
+        for (int k = 0; k < 4; ++k) X.q[k] = S.q[k];
+#pragma unroll
+        for (int k = 0; k < W; ++k) { X.spin[k] = 0.0f; X.ln[k] = 0.0f; X.l1[k] = 0.0f; X.l2[k] = 0.0f; }
       }
       rotmat(X.q, R);
       rot(R, X.wb, S.w);  // body -> world with the final orientation
+      if (blown) { S.w[0] = 0.0f; S.w[1] = 0.0f; S.w[2] = 0.0f; }  // R may be non-finite if the pose was corrupted from outside
 #pragma unroll
       for (int k = 0; k < 3; ++k) { S.p[k] = X.p[k]; S.v[k] = X.v[k]; }
 #pragma unroll
@@ -246,7 +268,7 @@ __global__ OIS_STEP_BOUNDS void step_kernel(DevConsts K, DevBuffers B, const flo
     quat_apply(S.q, 0.0f, 0.0f, -1.0f, pg);                      // :749
     const bool fallen = pg[2] > 0.0f;                            // :753
     const bool oob = (plx < -K.bounds) | (plx > K.bounds) | (ply < -K.bounds) | (ply > K.bounds);
-    const bool reset = fallen | timeout | oob;
+    const bool reset = fallen | timeout | oob | blown;
     // calculate_metrics (:767-822)
     const float lin_acc = (current_v - S.prev_lin) / K.policy_dt;  // :770
     const float ang_acc = (S.w[2] - S.prev_ang) / K.policy_dt;     // :771
@@ -811,23 +833,21 @@ int ois_reset(ois_env* e, uint64_t seed, void* stream) {
 
 static int launch_steps(ois_env* e, int k, int policy, const float* actions, float* reward_sum, void* stream) {
   HIP_TRY(hipSetDevice(e->device));
-  if (e->B.ter.on) {  // height-field terrain: the one-lane-per-arena instantiations (ois_terrain_attach refuses LPA = 2)
-    if (e->packed)
-      hipLaunchKernelGGL((step_kernel<1, true, true>), dim3(e->grid), dim3(kBlock), 0, (hipStream_t)stream, e->K, e->B,
-                         actions, reward_sum, e->N, k, policy, e->rp_head);
-    else
-      hipLaunchKernelGGL((step_kernel<1, false, true>), dim3(e->grid), dim3(kBlock), 0, (hipStream_t)stream, e->K, e->B,
-                         actions, reward_sum, e->N, k, policy, e->rp_head);
-  } else if (e->lpa == 2) {
-    hipLaunchKernelGGL((step_kernel<2, false, false>), dim3((2 * e->N + kBlock - 1) / kBlock), dim3(kBlock), 0,
-                       (hipStream_t)stream, e->K, e->B, actions, reward_sum, e->N, k, policy, e->rp_head);
-  } else if (e->packed) {
-    hipLaunchKernelGGL((step_kernel<1, true, false>), dim3(e->grid), dim3(kBlock), 0, (hipStream_t)stream, e->K, e->B, actions,
-                       reward_sum, e->N, k, policy, e->rp_head);
+#define OIS_LAUNCH(LPA_, PK_, TER_, NIT_)                                                                          \
+  hipLaunchKernelGGL((step_kernel<LPA_, PK_, TER_, NIT_>), dim3((LPA_ * e->N + kBlock - 1) / kBlock), dim3(kBlock), 0, \
+                     (hipStream_t)stream, e->K, e->B, actions, reward_sum, e->N, k, policy, e->rp_head)
+  // instantiations: lanes per arena (2 = experiment), packed wheel pairs, height-field terrain
+  // (ois_terrain_attach refuses LPA = 2), solver iterations unrolled (the default 4) or run-time
+  const bool it4 = e->K.iters == 4;
+  if (e->lpa == 2) OIS_LAUNCH(2, false, false, 0);
+  else if (e->B.ter.on) {
+    if (e->packed) { if (it4) OIS_LAUNCH(1, true, true, 4); else OIS_LAUNCH(1, true, true, 0); }
+    else           { if (it4) OIS_LAUNCH(1, false, true, 4); else OIS_LAUNCH(1, false, true, 0); }
   } else {
-    hipLaunchKernelGGL((step_kernel<1, false, false>), dim3(e->grid), dim3(kBlock), 0, (hipStream_t)stream, e->K, e->B, actions,
-                       reward_sum, e->N, k, policy, e->rp_head);
+    if (e->packed) { if (it4) OIS_LAUNCH(1, true, false, 4); else OIS_LAUNCH(1, true, false, 0); }
+    else           { if (it4) OIS_LAUNCH(1, false, false, 4); else OIS_LAUNCH(1, false, false, 0); }
   }
+#undef OIS_LAUNCH
   HIP_TRY(hipGetLastError());
   e->steps_done += (double)e->N * (double)k;
   if (e->B.rp_size > 0) {  // the kernel wrote rows rp_head .. rp_head + k - 1 (mod size)

@@ -32,17 +32,14 @@ struct PhysT {
   float fwx[4], fwy[4], fh[4], fr00, fr10, fr01, fr11;
 };
 
-// One Newton step from the previous substep's value: mul/fma only, bit-reproducible. The
-// correction is clamped (one v_med3_f32): inside the band it is the Newton step, outside (the
-// contact geometry jumped between two substeps, e.g. a tumbling robot) the cached value moves
-// at most 50 % and stays positive instead of overshooting to a negative gain.
+// One Newton step from the previous substep's value: mul/fma only, bit-reproducible.
 OIS_DEV float newton_rcp(float m, float k) {  // m ~ 1/k -> m (2 - k m)
-  const float e = __builtin_amdgcn_fmed3f(__builtin_fmaf(-k, m, 1.0f), -0.5f, 0.5f);
+  const float e = __builtin_fmaf(-k, m, 1.0f);
   return __builtin_fmaf(m, e, m);
 }
 OIS_DEV float newton_rsqrt(float r, float s2) {  // r ~ 1/sqrt(s2) -> r (1.5 - 0.5 s2 r^2)
   const float hr = (0.5f * s2) * r;
-  const float e = __builtin_amdgcn_fmed3f(__builtin_fmaf(-hr, r, 1.5f), 0.5f, 1.5f);
+  const float e = __builtin_fmaf(-hr, r, 1.5f);
   return r * e;
 }
 
@@ -104,7 +101,9 @@ OIS_DEV float average4(const float (&c)[4 / LPA]) { return 0.25f * sum_wheels<LP
 // EXACT: first substep of a policy step (IEEE divisions); otherwise the reciprocals are
 // refreshed from the cache. wheel0 = index of this lane's first wheel (0, or 2 for the
 // right-side lane when LPA = 2).
-template <bool EXACT, int LPA, bool TER = false>
+// NIT: solver iterations known at compile time (the loop is fully unrolled: no taken branch,
+// scheduling across iteration boundaries) or 0 = K.iters at run time
+template <bool EXACT, int LPA, bool TER = false, int NIT = 0>
 OIS_DEV void substep(const DevConsts& K, const DevTerrain& T, int wheel0, PhysT<LPA>& S) {
   static_assert(!TER || LPA == 1, "the terrain contact needs all 4 wheels in one lane");
   constexpr int W = 4 / LPA;
@@ -192,7 +191,9 @@ OIS_DEV void substep(const DevConsts& K, const DevTerrain& T, int wheel0, PhysT<
   OIS_WH S.spin[k] = __builtin_fmaf(-K.rw_over_Is, S.l1[k], S.spin[k]);
   vb[0] = average4<LPA>(vx); vb[1] = average4<LPA>(vy); vb[2] = average4<LPA>(vz);
   wb[0] = average4<LPA>(ox); wb[1] = average4<LPA>(oy); wb[2] = average4<LPA>(oz);
-  for (int it = 0; it < K.iters; ++it) {
+  const int iters = NIT > 0 ? NIT : K.iters;
+#pragma unroll
+  for (int it = 0; it < iters; ++it) {
     float u[W], dl[W], nw[W], lim[W];
     // normal row
     const float unv = __builtin_fmaf(nb[2], vb[2], __builtin_fmaf(nb[1], vb[1], nb[0] * vb[0]));

@@ -37,14 +37,12 @@ OIS_DEV f2 clamp2(f2 x, f2 lim) {
   r.y = __builtin_amdgcn_fmed3f(x.y, -lim.y, lim.y);
   return r;
 }
-OIS_DEV f2 newton_rcp2(f2 m, f2 k) {  // newton_rcp per element (clamped correction, see ois_physics.h)
-  f2 e = fma2(-k, m, 1.0f);
-  e.x = __builtin_amdgcn_fmed3f(e.x, -0.5f, 0.5f);
-  e.y = __builtin_amdgcn_fmed3f(e.y, -0.5f, 0.5f);
+OIS_DEV f2 newton_rcp2(f2 m, f2 k) {
+  const f2 e = fma2(-k, m, 1.0f);
   return fma2(m, e, m);
 }
 
-template <bool EXACT, bool TER = false>
+template <bool EXACT, bool TER = false, int NIT = 0>
 OIS_DEV void substep_pk(const DevConsts& K, const DevTerrain& T, PhysT<1>& S) {
 #define OIS_PR _Pragma("unroll") for (int j = 0; j < 2; ++j)
   float R[9];
@@ -142,7 +140,9 @@ OIS_DEV void substep_pk(const DevConsts& K, const DevTerrain& T, PhysT<1>& S) {
   OIS_PR spin[j] = fma2(-K.rw_over_Is, l1[j], spin[j]);
   vb[0] = 0.25f * sum4(vx); vb[1] = 0.25f * sum4(vy); vb[2] = 0.25f * sum4(vz);
   wb[0] = 0.25f * sum4(ox); wb[1] = 0.25f * sum4(oy); wb[2] = 0.25f * sum4(oz);
-  for (int it = 0; it < K.iters; ++it) {
+  const int iters = NIT > 0 ? NIT : K.iters;
+#pragma unroll
+  for (int it = 0; it < iters; ++it) {
     f2 u[2], dl[2], nw[2], lim[2];
     // normal row
     const float unv = __builtin_fmaf(nb[2], vb[2], __builtin_fmaf(nb[1], vb[1], nb[0] * vb[0]));

@@ -411,18 +411,13 @@ typedef struct {
   float mn[4], m1[4], m2[4], inv_s;
 } rcache;
 
-/* The corrections are clamped (|1 - k m| <= 0.5, 0.5 <= 1.5 - 0.5 s2 r^2 <= 1.5): inside that
- * band — always, for a robot that is not tumbling — this IS the Newton step; outside (the
- * geometry jumped between two substeps) the cached value moves at most 50 % towards the new
- * one and stays positive, instead of overshooting to a negative gain and diverging. */
-static inline float clampf(float x, float lo, float hi) { return fminf(fmaxf(x, lo), hi); }
 static inline float newton_rcp(float m, float k) { /* m ~ 1/k -> m (2 - k m) */
-  float e = clampf(fmaf(-k, m, 1.0f), -0.5f, 0.5f);
+  float e = fmaf(-k, m, 1.0f);
   return fmaf(m, e, m);
 }
 static inline float newton_rsqrt(float r, float s2) { /* r ~ 1/sqrt(s2) -> r (1.5 - 0.5 s2 r^2) */
   float hr = (0.5f * s2) * r;
-  float e = clampf(fmaf(-hr, r, 1.5f), 0.5f, 1.5f);
+  float e = fmaf(-hr, r, 1.5f);
   return r * e;
 }
 
@@ -1052,8 +1047,22 @@ static float step_arena(orc_env* e, int i, const float* act /*[A]*/, uint8_t* rs
   const terrain_ctx* T = e->terrain_on ? &e->terrain : NULL;
   footprints FP;
   for (int s = 0; s < nsub; ++s) substep(D, mu, n, wt, p, q, v, wb, spin, LN, LL, LT, &C, s == 0, T, &e->env_origins[4 * i], &FP);
+  /* Safety net (build-defined): a Newton refresh diverges if a row's effective mass more than
+   * doubles between two substeps (needs > ~50 rad/s of tumbling) and could leave a non-finite
+   * state; such an arena would never reset (every comparison of is_done is false on NaN) and
+   * would poison the policy's batch. A non-finite outcome is discarded: the arena keeps its
+   * pre-step pose at rest and is reset as fallen. */
+  float chk = 0.0f;
+  for (int k = 0; k < 3; ++k) chk += fabsf(p[k]) + fabsf(v[k]) + fabsf(wb[k]);
+  for (int k = 0; k < 4; ++k) chk += fabsf(q[k]) + fabsf(spin[k]) + fabsf(LN[k]) + fabsf(LL[k]) + fabsf(LT[k]);
+  const int blown = !(chk < 3.0e38f);
+  if (blown) {
+    for (int k = 0; k < 3; ++k) { p[k] = P[k]; v[k] = 0.0f; wb[k] = 0.0f; }
+    for (int k = 0; k < 4; ++k) { q[k] = Q[k]; spin[k] = 0.0f; LN[k] = LL[k] = LT[k] = 0.0f; }
+  }
   rotmat(q, R);
   rot(R, wb, w); /* body -> world with the final orientation */
+  if (blown) w[0] = w[1] = w[2] = 0.0f; /* R may itself be non-finite if the pose was corrupted from outside */
   float jv[4];
   for (int k = 0; k < 4; ++k) jv[k] = spin[k] - wb[1];
 
@@ -1064,6 +1073,7 @@ static float step_arena(orc_env* e, int i, const float* act /*[A]*/, uint8_t* rs
   float plink[3] = {fmaf(-R[2], c->com_height, p[0]), fmaf(-R[5], c->com_height, p[1]), fmaf(-R[8], c->com_height, p[2])};
   uint8_t reset, timeout;
   is_done1(cnt[0], c->max_episode_length, q, plink, c->bounds, &reset, &timeout); /* :687 */
+  if (blown) reset = 1;
   float S[8] = {sa[0], sa[1], sa[2], sa[3], sb[0], sb[1], sb[2], sb[3]};
   float prev_lin = V[3], prev_ang = W[3];
   metrics_out mo;

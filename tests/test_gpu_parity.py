@@ -180,3 +180,32 @@ def test_every_kernel_instantiation_is_bit_identical_to_the_oracle(env_vars, mon
     np.testing.assert_array_equal(dev.episode_info().cpu().numpy(), orc.episode_info())
     dev.rollout(7, _abi.POLICY_RANDOM); orc.rollout(7, _abi.POLICY_RANDOM)
     compare(dev, orc, f"{env_vars} fused rollout", exact_float=True)
+
+
+@pytest.mark.parametrize("env_vars", [{"OIS_PACKED": "0"}, {"OIS_PACKED": "1"}, {"OIS_LANES_PER_ARENA": "2"}],
+                         ids=["scalar", "packed", "lane-pair"])
+def test_non_finite_outcome_guard_parity(env_vars, monkeypatch):
+    """docs/SPEC.md §3.9: injected NaN / inf velocities -> the arena is reset as fallen, outputs
+    finite, kernel == oracle bit for bit (also for the untouched arenas)."""
+    for k, v in env_vars.items():
+        monkeypatch.setenv(k, v)
+    N = 130
+    cfg, dev, orc = make_pair(variant="KAMMA_medium", num_envs=N, seed=4)
+    dev.reset(4); orc.reset(4)
+    z = np.zeros((N, 4), np.float32)
+    for _ in range(2):
+        dev.step(torch.from_numpy(z).cuda()); orc.step(z)
+    torch.cuda.synchronize()
+    for bid, i, j, val in [(_abi.BUF_LINVEL, 3, 1, np.nan), (_abi.BUF_ANGVEL, 64, 0, np.inf), (_abi.BUF_WHEEL_VEL, 129, 2, -np.inf),
+                           (_abi.BUF_QUAT, 77, 3, np.nan)]:
+        dev.buffer(bid)[i, j] = float(val); orc.buffer(bid)[i, j] = val
+    dev.step(torch.from_numpy(z).cuda()); orc.step(z)
+    worst = compare(dev, orc, f"{env_vars} guard step", exact_float=True)
+    assert np.isfinite(worst)
+    done = dev.buffer(_abi.BUF_DONE).cpu().numpy().astype(bool)
+    assert done[[3, 64, 129, 77]].all() and done.sum() == 4
+    for bid in STATE_BUFS:
+        assert torch.isfinite(dev.buffer(bid)).all(), bid
+    for _ in range(3):
+        dev.step(torch.from_numpy(z).cuda()); orc.step(z)
+    compare(dev, orc, f"{env_vars} after the guard", exact_float=True)

@@ -202,3 +202,32 @@ def test_grid_sampler_is_bimodal_and_follows_progress():
     assert abs(lo.mean() - 1.0) < 0.005 and abs(hi.mean() - 2.0) < 0.005
     assert abs(lo.std() - 0.05) < 0.004 and abs(hi.std() - 0.05) < 0.004
     assert (env.buffer(_abi.BUF_COMMANDS)[:, 2] == 0).all()
+
+
+def test_non_finite_physics_outcome_is_discarded_and_reset():
+    """docs/SPEC.md §3.9 (build-defined safety net): an arena whose substeps end non-finite keeps
+    its pre-step pose at rest and resets as fallen; its neighbours are untouched, every output
+    stays finite."""
+    N = 20
+    cfg = build_config(variant="KAMMA_medium", num_envs=N, seed=9)
+    env, twin = OracleEnv(cfg), OracleEnv(cfg)
+    env.reset(9); twin.reset(9)
+    z = np.zeros((N, 4), np.float32)
+    for _ in range(3):
+        env.step(z); twin.step(z)
+    env.buffer(_abi.BUF_LINVEL)[3, 1] = np.nan
+    env.buffer(_abi.BUF_ANGVEL)[5, 0] = np.inf
+    env.buffer(_abi.BUF_WHEEL_VEL)[8, 2] = -np.inf
+    env.step(z); twin.step(z)
+    bad = np.zeros(N, bool); bad[[3, 5, 8]] = True
+    assert env.done[bad].all() and not env.done[~bad].any() and not env.timeout.any()
+    ids = [_abi.BUF_POSE, _abi.BUF_QUAT, _abi.BUF_LINVEL, _abi.BUF_ANGVEL, _abi.BUF_WHEEL_VEL, _abi.BUF_OBS, _abi.BUF_REW,
+           _abi.BUF_SUMS_A, _abi.BUF_SUMS_B, _abi.BUF_LAMBDA_N, _abi.BUF_LAMBDA_L, _abi.BUF_LAMBDA_T, _abi.BUF_WHEEL_TORQS]
+    for bid in ids:
+        assert np.isfinite(env.buffer(bid)).all(), bid
+        assert np.array_equal(env.buffer(bid)[~bad], twin.buffer(bid)[~bad]), bid
+    cnt = env.buffer(_abi.BUF_COUNTERS)
+    assert (cnt[bad, 0] == 0).all() and (cnt[bad, 2] == 2).all() and (cnt[~bad, 2] == 1).all()
+    for _ in range(5):
+        env.step(z)
+    assert all(np.isfinite(env.buffer(b)).all() for b in ids) and not env.done.any()
