@@ -22,7 +22,10 @@ using namespace ois;
 
 namespace {
 
-constexpr int kBlock = 64;  // one wave per workgroup
+#ifndef OIS_BLOCK
+#define OIS_BLOCK 64  // threads per workgroup of the step / reset kernels (one wave)
+#endif
+constexpr int kBlock = OIS_BLOCK;
 #ifndef OIS_STEP_BOUNDS
 #define OIS_STEP_BOUNDS __launch_bounds__(kBlock)
 #endif
@@ -141,7 +144,7 @@ __global__ OIS_STEP_BOUNDS void step_kernel(DevConsts K, DevBuffers B, const flo
     }
     float aw[W];
 #pragma unroll
-    for (int k = 0; k < W; ++k) aw[k] = (LPA == 1) ? a4[k] : (h ? a4[2 + k] : a4[k]);
+    for (int k = 0; k < W; ++k) aw[k] = (LPA == 1) ? a4[k] : (h ? a4[(2 + k) & 3] : a4[k]);  // & 3: constant index for LPA = 1 too (no LDS array)
     // ---- pre_physics_step (KAMMA.py:596-656) ----
     const float current_v = S.vfwd;      // :607
     const float current_omega = S.w[2];  // :608
@@ -777,7 +780,7 @@ int ois_create(const ois_config* cfg, int device, void* workspace_device, size_t
     int cus = 0;
     if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device) != hipSuccess || cus <= 0) cus = 256;
     const char* pk = getenv("OIS_PACKED");
-    e->packed = pk ? (pk[0] == '1') : (e->grid <= 4 * cus);
+    e->packed = pk ? (pk[0] == '1') : ((e->N + 63) / 64 <= 4 * cus);  // waves <= SIMDs
   }
   e->seed = cfg->seed;
   e->reset_done = false;

@@ -26,8 +26,8 @@ OIS_DEV f2 max2(f2 a, f2 b) { f2 r; r.x = fmaxf(a.x, b.x); r.y = fmaxf(a.y, b.y)
 OIS_DEV f2 min2(f2 a, f2 b) { f2 r; r.x = fminf(a.x, b.x); r.y = fminf(a.y, b.y); return r; }
 // pair j = wheels (j, j + 2): j = 0 front (fl, fr), j = 1 rear (rl, rr). With this pairing the
 // SPEC's wheel sum (w0 + w1) + (w2 + w3) is one packed add {w0 + w1, w2 + w3} and one scalar add.
-OIS_DEV f2 ld2(const float* p) { f2 r; r.x = p[0]; r.y = p[2]; return r; }
-OIS_DEV void st2(float* p, f2 v) { p[0] = v.x; p[2] = v.y; }
+template <int N> OIS_DEV f2 ld2(const float (&a)[N], int j) { f2 r; r.x = a[j]; r.y = a[j + 2]; return r; }
+template <int N> OIS_DEV void st2(float (&a)[N], int j, f2 v) { a[j] = v.x; a[j + 2] = v.y; }
 OIS_DEV float sum4(const f2 (&c)[2]) { const f2 s = c[0] + c[1]; return s.x + s.y; }
 // clamp(x, -lim, lim) with lim >= 0: one v_med3_f32 instead of v_max + v_min (same value for
 // every non-NaN input)
@@ -62,10 +62,11 @@ OIS_DEV void substep_pk(const DevConsts& K, const DevTerrain& T, PhysT<1>& S) {
   vb[2] = __builtin_fmaf(-K.gdt, R[8], vb[2]);
   f2 spin[2], tau[2], ln[2], l1[2], l2[2], mn[2], m1[2], m2[2];
   OIS_PR {
-    spin[j] = ld2(&S.spin[j]); tau[j] = ld2(&S.tau[j]);
-    ln[j] = ld2(&S.ln[j]); l1[j] = ld2(&S.l1[j]); l2[j] = ld2(&S.l2[j]);
-    mn[j] = ld2(&S.mn[j]); m1[j] = ld2(&S.m1[j]); m2[j] = ld2(&S.m2[j]);
+    spin[j] = ld2(S.spin, j);
+    ln[j] = ld2(S.ln, j); l1[j] = ld2(S.l1, j); l2[j] = ld2(S.l2, j);
+    mn[j] = ld2(S.mn, j); m1[j] = ld2(S.m1, j); m2[j] = ld2(S.m2, j);
   }
+  tau[0].x = S.tau[0]; tau[0].y = S.tau[2]; tau[1].x = S.tau[1]; tau[1].y = S.tau[3];  // constant indices: keeps tau out of LDS
   // wheel drive + viscous joint damping, reaction on the chassis
   f2 Tq[2];
   OIS_PR {
@@ -96,7 +97,7 @@ OIS_DEV void substep_pk(const DevConsts& K, const DevTerrain& T, PhysT<1>& S) {
     const float cx = j ? -K.wx : K.wx;  // front axle +x, rear axle -x
     const float rx = __builtin_fmaf(K.rw, dx, cx);
     // gap = np + fma(nb2, rz, fma(nb1, ry, nb0 * rx))
-    const f2 gap = (TER ? np - ld2(&off[j]) : (f2)(np)) + fma2(nb[2], (f2)(rz), fma2(nb[1], ry, nb[0] * rx));
+    const f2 gap = (TER ? np - ld2(off, j) : (f2)(np)) + fma2(nb[2], (f2)(rz), fma2(nb[1], ry, nb[0] * rx));
     f2 bb;
     bb.x = gap.x >= 0.0f ? -(gap.x * K.inv_dt) : fminf(-(gap.x * K.beta_inv_dt), K.vdep);
     bb.y = gap.y >= 0.0f ? -(gap.y * K.inv_dt) : fminf(-(gap.y * K.beta_inv_dt), K.vdep);
@@ -199,9 +200,9 @@ OIS_DEV void substep_pk(const DevConsts& K, const DevTerrain& T, PhysT<1>& S) {
     wb[0] = 0.25f * sum4(ox); wb[1] = 0.25f * sum4(oy); wb[2] = 0.25f * sum4(oz);
   }
   OIS_PR {
-    st2(&S.spin[j], clamp2(spin[j], (f2)(K.maxw)));
-    st2(&S.ln[j], ln[j]); st2(&S.l1[j], l1[j]); st2(&S.l2[j], l2[j]);
-    st2(&S.mn[j], mn[j]); st2(&S.m1[j], m1[j]); st2(&S.m2[j], m2[j]);
+    st2(S.spin, j, clamp2(spin[j], (f2)(K.maxw)));
+    st2(S.ln, j, ln[j]); st2(S.l1, j, l1[j]); st2(S.l2, j, l2[j]);
+    st2(S.mn, j, mn[j]); st2(S.m1, j, m1[j]); st2(S.m2, j, m2[j]);
   }
   // linear velocity back to the world frame, velocity caps (origin_v18.py:65-70), integrate
   rot(R, vb, S.v);
