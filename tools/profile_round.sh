@@ -1,0 +1,49 @@
+#!/bin/bash
+# Regenerates the measured artefacts of one round on the GPU box (run through gpurun from the
+# repo root): bench lines, the rocprofv3 kernel-trace summary of the same command, and the HBM
+# traffic counters (separate --pmc passes, as the microarch guide prescribes).
+#   tools/profile_round.sh r1        -> gpurun_out/r1_*   (copy what is judged into profiles/)
+set -e -o pipefail
+R=${1:-r1}
+OUT=$PWD/gpurun_out
+mkdir -p $OUT
+export TMPDIR=/tmp
+python bench.py > $OUT/${R}_bench.json 2> $OUT/${R}_bench.err
+echo "bench done" && tail -c 300 $OUT/${R}_bench.json
+python bench.py --no-actor --no-cpu-baseline --steps 400 --warmup 40 > $OUT/${R}_bench_envonly.json 2>> $OUT/${R}_bench.err
+P=/tmp/ois_prof_$$
+rm -rf $P && mkdir -p $P
+(cd /tmp && rocprofv3 --kernel-trace --stats --output-format csv -d $P/kt -- python3 $OLDPWD/bench.py --steps 100 --warmup 10 --no-cpu-baseline > $OUT/${R}_bench_under_rocprof.json 2> $P/kt.err) || { tail -5 $P/kt.err; exit 1; }
+cp $(find $P/kt -name '*kernel_stats.csv' | head -1) $OUT/${R}_bench_kernel_stats.csv
+echo "kernel trace done"
+for C in FETCH_SIZE WRITE_SIZE; do
+  (cd /tmp && rocprofv3 --pmc $C --kernel-trace --output-format csv -d $P/$C -- python3 $OLDPWD/bench.py --steps 60 --warmup 10 --no-actor --no-cpu-baseline > /dev/null 2> $P/$C.err) || { tail -5 $P/$C.err; exit 1; }
+  cp $(find $P/$C -name '*counter_collection.csv' | head -1) $P/$C.csv
+done
+python3 - "$P" "$OUT" "$R" <<'PY'
+import csv, json, sys
+P, OUT, R = sys.argv[1:4]
+res = {}
+for c in ("FETCH_SIZE", "WRITE_SIZE"):
+    vals = []
+    rows = list(csv.DictReader(open(f"{P}/{c}.csv")))
+    for r in rows:
+        if "step_kernel" in r.get("Kernel_Name", "") and r.get("Counter_Name") == c:
+            vals.append(float(r["Counter_Value"]))
+    res[c] = vals
+    with open(f"{OUT}/{R}_pmc_{c.split('_')[0].lower()}_sample.csv", "w") as f:
+        w = csv.writer(f); w.writerow(["Kernel_Name", "Counter_Name", "Counter_Value"])
+        for r in [x for x in rows if "step_kernel" in x.get("Kernel_Name", "")][:12]:
+            w.writerow([r["Kernel_Name"][:60], r["Counter_Name"], r["Counter_Value"]])
+f, w = res["FETCH_SIZE"], res["WRITE_SIZE"]
+fm, wm = sum(f) / len(f), sum(w) / len(w)
+out = {"FETCH_SIZE_KB_per_launch_mean": fm, "FETCH_SIZE_launches": len(f), "WRITE_SIZE_KB_per_launch_mean": wm,
+       "WRITE_SIZE_launches": len(w), "fetch_correction": 2.0,
+       "hbm_bytes_per_launch": (2.0 * fm + wm) * 1024.0, "arenas": 65536,
+       "kernel": "step_kernel<1,true,false,4> (one arena per lane, packed fp32 over wheel pairs, 1 policy step per launch)",
+       "command": "rocprofv3 --pmc FETCH_SIZE|WRITE_SIZE --kernel-trace --output-format csv -- python3 bench.py --steps 60 "
+                  "--warmup 10 --no-actor --no-cpu-baseline (two separate passes; FETCH_SIZE x2 = the guide's gfx950 correction)"}
+json.dump(out, open(f"{OUT}/{R}_pmc_traffic.json", "w"), indent=1)
+print(json.dumps(out))
+PY
+grep step_kernel $OUT/${R}_bench_kernel_stats.csv | cut -c1-200
