@@ -251,3 +251,47 @@ def timeseries_from_events(path: str) -> Tuple[List[int], Dict[str, List[float]]
                     table.setdefault(step, {})[c] = v
     steps = sorted(table)
     return steps, {c: [table[s].get(c, float("nan")) for s in steps] for c in CSV_COLUMNS}
+
+
+# ---- eval artefact: tracking error vs commanded speed (src/options_sim/cli/eval_artifacts.py) ----
+TRACKING_ERR_TAGS = ("Info / rew_Tracking error", "Info/rew_Tracking error", "tracking_error")
+DESIRED_VEL_TAGS = ("Info / rew_Desired velocity", "Info/rew_Desired velocity", "desired_velocity")
+
+
+def write_tracking_error_vs_speed(event_path: str, out_csv: Optional[str] = None, smooth: int = 0,
+                                  vmin: float = 1.0, vmax: float = 2.0) -> Tuple[List[float], List[float]]:
+    """``tracking_error_vs_speed.csv`` (columns ``speed_m_s,tracking_error_m_s``) from an eval
+    run's event file, as eval_artifacts.py:120-160 builds it: the desired-velocity series
+    left-joined with the tracking-error series on the step (a vmin→vmax ramp if the former is
+    missing), optional trailing moving average over the error."""
+    series: Dict[str, List[Tuple[int, float]]] = defaultdict(list)
+    for step, _, scalars in read_events(event_path):
+        for tag, v in scalars.items():
+            series[tag].append((step, v))
+    te = next((series[t] for t in TRACKING_ERR_TAGS if series.get(t)), None)
+    dv = next((series[t] for t in DESIRED_VEL_TAGS if series.get(t)), None)
+    if not te:
+        raise ValueError(f"no tracking-error series in {event_path} (tags tried: {TRACKING_ERR_TAGS})")
+    if dv:
+        by_step = dict(te)
+        xs = [v for s, v in dv if s in by_step]
+        ys = [by_step[s] for s, _ in dv if s in by_step]
+    else:
+        n = len(te)
+        xs = [vmin + (vmax - vmin) * i / max(n - 1, 1) for i in range(n)]
+        ys = [v for _, v in te]
+    if smooth and smooth > 1:
+        out, window, total = [], [], 0.0
+        for v in ys:
+            window.append(v); total += v
+            if len(window) > smooth:
+                total -= window.pop(0)
+            out.append(total / len(window))
+        ys = out
+    if out_csv is None:
+        out_csv = os.path.join(os.path.dirname(event_path), "tracking_error_vs_speed.csv")
+    with open(out_csv, "w", newline="") as f:
+        w = csv.writer(f)
+        w.writerow(["speed_m_s", "tracking_error_m_s"])
+        w.writerows(zip(xs, ys))
+    return xs, ys

@@ -121,3 +121,28 @@ def test_tracker_on_the_real_env(tmp_path):
     assert {"Reward_comp_env0 / torque_fl", "Reward_comp_env0 / env0_perc_guiding", "Info / rew_Final reward",
             "Info / gamma_1 action assist", "Info / terrain_level"} <= tags
     env.close()
+
+
+def test_tracking_error_vs_speed_csv(tmp_path):
+    """eval_artifacts.py: join on step, trailing moving average, header of the shipped CSV
+    (my_runs/eval_kamma_4d/.../tracking_error_vs_speed.csv)"""
+    w = tr.EventFileWriter(str(tmp_path))
+    for i, s in enumerate(range(100, 1100, 100)):
+        w.add_scalar("Info / rew_Desired velocity", 1.0 + 0.1 * i, s)
+        if s != 500:  # a step without a tracking-error point drops out of the join
+            w.add_scalar("Info / rew_Tracking error", float(i), s)
+    w.close()
+    xs, ys = tr.write_tracking_error_vs_speed(w.path, smooth=3)
+    assert len(xs) == 9 and xs[0] == pytest.approx(1.0) and xs[4] == pytest.approx(1.5)
+    raw = [0, 1, 2, 3, 5, 6, 7, 8, 9]
+    assert ys == pytest.approx([np.mean(raw[max(0, k - 2):k + 1]) for k in range(9)])
+    rows = list(csv.reader(open(tmp_path / "tracking_error_vs_speed.csv")))
+    assert rows[0] == ["speed_m_s", "tracking_error_m_s"] and len(rows) == 10
+    w2 = tr.EventFileWriter(str(tmp_path / "b"))
+    w2.add_scalar("Info / rew_Tracking error", 0.5, 1); w2.add_scalar("Info / rew_Tracking error", 0.7, 2)
+    w2.close()
+    xs, ys = tr.write_tracking_error_vs_speed(w2.path)  # no desired-velocity tag: the 1 -> 2 m/s ramp
+    assert xs == [1.0, 2.0] and ys == pytest.approx([0.5, 0.7])
+    w3 = tr.EventFileWriter(str(tmp_path / "c")); w3.close()
+    with pytest.raises(ValueError):
+        tr.write_tracking_error_vs_speed(w3.path)
