@@ -774,13 +774,12 @@ int ois_create(const ois_config* cfg, int device, void* workspace_device, size_t
     // selects the pair layout (both are bit-identical to the oracle and covered by the tests).
     const char* w = getenv("OIS_LANES_PER_ARENA");
     e->lpa = (w && w[0] == '2') ? 2 : 1;
-    // Packed fp32 over wheel pairs pays exactly while every SIMD holds at most one wave
-    // (measured: 44 vs 55 us/step at 65 536 arenas, 80 vs 67 us at 81 920): a lone wave issues
-    // a v_pk_fma_f32 as fast as a v_fma_f32, two co-resident waves do not.
-    int cus = 0;
-    if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device) != hipSuccess || cus <= 0) cus = 256;
+    // Packed fp32 over wheel pairs is the default at every size: both step kernels need ~256
+    // VGPRs, so a SIMD holds one wave of either and a lone wave issues a v_pk_fma_f32 as fast as
+    // a v_fma_f32 (measured per policy step, fused: 30.5 vs 46.7 us at 65 536 arenas, 60.8 vs
+    // 92.7 us at 131 072, 242 vs 368 us at 524 288). OIS_PACKED=0 selects the scalar kernel.
     const char* pk = getenv("OIS_PACKED");
-    e->packed = pk ? (pk[0] == '1') : ((e->N + 63) / 64 <= 4 * cus);  // waves <= SIMDs
+    e->packed = pk ? (pk[0] == '1') : true;
   }
   e->seed = cfg->seed;
   e->reset_done = false;
