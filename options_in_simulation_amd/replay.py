@@ -3,18 +3,26 @@
 Mirrors the train scripts' ``FIFOMemory`` (train/train_kaddpg_4d_nofifo_random_RLIL.py:
 105-206): tensors ``[memory_size, num_envs, dim]``, the row at ``memory_index`` is overwritten
 and the index wraps, ``sample`` draws uniformly (without replacement by default) over the
-filled part. The difference: nobody calls ``add_samples`` — ``ois_step`` / ``ois_rollout``
-write the transition row themselves (states = previous observation, actions = executed
+filled part. The difference: nobody calls ``add_samples`` for the transition itself —
+``ois_step`` / ``ois_rollout`` write the row (states = previous observation, actions = executed
 torques / action_scale as the trainer substitutes at src/my_trainers/base_KA_DDPG.py:212,
 rewards, next_states, terminated), so a training loop needs no per-step host work for it.
+
+The on-policy agents keep more per step (``log_prob``, ``values``, later ``returns`` and
+``advantages``: src/my_agents/ppo.py:189-196): ``create_tensor`` adds such tensors beside the
+kernel-written ones and ``add_samples(**tensors)`` puts the agent's values into the row the
+kernel has just written, so the rollout memory of a PPO update lives on the device end to end
+(``gae.compute_gae`` consumes ``get_tensor_by_name("rewards")`` etc. as they are).
 """
 from __future__ import annotations
 
-from typing import Dict, List, Sequence
+from typing import Dict, List, Optional, Sequence
 
 import torch
 
 from .vecenv import NativeEnv, VecEnv
+
+KERNEL_TENSORS = ("states", "actions", "rewards", "next_states", "terminated")
 
 
 class DeviceFIFOMemory:
@@ -28,7 +36,7 @@ class DeviceFIFOMemory:
         self.tensors: Dict[str, torch.Tensor] = native.attach_replay(self.memory_size)
         self.sampling_indexes = None
 
-    # skrl Memory surface used by the agents -------------------------------------------------
+    # ---- skrl Memory surface used by the agents ---------------------------------------------
     @property
     def memory_index(self) -> int:
         return self.native.replay_cursor()[0]
@@ -41,9 +49,40 @@ class DeviceFIFOMemory:
         idx, filled = self.native.replay_cursor()
         return self.memory_size * self.num_envs if filled else idx * self.num_envs
 
+    def get_tensor_names(self):
+        return sorted(self.tensors)
+
+    def create_tensor(self, name: str, size: int = 1, dtype: Optional[torch.dtype] = None, keep_dimensions: bool = False) -> bool:
+        """skrl ``Memory.create_tensor``: a ``[memory_size, num_envs, size]`` tensor beside the
+        kernel-written ones (``log_prob``, ``values``, ``returns``, ``advantages`` …). The five
+        transition tensors exist already; asking for one of them only checks its width."""
+        if name in self.tensors:
+            if name in KERNEL_TENSORS and self.tensors[name].shape[-1] != int(size):
+                raise ValueError(f"{name} is written by the step kernel with width {self.tensors[name].shape[-1]}, not {size}")
+            return False
+        self.tensors[name] = torch.zeros((self.memory_size, self.num_envs, int(size)), dtype=dtype or torch.float32,
+                                         device=self.device)
+        return True
+
+    def add_samples(self, **tensors: torch.Tensor) -> None:
+        """Complete the row the step kernel has just written (call after ``env.step``) with the
+        agent's own per-step tensors. Transition tensors passed along (states, actions, …), as
+        ``record_transition`` does (ppo.py:270-272), are ignored: the kernel wrote them."""
+        idx, _ = self.native.replay_cursor()
+        row = (idx - 1) % self.memory_size
+        for name, value in tensors.items():
+            if name in KERNEL_TENSORS or name == "truncated":
+                continue
+            if name not in self.tensors:
+                raise KeyError(f"unknown memory tensor {name!r}: create_tensor() it first")
+            self.tensors[name][row].copy_(value.reshape(self.num_envs, -1))
+
     def get_tensor_by_name(self, name: str, keepdim: bool = True) -> torch.Tensor:
         t = self.tensors[name]
         return t if keepdim else t.reshape(-1, t.shape[-1])
+
+    def set_tensor_by_name(self, name: str, tensor: torch.Tensor) -> None:
+        self.tensors[name].copy_(tensor.reshape(self.tensors[name].shape))
 
     def sample_by_index(self, names: Sequence[str], indexes: torch.Tensor, mini_batches: int = 1) -> List[List[torch.Tensor]]:
         flat = {n: self.tensors[n].reshape(-1, self.tensors[n].shape[-1]) for n in names}
@@ -61,6 +100,13 @@ class DeviceFIFOMemory:
         else:
             indexes = torch.randperm(size, dtype=torch.long, device=self.device)[:batch_size]
         self.sampling_indexes = indexes
+        return self.sample_by_index(names, indexes, mini_batches)
+
+    def sample_all(self, names: Sequence[str], mini_batches: int = 1) -> List[List[torch.Tensor]]:
+        """every stored sample once, in random order, split into mini-batches (what
+        ``PPO._update`` iterates over, ppo.py:380)"""
+        size = self.memory_size * self.num_envs
+        indexes = torch.randperm(size, dtype=torch.long, device=self.device)
         return self.sample_by_index(names, indexes, mini_batches)
 
     def close(self):

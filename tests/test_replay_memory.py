@@ -162,3 +162,53 @@ def test_device_fifo_memory_surface():
     mem.close()
     env.step(torch.zeros((64, 4), device="cuda"))
     torch.cuda.synchronize()
+
+
+@pytest.mark.gpu
+def test_on_policy_rollout_memory_and_gae_stay_on_the_device():
+    """a PPO rollout as src/my_agents/ppo.py keeps it (:189-196, :270-272, :362-378): the kernel
+    writes the transition, the agent adds log_prob / values, GAE runs on the memory tensors"""
+    from options_in_simulation_amd import VecEnv, compute_gae
+    from options_in_simulation_amd.replay import DeviceFIFOMemory
+    N, T = 128, 16
+    env = VecEnv(num_envs=N, device="cuda:0", variant="KAMMA_eval", seed=5)
+    states, _ = env.reset()
+    mem = DeviceFIFOMemory(env, memory_size=T)
+    assert mem.create_tensor("log_prob", 1) and mem.create_tensor("values", 1)
+    assert mem.create_tensor("returns", 1) and mem.create_tensor("advantages", 1)
+    assert not mem.create_tensor("states", 6)
+    with pytest.raises(ValueError):
+        mem.create_tensor("actions", 2)
+    g = torch.Generator(device="cuda").manual_seed(0)
+    vals = []
+    for t in range(T):
+        actions = torch.rand((N, 4), device="cuda", generator=g)
+        values = torch.randn((N, 1), device="cuda", generator=g)
+        next_states, rew, term, trunc, _ = env.step(actions)
+        mem.add_samples(states=states, actions=actions, rewards=rew, next_states=next_states, terminated=term,
+                        truncated=trunc, log_prob=-values, values=values)
+        vals.append(values)
+        assert torch.equal(mem.get_tensor_by_name("values")[t], values)
+        assert torch.equal(mem.get_tensor_by_name("rewards")[t], rew)          # written by the kernel
+        assert torch.equal(mem.get_tensor_by_name("next_states")[t], next_states)
+        states = next_states
+    with pytest.raises(KeyError):
+        mem.add_samples(entropy=vals[0])
+    last_values = torch.randn((N, 1), device="cuda", generator=g)
+    r, d, v = (mem.get_tensor_by_name(n) for n in ("rewards", "terminated", "values"))
+    returns, adv = compute_gae(r, d, v, last_values, 0.99, 0.95)
+    mem.set_tensor_by_name("returns", returns); mem.set_tensor_by_name("advantages", adv)
+    # the torch loop of ppo.py:345-358 on the same tensors
+    advantage, advantages, nd = 0, torch.zeros_like(r), d.logical_not()
+    for i in reversed(range(T)):
+        nv = v[i + 1] if i < T - 1 else last_values
+        advantage = r[i] - v[i] + 0.99 * nd[i] * (nv + 0.95 * advantage)
+        advantages[i] = advantage
+    assert torch.equal(returns, advantages + v)
+    ref = (advantages - advantages.mean()) / (advantages.std() + 1e-8)
+    torch.testing.assert_close(mem.get_tensor_by_name("advantages"), ref, rtol=1e-4, atol=1e-5)
+    batches = mem.sample_all(["states", "actions", "log_prob", "values", "returns", "advantages"], mini_batches=4)
+    assert len(batches) == 4 and sum(b[0].shape[0] for b in batches) == T * N and batches[0][1].shape[1] == 4
+    assert sorted(mem.get_tensor_names()) == sorted(["states", "actions", "rewards", "next_states", "terminated",
+                                                     "log_prob", "values", "returns", "advantages"])
+    mem.close(); env.close()
