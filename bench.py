@@ -103,6 +103,10 @@ def main():
     ap.add_argument("--no-actor", action="store_true", help="env-only loop (fixed random actions)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--variant", default="KAMMA_medium")
+    ap.add_argument("--domain-rand", action="store_true",
+                    help="BASELINE.json configs[3]: per-arena friction U(0.5, 1.0) and plane slope from the generator's set")
+    ap.add_argument("--terrain", action="store_true",
+                    help="configs[3] on the reference's full terrain family: 6 x 2 random tiles, wheel contact on the height field")
     args = ap.parse_args()
 
     import torch
@@ -134,6 +138,16 @@ def main():
     N = args.arenas
     cfg = build_config(variant=args.variant, num_envs=N, seed=42, arena_offset=rank * N)
     env = NativeEnv(cfg, device)
+    terrain_note = "flat terrain"
+    if args.domain_rand:
+        env.randomize_params(0.5, 1.0, [-0.3, -0.2, 0.0, 0.2, 0.3])  # origin_terrain_generator.py:92
+        terrain_note = "per-arena friction U(0.5,1.0) + plane slope {-0.3,-0.2,0,0.2,0.3}"
+    if args.terrain:
+        import numpy as np
+        from options_in_simulation_amd import terrain as tg
+        T = tg.Terrain({"numLevels": 6, "numTerrains": 2, "mapLength": 10.0, "mapWidth": 10.0}, N, seed=42)
+        env.attach_terrain(T, T.sample_levels_types(N, rng=np.random.RandomState(rank)))
+        terrain_note = "height-field terrain, 6 x 2 random tiles of 10 m (stairs +-0.15 m, obstacles, pyramid slopes)"
     env.reset(42)
     actor = None if args.no_actor else build_actor(torch, device)
     obs = env.buffer(_abi.BUF_OBS)
@@ -188,15 +202,15 @@ def main():
             "value": value, "unit": "env-steps/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": f"{N} arenas/GPU, flat terrain, {args.variant} task, "
+            "config": {"workload": f"{N} arenas/GPU, {terrain_note}, {args.variant} task, "
                                    + ("fixed random actions (env only)" if actor is None else
                                       "scripted actor MLP 6-512-512-128-4 (fp32 PyTorch-ROCm) inference in-loop")
-                                   + " [BASELINE.json configs[2]]",
+                                   + (" [BASELINE.json configs[3]]" if (args.domain_rand or args.terrain) else " [BASELINE.json configs[2]]"),
                        "arenas_per_gpu": N, "substeps_per_step": cfg.decimation + cfg.extra_substeps,
                        "solver_iterations": cfg.solver_iterations, "sharding": f"arenas x{world}, no data-path collective",
                        "stats_allgather_every": args.log_interval},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": pmc_traffic(N),
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": None if args.terrain else pmc_traffic(N),
                          "kernel": "step_kernel", "kernel_ms": kernel_ms,
                          "algorithmic_bytes_per_launch": ALGO_BYTES_PER_ENV_STEP * N,
                          "traffic_source": "profiles/r1_pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, "
