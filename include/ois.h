@@ -23,6 +23,16 @@
  *   ois_env0_diag               <- task.observed_components (KAMMA.py:840-867)
  *   ois_stats_fetch             <- finished-episode return tracking of the agent base
  *                                  class (src/my_agents/base.py:305-341)
+ *   ois_replay_*                <- FIFOMemory.add_samples as fed by record_transition
+ *                                  (train_kaddpg_4d_nofifo_random_RLIL.py:105-206,
+ *                                  base_KA_DDPG.py:205-224): the step kernel writes the row
+ *   ois_gae                     <- compute_gae (src/my_agents/ppo.py:321-360) and
+ *                                  compute_advantages_and_returns (ppoc.py:305-336)
+ *   ois_terrain_attach          <- get_terrain / _create_trimesh / update_SI_level
+ *                                  (KAMMA.py:296-349, 502-529; commented out there)
+ *   ois_height_scan             <- get_heights (KAMMA.py:872-893)
+ *   ois_randomize_params, ois_save_state / ois_load_state: no reference counterpart
+ *                                  (BASELINE.json configs[3]; SURVEY.md §5 checkpoint)
  *
  * Conventions
  *   - plain C, no torch types; every pointer named *device* is a HIP device pointer.

@@ -6,7 +6,10 @@
 // One launch = one (or k) policy step(s) for all arenas: controller -> action mixing ->
 // torque clip -> 20 contact-solver substeps -> termination -> reward -> auto-reset ->
 // observation -> forward-speed projection, state in registers throughout.
-// LPA lanes per arena (ois_device.h): 1 = a lane owns an arena, 2 = a lane pair shares one.
+// step_kernel<LPA, PK, TER, NIT>: LPA lanes per arena (1 = a lane owns an arena, 2 = a lane pair
+// shares one), PK packed fp32 over wheel pairs (ois_physics_pk.h), TER wheel contact on a height
+// field, NIT solver iterations unrolled at compile time (0 = run-time count). Also here:
+// reset / params / episode-info / stats / height-scan kernels; ois_gae.hip holds the GAE scan.
 #include <hip/hip_runtime.h>
 
 #include <cmath>
@@ -768,10 +771,11 @@ int ois_create(const ois_config* cfg, int device, void* workspace_device, size_t
   e->grid = (e->N + kBlock - 1) / kBlock;
   {
     // Lanes per arena. Measured on MI355X at 65 536 arenas: a lane pair per arena
-    // (2 waves per SIMD, 825 instr/lane-substep) runs a fused 20-step rollout in 51-53 us/step
-    // against 53-55 us for one lane per arena (1 wave per SIMD, 1494 instr), but a single-step
-    // launch in 80 us against 60 us. One lane per arena is the default; OIS_LANES_PER_ARENA=2
-    // selects the pair layout (both are bit-identical to the oracle and covered by the tests).
+    // (2 waves per SIMD, 31 DPP adds per substep) runs a fused rollout in 45 us per policy step and
+    // a single-step launch in 68 us, against 30.5 us / 42 us for one lane per arena with packed
+    // wheel pairs. One lane per arena is the default; OIS_LANES_PER_ARENA=2 selects the pair
+    // layout (an experiment kept because it is bit-identical to the oracle and covered by the
+    // tests; no terrain, no unrolled-iteration variant).
     const char* w = getenv("OIS_LANES_PER_ARENA");
     e->lpa = (w && w[0] == '2') ? 2 : 1;
     // Packed fp32 over wheel pairs is the default at every size: both step kernels need ~256
