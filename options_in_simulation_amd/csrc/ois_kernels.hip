@@ -147,7 +147,13 @@ __global__ OIS_STEP_BOUNDS void step_kernel(DevConsts K, DevBuffers B, const flo
     }
     float aw[W];
 #pragma unroll
-    for (int k = 0; k < W; ++k) aw[k] = (LPA == 1) ? a4[k] : (h ? a4[(2 + k) & 3] : a4[k]);  // & 3: constant index for LPA = 1 too (no LDS array)
+    for (int k = 0; k < W; ++k) {
+      // value selects, never an index computed from h: a run-time index would make the compiler
+      // move a4 to LDS, and that code reads the workgroup size through the dispatch pointer —
+      // host memory, ~13 us per launch (tools/lds_launch_probe.hip)
+      const float lo = a4[k & 3], hi = a4[(2 + k) & 3];
+      aw[k] = (LPA == 1) ? lo : (h ? hi : lo);
+    }
     // ---- pre_physics_step (KAMMA.py:596-656) ----
     const float current_v = S.vfwd;      // :607
     const float current_omega = S.w[2];  // :608

@@ -124,3 +124,30 @@ def test_composite_body_from_urdf_numbers():
     assert m == 25.0  # = vehicle_mass KAMMA.py:174
     assert com == pytest.approx(4 * 0.056 / 25)
     assert ixx == pytest.approx(0.70054, abs=1e-4) and iyy == pytest.approx(0.94864, abs=1e-4) and izz == pytest.approx(1.4681, abs=1e-4)
+
+
+def test_no_kernel_reads_the_dispatch_packet(tmp_path):
+    """The AQL dispatch packet lives in host memory: a kernel that reads it (e.g. because the
+    compiler promoted a run-time-indexed private array to LDS and linearises the thread id from
+    the packet's workgroup size) pays ~13 us per launch on MI355X (tools/lds_launch_probe.hip,
+    DESIGN.md section 4). No kernel of the library may enable the dispatch-pointer SGPRs or fall
+    back to scratch."""
+    import shutil
+    import subprocess
+    hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    if not os.path.exists(hipcc):
+        pytest.skip("hipcc not available")
+    csrc = os.path.join(ROOT, "options_in_simulation_amd", "csrc")
+    flags = ["-O3", "-std=c++17", "--offload-arch=gfx950", "-ffp-contract=off", "-fno-fast-math", "-fno-slp-vectorize",
+             "-Wno-unused-function", "-Wno-pass-failed", "-S", "--cuda-device-only"]
+    for src in ("ois_kernels.hip", "ois_gae.hip"):
+        out = tmp_path / (src + ".s")
+        subprocess.run([hipcc, *flags, "-o", str(out), os.path.join(csrc, src)], check=True, capture_output=True)
+        text = out.read_text()
+        kernels = re.findall(r"\.amdhsa_kernel (\S+)(.*?)\.end_amdhsa_kernel", text, flags=re.S)
+        assert kernels
+        for name, body in kernels:
+            assert ".amdhsa_user_sgpr_dispatch_ptr 0" in body, f"{name} reads the dispatch packet"
+            assert ".amdhsa_private_segment_fixed_size 0" in body, f"{name} uses scratch"
+            if "step_kernel" in name:
+                assert ".amdhsa_group_segment_fixed_size 0" in body, f"{name}: a private array was promoted to LDS"
