@@ -7,7 +7,6 @@ the rollout with ~8 torch launches per step.
 """
 from __future__ import annotations
 
-import ctypes as C
 from typing import Tuple
 
 import torch

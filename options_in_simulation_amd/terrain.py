@@ -17,8 +17,7 @@ seeds: its fields are not reproducible, so nothing here can be pinned to one).
 """
 from __future__ import annotations
 
-from dataclasses import dataclass
-from typing import Dict, Optional, Sequence, Tuple
+from typing import Dict, Optional
 
 import numpy as np
 

@@ -3,7 +3,6 @@ Algorithmic bytes per rollout entry: 4 (reward) + 4 (value) + 1 (terminated) rea
 = 17 B; + 8 B (read + write of the advantage) for the normalisation pass."""
 import json
 import sys
-import time
 
 import torch
 

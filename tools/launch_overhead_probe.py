@@ -1,5 +1,5 @@
 """time(k) of fused rollouts for several k and N: separates the per-launch cost from the per-step cost"""
-import os, sys, time, json
+import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from options_in_simulation_amd import _abi, build_config
