@@ -483,29 +483,67 @@ __global__ void randomize_params_kernel(DevConsts K, DevBuffers B, int N, float 
   B.params[i] = make_float4(rand_float(mu_lo, mu_hi, u[0]), nx, ny, nz);
 }
 
-// extras["episode"] (KAMMA.py:480-488): deterministic in-order sum of the per-wave records
-// of the most recent reset event. One block of 64 threads; thread t owns record slot t.
-__global__ __launch_bounds__(64) void episode_info_kernel(DevConsts K, DevBuffers B, int nwaves, int N) {
-  __shared__ float acc[32];
-  __shared__ long long lsum[64];
-  const int t = threadIdx.x;
-  // :488 torch.mean(terrain_levels.float()) over ALL arenas (integer sum: exact and order-free)
-  long long ls = 0;
-  if (B.ter.on) for (int i = t; i < N; i += 64) ls += B.terrain_idx[i].x;
-  lsum[t] = ls;
-  int smax = -1;
-  for (int w = 0; w < nwaves; ++w) smax = max(smax, B.stamps[w]);
+// extras["episode"] (KAMMA.py:480-488): deterministic two-level sum of the per-group records of
+// the most recent reset event (docs/SPEC.md §2.10). Level 1: one block per chunk of kChunkGroups
+// consecutive groups sums, in group order, the records carrying the chunk's newest stamp;
+// level 2: one block sums, in chunk order, the partials of the chunks whose newest stamp is the
+// global newest. (A single block walking all groups took 0.66 ms at 65 536 arenas and 7.6 ms at
+// 524 288 — more than the policy step it reports on; the reference reads infos every step.)
+constexpr int kChunkGroups = 64;  // 1024 arenas per chunk
+
+__global__ __launch_bounds__(64) void episode_partial_kernel(DevBuffers B, int ngroups, int N, float* __restrict__ part,
+                                                            int* __restrict__ cmax, long long* __restrict__ lvl) {
+  const int c = blockIdx.x, t = threadIdx.x;
+  const int g0 = c * kChunkGroups, g1 = min(g0 + kChunkGroups, ngroups);
+  int m = -1;
+  for (int g = g0; g < g1; ++g) m = max(m, B.stamps[g]);
   if (t < 32) {
-    float a = 0.0f;
-    bool first = true;
-    for (int w = 0; w < nwaves; ++w) {
-      if (B.stamps[w] != smax) continue;
-      const float x = B.partials[(size_t)w * 32 + t];
-      if (t == 24 || t == 25) { if (first) a = x; }  // gamma1 / gamma2 (identical in every arena)
-      else a += x;
-      first = false;
+    const bool is_gamma = t == 24 || t == 25;  // gamma1 / gamma2: identical in every record of one event
+    float a = is_gamma ? -__builtin_inff() : 0.0f;
+#pragma unroll 8
+    for (int g = g0; g < g1; ++g) {  // unconditional loads, predicated accumulate: the loads pipeline
+      const bool match = B.stamps[g] == m;
+      const float x = B.partials[(size_t)g * 32 + t];
+      const float y = is_gamma ? fmaxf(a, x) : a + x;
+      a = match ? y : a;
+    }
+    part[(size_t)c * 32 + t] = a;
+  }
+  if (t == 0) cmax[c] = m;
+  // :488 torch.mean(terrain_levels.float()) over ALL arenas: integer sums, exact and order-free
+  long long ls = 0;
+  if (B.ter.on) {
+    const int a1 = min(g1 * kGroup, N);
+    for (int i = g0 * kGroup + t; i < a1; i += 64) ls += B.terrain_idx[i].x;
+  }
+  for (int w = 32; w >= 1; w >>= 1) ls += __shfl_xor(ls, w, 64);
+  if (t == 0) lvl[c] = ls;
+}
+
+__global__ __launch_bounds__(64) void episode_final_kernel(DevConsts K, DevBuffers B, int nchunks, int N,
+                                                          const float* __restrict__ part, const int* __restrict__ cmax,
+                                                          const long long* __restrict__ lvl) {
+  __shared__ float acc[32];
+  __shared__ long long tot_s;
+  const int t = threadIdx.x;
+  int smax = -1;
+  for (int c = 0; c < nchunks; ++c) smax = max(smax, cmax[c]);
+  if (t < 32) {
+    const bool is_gamma = t == 24 || t == 25;
+    float a = is_gamma ? -__builtin_inff() : 0.0f;
+#pragma unroll 8
+    for (int c = 0; c < nchunks; ++c) {
+      const bool match = cmax[c] == smax;
+      const float x = part[(size_t)c * 32 + t];
+      const float y = is_gamma ? fmaxf(a, x) : a + x;
+      a = match ? y : a;
     }
     acc[t] = a;
+  }
+  if (t == 32) {
+    long long tot = 0;
+    for (int c = 0; c < nchunks; ++c) tot += lvl[c];
+    tot_s = tot;
   }
   __syncthreads();
   if (t == 0) {
@@ -524,23 +562,32 @@ __global__ __launch_bounds__(64) void episode_info_kernel(DevConsts K, DevBuffer
     }
     I[OIS_EI_GAMMA1] = acc[24];       // :486
     I[OIS_EI_GAMMA2] = acc[25];       // :487
-    long long tot = 0;
-    for (int k = 0; k < 64; ++k) tot += lsum[k];
-    I[OIS_EI_TERRAIN_LEVEL] = (float)tot / (float)N;  // :488 (zeros without a terrain, :223)
+    I[OIS_EI_TERRAIN_LEVEL] = (float)tot_s / (float)N;  // :488 (zeros without a terrain, :223)
     I[OIS_EI_STEP] = (float)smax;
   }
 }
 
-// finished-episode statistics: in-order reduction of the per-wave accumulators
-__global__ __launch_bounds__(64) void stats_kernel(DevBuffers B, int nwaves, float* out8, int reset_after) {
-  const int t = threadIdx.x;
+// finished-episode statistics: the same two-level order over the per-group accumulators
+__global__ __launch_bounds__(64) void stats_partial_kernel(DevBuffers B, int ngroups, float* __restrict__ part8, int reset_after) {
+  const int c = blockIdx.x, t = threadIdx.x;
   if (t >= 8) return;
+  const int g0 = c * kChunkGroups, g1 = min(g0 + kChunkGroups, ngroups);
   float a = t < 4 ? 0.0f : -__builtin_inff();
-  for (int w = 0; w < nwaves; ++w) {
-    float* p = B.stat_acc + (size_t)w * 8 + t;
+  for (int g = g0; g < g1; ++g) {
+    float* p = B.stat_acc + (size_t)g * 8 + t;
     const float x = *p;
     a = t < 4 ? a + x : fmaxf(a, x);
     if (reset_after) *p = t < 4 ? 0.0f : -__builtin_inff();
+  }
+  part8[(size_t)c * 8 + t] = a;
+}
+__global__ __launch_bounds__(64) void stats_final_kernel(int nchunks, const float* __restrict__ part8, float* __restrict__ out8) {
+  const int t = threadIdx.x;
+  if (t >= 8) return;
+  float a = t < 4 ? 0.0f : -__builtin_inff();
+  for (int c = 0; c < nchunks; ++c) {
+    const float x = part8[(size_t)c * 8 + t];
+    a = t < 4 ? a + x : fmaxf(a, x);
   }
   out8[t] = a;
 }
@@ -565,8 +612,8 @@ size_t align256(size_t x) { return (x + 255) & ~(size_t)255; }
 struct Layout {
   size_t off[OIS_BUF_COUNT_];
   size_t bytes[OIS_BUF_COUNT_];
-  size_t partials, stamps, stat_acc, stat_out, total;
-  int nwaves;
+  size_t partials, stamps, stat_acc, stat_out, red_part, red_cmax, red_lvl, red_part8, total;
+  int nwaves, nchunks;
 };
 
 Layout make_layout(int N) {
@@ -593,6 +640,11 @@ Layout make_layout(int N) {
   L.stamps = o; o = align256(o + (size_t)L.nwaves * sizeof(int32_t));
   L.stat_acc = o; o = align256(o + (size_t)L.nwaves * 8 * sizeof(float));
   L.stat_out = o; o = align256(o + 32 * sizeof(float));  // 8 stats out / 16-entry slope table scratch
+  L.nchunks = (L.nwaves + kChunkGroups - 1) / kChunkGroups;  // level-1 partials of the logging reductions
+  L.red_part = o; o = align256(o + (size_t)L.nchunks * 32 * sizeof(float));
+  L.red_cmax = o; o = align256(o + (size_t)L.nchunks * sizeof(int));
+  L.red_lvl = o; o = align256(o + (size_t)L.nchunks * sizeof(long long));
+  L.red_part8 = o; o = align256(o + (size_t)L.nchunks * 8 * sizeof(float));
   L.total = o;
   return L;
 }
@@ -967,7 +1019,13 @@ int ois_episode_info(ois_env* e, void* stream) {
   if (!e) return fail(OIS_EINVAL, "null env");
   if (!e->reset_done) return fail(OIS_ESTATE, "ois_episode_info called before ois_reset");
   HIP_TRY(hipSetDevice(e->device));
-  hipLaunchKernelGGL(episode_info_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, e->K, e->B, e->L.nwaves, e->N);
+  float* part = (float*)(e->ws + e->L.red_part);
+  int* cmax = (int*)(e->ws + e->L.red_cmax);
+  long long* lvl = (long long*)(e->ws + e->L.red_lvl);
+  hipLaunchKernelGGL(episode_partial_kernel, dim3(e->L.nchunks), dim3(64), 0, (hipStream_t)stream, e->B, e->L.nwaves, e->N, part,
+                     cmax, lvl);
+  hipLaunchKernelGGL(episode_final_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, e->K, e->B, e->L.nchunks, e->N, part, cmax,
+                     lvl);
   HIP_TRY(hipGetLastError());
   return OIS_OK;
 }
@@ -977,7 +1035,9 @@ int ois_stats_fetch(ois_env* e, ois_stats* out, int reset_after, void* stream) {
   if (!e->reset_done) return fail(OIS_ESTATE, "ois_stats_fetch called before ois_reset");
   HIP_TRY(hipSetDevice(e->device));
   float* d = (float*)(e->ws + e->L.stat_out);
-  hipLaunchKernelGGL(stats_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, e->B, e->L.nwaves, d, reset_after);
+  float* part8 = (float*)(e->ws + e->L.red_part8);
+  hipLaunchKernelGGL(stats_partial_kernel, dim3(e->L.nchunks), dim3(64), 0, (hipStream_t)stream, e->B, e->L.nwaves, part8, reset_after);
+  hipLaunchKernelGGL(stats_final_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, e->L.nchunks, part8, d);
   HIP_TRY(hipGetLastError());
   float h[8];
   HIP_TRY(hipMemcpyAsync(h, d, sizeof h, hipMemcpyDeviceToHost, (hipStream_t)stream));

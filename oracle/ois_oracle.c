@@ -649,6 +649,7 @@ void orc_substep(const ois_config* cfg, float mu, const float n_world[3], const 
 /* ------------------------------------------------------------------ environment ------ */
 #define GROUP 16          /* arenas per reduction group (= one wave64 of the HIP kernel) */
 #define PART_STRIDE 32    /* floats per group partial record */
+#define CHUNK_GROUPS 64   /* groups per level-1 chunk of the logging reductions (= 1024 arenas) */
 /* partial-record slots: 0..15 as OIS_EI_COUNT..OBSERVED_OVER_FINAL (sums over reset arenas),
  * 16 gamma1, 17 gamma2, 20..22 eval sums, 24 return^2 sum, 25 return min, 26 return max, 27 length sum */
 enum { P_G1 = 16, P_G2 = 17, P_SM = 20, P_TE = 21, P_DV = 22, P_RET2 = 24, P_RMIN = 25, P_RMAX = 26, P_LEN = 27 };
@@ -1306,17 +1307,30 @@ int orc_height_scan(orc_env* e, float* out) {
 /* extras["episode"] (KAMMA.py:480-488) from the most recent reset event */
 int orc_episode_info(orc_env* e) {
   if (!e) return fail(OIS_EINVAL, "null env");
+  /* two-level order (docs/SPEC.md §2.10): chunks of CHUNK_GROUPS consecutive groups are summed in
+   * group order over the records carrying the chunk's newest stamp; the chunk partials whose
+   * newest stamp is the global newest are summed in chunk order */
   int32_t smax = -1;
   for (int g = 0; g < e->G; ++g) smax = e->stamps[g] > smax ? e->stamps[g] : smax;
   float acc[PART_STRIDE];
   memset(acc, 0, sizeof acc);
   int first = 1;
-  for (int g = 0; g < e->G; ++g) {
-    if (e->stamps[g] != smax) continue;
-    const float* P = &e->partials[(size_t)g * PART_STRIDE];
-    for (int k = 0; k < 16; ++k) acc[k] += P[k];
-    acc[P_SM] += P[P_SM]; acc[P_TE] += P[P_TE]; acc[P_DV] += P[P_DV];
-    if (first) { acc[P_G1] = P[P_G1]; acc[P_G2] = P[P_G2]; first = 0; }
+  for (int g0 = 0; g0 < e->G; g0 += CHUNK_GROUPS) {
+    int g1 = g0 + CHUNK_GROUPS < e->G ? g0 + CHUNK_GROUPS : e->G;
+    int32_t cm = -1;
+    for (int g = g0; g < g1; ++g) cm = e->stamps[g] > cm ? e->stamps[g] : cm;
+    if (cm != smax) continue;
+    float part[PART_STRIDE];
+    memset(part, 0, sizeof part);
+    for (int g = g0; g < g1; ++g) {
+      if (e->stamps[g] != cm) continue;
+      const float* P = &e->partials[(size_t)g * PART_STRIDE];
+      for (int k = 0; k < 16; ++k) part[k] += P[k];
+      part[P_SM] += P[P_SM]; part[P_TE] += P[P_TE]; part[P_DV] += P[P_DV];
+      if (first) { acc[P_G1] = P[P_G1]; acc[P_G2] = P[P_G2]; first = 0; }
+    }
+    for (int k = 0; k < 16; ++k) acc[k] += part[k];
+    acc[P_SM] += part[P_SM]; acc[P_TE] += part[P_TE]; acc[P_DV] += part[P_DV];
   }
   float* I = e->episode_info;
   memset(I, 0, sizeof e->episode_info);
@@ -1340,10 +1354,15 @@ int orc_episode_info(orc_env* e) {
 int orc_stats_fetch(orc_env* e, ois_stats* out, int reset_after) {
   if (!e || !out) return fail(OIS_EINVAL, "null argument");
   float cnt = 0, ret = 0, ret2 = 0, len = 0, mn = INFINITY, mx = -INFINITY;
-  for (int g = 0; g < e->G; ++g) {
-    const float* A = &e->stat_acc[(size_t)g * ST_STRIDE];
-    cnt += A[ST_COUNT]; ret += A[ST_RET]; ret2 += A[ST_RET2]; len += A[ST_LEN];
-    mn = fminf(mn, A[ST_RMIN]); mx = fmaxf(mx, A[ST_RMAX]);
+  for (int g0 = 0; g0 < e->G; g0 += CHUNK_GROUPS) { /* same two-level order as the extras */
+    int g1 = g0 + CHUNK_GROUPS < e->G ? g0 + CHUNK_GROUPS : e->G;
+    float c_cnt = 0, c_ret = 0, c_ret2 = 0, c_len = 0;
+    for (int g = g0; g < g1; ++g) {
+      const float* A = &e->stat_acc[(size_t)g * ST_STRIDE];
+      c_cnt += A[ST_COUNT]; c_ret += A[ST_RET]; c_ret2 += A[ST_RET2]; c_len += A[ST_LEN];
+      mn = fminf(mn, A[ST_RMIN]); mx = fmaxf(mx, A[ST_RMAX]);
+    }
+    cnt += c_cnt; ret += c_ret; ret2 += c_ret2; len += c_len;
   }
   out->episodes = cnt; out->return_sum = ret; out->return_sqsum = ret2; out->return_min = mn;
   out->return_max = mx; out->length_sum = len; out->steps = e->steps_done; out->reserved = 0.0;
