@@ -243,17 +243,21 @@ class NativeEnv:
 
 class _LazyEpisodeInfo(dict):
     """``extras["episode"]`` (KAMMA.py:480-488): a dict of 0-dim tensors, produced on first
-    access so that a step costs no extra launch when nobody looks."""
+    access so that a step costs no extra launch when nobody looks. The trainers read every value
+    with ``.item()`` (base_KA_DDPG.py:259-262: 22 device-to-host syncs per step on device
+    tensors); with ``on_host`` (default) the 32-float vector comes over in ONE copy and the
+    values are 0-dim CPU tensors, whose ``.item()`` is free."""
 
-    def __init__(self, native: NativeEnv, eval_keys: bool):
+    def __init__(self, native: NativeEnv, eval_keys: bool, on_host: bool = True):
         super().__init__()
-        self._native, self._eval, self._done = native, eval_keys, False
+        self._native, self._eval, self._done, self._on_host = native, eval_keys, False, on_host
 
     def _materialize(self):
         if self._done:
             return
         self._done = True
-        vec = self._native.episode_info().clone()
+        vec = self._native.episode_info()
+        vec = vec.cpu() if self._on_host else vec.clone()
         for slot, key in _abi.EPISODE_INFO_KEYS.items():
             dict.__setitem__(self, key, vec[slot])
         for key in _abi.EPISODE_INFO_ZERO_KEYS:
@@ -318,6 +322,7 @@ class TorqueDistributionTask:
         self.clip_obs = float(c.clip_obs)
         self.extras: Dict[str, Any] = {}
         self._diag_step = -1
+        self.infos_on_host = True  # extras["episode"] values as CPU 0-dim tensors (one D2H copy), see _LazyEpisodeInfo
         self._diag_cache: Dict[str, float] = {}
         n = self.native
         # tensors of the task (views of the library's buffers; rl_task.py:145-154, KAMMA.py:378-410)
@@ -447,12 +452,12 @@ class TorqueDistributionTask:
     def post_reset(self, seed: Optional[int] = None):
         """KAMMA.py:366-414"""
         self.native.reset(seed)
-        self.extras = {"episode": _LazyEpisodeInfo(self.native, bool(self.cfg_native.eval_sums))}
+        self.extras = {"episode": _LazyEpisodeInfo(self.native, bool(self.cfg_native.eval_sums), self.infos_on_host)}
 
     def step(self, actions: torch.Tensor):
         """pre_physics_step + substeps + post_physics_step (KAMMA.py:596-727) in one launch"""
         self.native.step(actions)
-        self.extras = {"episode": _LazyEpisodeInfo(self.native, bool(self.cfg_native.eval_sums))}
+        self.extras = {"episode": _LazyEpisodeInfo(self.native, bool(self.cfg_native.eval_sums), self.infos_on_host)}
         return self.obs_buf, self.rew_buf, self.reset_buf, self.extras
 
     def close(self):
