@@ -288,6 +288,14 @@ int ois_replay_attach(ois_env* env, int memory_size, void* memory_device, size_t
 int ois_replay_buffer(ois_env* env, int id, void** ptr_device, size_t* bytes);
 /* memory_index = next row to be written, filled = 1 once the index has wrapped */
 int ois_replay_cursor(const ois_env* env, int* memory_index, int* filled);
+/* Gather a mini-batch in ONE launch (FIFOMemory.sample / sample_by_index,
+ * train_kaddpg_4d_nofifo_random_RLIL.py:112-145: five indexed copies there). indexes_device:
+ * int64 [count] positions in the flattened [memory_size * num_envs] sample space (values outside
+ * it are clamped into it). Outputs are contiguous device arrays [count, 6|4|1|6|1]; any of them
+ * may be NULL to skip that tensor. */
+int ois_replay_sample(ois_env* env, const int64_t* indexes_device, int count, float* states_out,
+                      float* actions_out, float* rewards_out, float* next_states_out,
+                      uint8_t* terminated_out, void* stream);
 
 /* ---- generalized advantage estimation over a rollout ----
  * The backward recurrence the on-policy agents run in a Python loop over the rollout memory,

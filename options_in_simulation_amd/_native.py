@@ -19,7 +19,7 @@ SYMBOLS = (
     "ois_destroy", "ois_reset", "ois_step", "ois_rollout", "ois_buffer", "ois_randomize_params",
     "ois_episode_info", "ois_stats_fetch", "ois_env0_diag", "ois_state_bytes", "ois_save_state",
     "ois_load_state", "ois_replay_bytes", "ois_replay_attach", "ois_replay_buffer", "ois_replay_cursor",
-    "ois_gae_scratch_bytes", "ois_gae", "ois_terrain_attach", "ois_height_scan",
+    "ois_gae_scratch_bytes", "ois_gae", "ois_terrain_attach", "ois_height_scan", "ois_replay_sample",
 )
 
 _lib = None
@@ -79,6 +79,7 @@ def load() -> C.CDLL:
     L.ois_gae_scratch_bytes.restype = C.c_size_t
     L.ois_gae.argtypes = [C.c_int, C.c_int, C.c_int, vp, vp, vp, vp, C.c_double, C.c_double, C.c_int, vp, vp, vp,
                           C.c_size_t, vp]
+    L.ois_replay_sample.argtypes = [vp, vp, C.c_int, vp, vp, vp, vp, vp, vp]
     L.ois_terrain_attach.argtypes = [vp, C.POINTER(_abi.OisTerrain), vp, vp, C.POINTER(C.c_int32), vp]
     L.ois_height_scan.argtypes = [vp, vp, vp]
     if L.ois_abi_version() != _abi.ABI_VERSION:

@@ -592,6 +592,30 @@ __global__ __launch_bounds__(64) void stats_final_kernel(int nchunks, const floa
   out8[t] = a;
 }
 
+// ------------------------------------------------------------------ replay sampling ---
+// One thread per sampled transition: 69 B gathered from 5 rows, written to 5 contiguous batches.
+__global__ __launch_bounds__(256) void replay_sample_kernel(DevBuffers B, size_t rows, const int64_t* __restrict__ idx, int count,
+                                                            float* __restrict__ st, float* __restrict__ ac, float* __restrict__ rw,
+                                                            float* __restrict__ nx, uint8_t* __restrict__ dn) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= count) return;
+  int64_t r = idx[i];
+  r = r < 0 ? 0 : (r >= (int64_t)rows ? (int64_t)rows - 1 : r);
+  if (st) {
+    const float2* s = reinterpret_cast<const float2*>(B.rp_states + (size_t)r * 6);
+    float2* o = reinterpret_cast<float2*>(st + (size_t)i * 6);
+    o[0] = s[0]; o[1] = s[1]; o[2] = s[2];
+  }
+  if (nx) {
+    const float2* s = reinterpret_cast<const float2*>(B.rp_next + (size_t)r * 6);
+    float2* o = reinterpret_cast<float2*>(nx + (size_t)i * 6);
+    o[0] = s[0]; o[1] = s[1]; o[2] = s[2];
+  }
+  if (ac) reinterpret_cast<float4*>(ac)[i] = reinterpret_cast<const float4*>(B.rp_actions)[r];
+  if (rw) rw[i] = B.rp_rewards[r];
+  if (dn) dn[i] = B.rp_done[r];
+}
+
 // ------------------------------------------------------------------ host side ---------
 thread_local char g_err[512] = "";
 int fail(int code, const char* fmt, const char* detail = "") {
@@ -1109,6 +1133,19 @@ struct StateHeader {
   double steps_done;
   uint64_t payload;
 };
+
+int ois_replay_sample(ois_env* e, const int64_t* indexes_device, int count, float* states_out, float* actions_out,
+                      float* rewards_out, float* next_states_out, uint8_t* terminated_out, void* stream) {
+  if (!e || !indexes_device) return fail(OIS_EINVAL, "null argument");
+  if (e->B.rp_size <= 0) return fail(OIS_ESTATE, "no replay memory attached");
+  if (count < 1) return fail(OIS_EINVAL, "count must be >= 1");
+  HIP_TRY(hipSetDevice(e->device));
+  const size_t rows = (size_t)e->B.rp_size * (size_t)e->N;
+  hipLaunchKernelGGL(replay_sample_kernel, dim3((count + 255) / 256), dim3(256), 0, (hipStream_t)stream, e->B, rows, indexes_device,
+                     count, states_out, actions_out, rewards_out, next_states_out, terminated_out);
+  HIP_TRY(hipGetLastError());
+  return OIS_OK;
+}
 
 size_t ois_state_bytes(const ois_env* e) { return e ? sizeof(StateHeader) + e->L.total : 0; }
 

@@ -84,12 +84,20 @@ class DeviceFIFOMemory:
     def set_tensor_by_name(self, name: str, tensor: torch.Tensor) -> None:
         self.tensors[name].copy_(tensor.reshape(self.tensors[name].shape))
 
+    def _gather(self, names: Sequence[str], indexes: torch.Tensor) -> List[torch.Tensor]:
+        """the kernel-written tensors in one launch (ois_replay_sample), the agent's own by indexing"""
+        fused = [n for n in names if n in KERNEL_TENSORS]
+        got = self.native.replay_sample(indexes, fused) if fused else {}
+        for n in names:
+            if n not in got:
+                t = self.tensors[n]
+                got[n] = t.reshape(-1, t.shape[-1])[indexes]
+        return [got[n] for n in names]
+
     def sample_by_index(self, names: Sequence[str], indexes: torch.Tensor, mini_batches: int = 1) -> List[List[torch.Tensor]]:
-        flat = {n: self.tensors[n].reshape(-1, self.tensors[n].shape[-1]) for n in names}
         if mini_batches > 1:
-            batches = torch.chunk(indexes, mini_batches)
-            return [[flat[n][b] for n in names] for b in batches]
-        return [[flat[n][indexes] for n in names]]
+            return [self._gather(names, b) for b in torch.chunk(indexes, mini_batches)]
+        return [self._gather(names, indexes)]
 
     def sample(self, names: Sequence[str], batch_size: int, mini_batches: int = 1) -> List[List[torch.Tensor]]:
         size = len(self)

@@ -225,6 +225,21 @@ class NativeEnv:
         _native.check(self.L.ois_replay_attach(self.h, 0, None, 0))
         self._replay_mem = None
 
+    def replay_sample(self, indexes: torch.Tensor, names=("states", "actions", "rewards", "next_states", "terminated")
+                      ) -> Dict[str, torch.Tensor]:
+        """one-launch gather of a mini-batch from the transition memory (ois_replay_sample);
+        ``indexes``: int64 positions in the flattened [memory_size * num_envs] sample space"""
+        idx = indexes.to(device=self.device, dtype=torch.int64).contiguous()
+        n = int(idx.numel())
+        spec = {"states": (torch.float32, 6), "actions": (torch.float32, 4), "rewards": (torch.float32, 1),
+                "next_states": (torch.float32, 6), "terminated": (torch.bool, 1)}
+        out = {k: torch.empty((n, spec[k][1]), dtype=spec[k][0], device=self.device) for k in names}
+        ptr = [C.c_void_p(out[k].data_ptr()) if k in out else None
+               for k in ("states", "actions", "rewards", "next_states", "terminated")]
+        _native.check(self.L.ois_replay_sample(self.h, C.c_void_p(idx.data_ptr()), n, *ptr, _stream_ptr(self.device)))
+        self._last_indexes = idx  # keep alive until the stream has consumed it
+        return out
+
     def replay_cursor(self) -> Tuple[int, bool]:
         i, f = C.c_int(), C.c_int()
         _native.check(self.L.ois_replay_cursor(self.h, C.byref(i), C.byref(f)))

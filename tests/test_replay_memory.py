@@ -212,3 +212,41 @@ def test_on_policy_rollout_memory_and_gae_stay_on_the_device():
     assert sorted(mem.get_tensor_names()) == sorted(["states", "actions", "rewards", "next_states", "terminated",
                                                      "log_prob", "values", "returns", "advantages"])
     mem.close(); env.close()
+
+
+@pytest.mark.gpu
+def test_fused_sample_equals_torch_indexing():
+    """ois_replay_sample vs five indexed copies of the same tensors (what FIFOMemory.sample does,
+    train_kaddpg_4d_nofifo_random_RLIL.py:112-145): bit-identical, incl. ragged counts, repeated
+    and out-of-range indexes (clamped), NULL outputs, and the agent's extra tensors alongside."""
+    from options_in_simulation_amd.vecenv import NativeEnv
+    from options_in_simulation_amd.replay import DeviceFIFOMemory
+    N, M = 333, 12
+    env = NativeEnv(build_config(variant="KA_DDPG_4D", num_envs=N, seed=2), "cuda:0")
+    env.reset(2)
+    mem = DeviceFIFOMemory(env, M)
+    mem.create_tensor("values", 1)
+    env.rollout(20, _abi.POLICY_RANDOM)  # wraps: every row written
+    mem.tensors["values"].copy_(torch.randn((M, N, 1), device="cuda"))
+    g = torch.Generator(device="cuda").manual_seed(1)
+    for count in (1, 255, 256, 1000, 5000):
+        idx = torch.randint(0, M * N, (count,), device="cuda", generator=g)
+        got = env.replay_sample(idx)
+        for name in NAMES:
+            t = mem.tensors[name]
+            assert torch.equal(got[name], t.reshape(-1, t.shape[-1])[idx]), (count, name)
+        assert got["terminated"].dtype == torch.bool and got["states"].shape == (count, 6)
+    idx = torch.tensor([-5, 0, M * N - 1, M * N + 7, 3, 3], device="cuda")
+    got = env.replay_sample(idx, names=("rewards", "terminated"))
+    assert set(got) == {"rewards", "terminated"}
+    ref = mem.tensors["rewards"].reshape(-1, 1)[idx.clamp(0, M * N - 1)]
+    assert torch.equal(got["rewards"], ref)
+    (s, v, a), = mem.sample(["states", "values", "actions"], batch_size=777)
+    fi = mem.sampling_indexes
+    assert torch.equal(s, mem.tensors["states"].reshape(-1, 6)[fi]) and torch.equal(v, mem.tensors["values"].reshape(-1, 1)[fi])
+    assert torch.equal(a, mem.tensors["actions"].reshape(-1, 4)[fi])
+    batches = mem.sample_all(["states", "rewards"], mini_batches=3)
+    assert sum(b[0].shape[0] for b in batches) == M * N
+    mem.close()
+    with pytest.raises(RuntimeError, match="no replay memory"):
+        env.replay_sample(idx)
