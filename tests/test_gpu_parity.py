@@ -209,3 +209,32 @@ def test_non_finite_outcome_guard_parity(env_vars, monkeypatch):
     for _ in range(3):
         dev.step(torch.from_numpy(z).cuda()); orc.step(z)
     compare(dev, orc, f"{env_vars} after the guard", exact_float=True)
+
+
+@pytest.mark.parametrize("env_vars", [{"OIS_PACKED": "0"}, {"OIS_PACKED": "1"}], ids=["scalar", "packed"])
+@pytest.mark.parametrize("terrain", [False, True], ids=["plane", "field"])
+def test_runtime_iteration_count_instantiations(env_vars, terrain, monkeypatch):
+    """solver_iterations != 4 selects the NIT = 0 kernels (run-time loop instead of the unrolled
+    four iterations): same arithmetic, checked against the oracle like the default ones."""
+    from options_in_simulation_amd import terrain as tg
+    for k, v in env_vars.items():
+        monkeypatch.setenv(k, v)
+    N = 140
+    cfg, dev, orc = make_pair(variant="KAMMA_medium", num_envs=N, seed=21, max_sim_steps=80.0)
+    assert cfg.solver_iterations == 4
+    cfg.solver_iterations = 3
+    from options_in_simulation_amd.vecenv import NativeEnv
+    from oracle.binding import OracleEnv
+    dev, orc = NativeEnv(cfg, "cuda:0"), OracleEnv(cfg)
+    if terrain:
+        T = tg.Terrain({"numLevels": 2, "numTerrains": 2, "mapLength": 8.0, "mapWidth": 8.0}, N, seed=9)
+        lt = T.sample_levels_types(N, rng=np.random.RandomState(2))
+        dev.attach_terrain(T, lt); orc.attach_terrain(T, lt)
+    dev.reset(21); orc.reset(21)
+    rng = np.random.default_rng(8)
+    for t in range(25):
+        a = rng.uniform(0, 1, size=(N, 4)).astype(np.float32)
+        dev.step(torch.from_numpy(a).cuda()); orc.step(a)
+    compare(dev, orc, f"{env_vars} iterations=3 terrain={terrain}", exact_float=True)
+    dev.rollout(6, _abi.POLICY_RANDOM); orc.rollout(6, _abi.POLICY_RANDOM)
+    compare(dev, orc, "fused", exact_float=True)
