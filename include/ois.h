@@ -55,7 +55,9 @@
 extern "C" {
 #endif
 
-#define OIS_ABI_VERSION 1
+/* 2: ois_replay_*, ois_gae, ois_terrain_attach, ois_height_scan, buffers 21-22, a larger workspace
+ * (state blobs of version 1 do not load) */
+#define OIS_ABI_VERSION 2
 
 /* error codes */
 #define OIS_OK 0
