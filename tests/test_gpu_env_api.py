@@ -130,3 +130,34 @@ def test_full_size_properties(N):
     # extras of the synchronous reset: in-order group sums are deterministic across the two envs
     assert torch.equal(a.episode_info(), b.episode_info())
     assert float(a.episode_info()[_abi.EI_COUNT]) == N
+
+
+def test_step_is_capturable_in_a_hip_graph():
+    """policy + ois_step recorded once with torch.cuda.graph and replayed: the library only
+    enqueues on the caller's stream (no allocation, no synchronisation in ois_step), so the
+    launch is capturable; the replays reproduce the eager run bit for bit."""
+    from options_in_simulation_amd.vecenv import NativeEnv
+    N = 1000
+    cfg = build_config(variant="KA_DDPG_4D", num_envs=N, seed=6)
+    eager, graphed = NativeEnv(cfg, "cuda:0"), NativeEnv(cfg, "cuda:0")
+    eager.reset(6); graphed.reset(6)
+
+    def policy(obs):
+        return torch.tanh(obs[:, :4] * 0.5 + obs[:, 2:6])
+
+    for _ in range(7):
+        eager.step(policy(eager.buffer(_abi.BUF_OBS)))
+    obs = graphed.buffer(_abi.BUF_OBS)
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        graphed.step(policy(obs))          # warm-up step outside the graph (step 1)
+    torch.cuda.current_stream().wait_stream(side)
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g):
+        graphed.step(policy(obs))          # captured, not executed
+    for _ in range(6):
+        g.replay()                         # steps 2..7
+    torch.cuda.synchronize()
+    for bid in (_abi.BUF_OBS, _abi.BUF_REW, _abi.BUF_POSE, _abi.BUF_QUAT, _abi.BUF_COUNTERS, _abi.BUF_SUMS_B):
+        assert torch.equal(eager.buffer(bid), graphed.buffer(bid)), bid
