@@ -428,7 +428,10 @@ class TorqueDistributionTask:
             tcfg = dict(self._task_cfg.get("env", {}).get("terrain", {}))
             terrain = tg.Terrain(tcfg, num_robots=self.num_envs, seed=self.cfg_native.seed if seed is None else seed)
         if levels_types is None:
-            levels_types = terrain.sample_levels_types(self.num_envs)
+            # drawn for the global arena range and sliced, so that arena i sits on the same tile
+            # whether it lives in a 1-GPU env or in a shard (like the RNG keyed by global arena id)
+            off = int(self.cfg_native.arena_offset)
+            levels_types = terrain.sample_levels_types(off + self.num_envs)[off:]
         self.terrain = terrain
         self.native.attach_terrain(terrain, levels_types, **attach_kw)
         self.terrain_origins = torch.from_numpy(np.asarray(terrain.env_origins, np.float32)).to(self.device)

@@ -397,3 +397,26 @@ def test_task_terrain_surface():
     assert np.median(cl) == pytest.approx(0.0705, abs=0.03) and (cl > -0.35).all() and (cl < 0.6).all()
     assert float(info["episode"]["terrain_level"]) == pytest.approx(lv.mean(), rel=1e-6)
     env.close()
+
+
+@pytest.mark.gpu
+def test_terrain_sharding_invariance():
+    """arena i stands on the same tile and follows the same trajectory whether it lives in a
+    1-GPU env or in shard 1 of 2 (levels / types are drawn for the global arena range)"""
+    from options_in_simulation_amd import VecEnv, default_task_cfg
+    N = 128
+    cfg = default_task_cfg()
+    cfg["task"]["env"]["terrain"].update({"mapLength": 8.0, "mapWidth": 8.0, "numLevels": 3, "numTerrains": 2})
+    full = VecEnv(cfg, num_envs=N, device="cuda:0", variant="KAMMA_medium", seed=4)
+    half = VecEnv(cfg, num_envs=N // 2, device="cuda:0", variant="KAMMA_medium", seed=4, arena_offset=N // 2)
+    full.task.get_terrain(); half.task.get_terrain()
+    assert torch.equal(full.task.terrain_levels[N // 2:], half.task.terrain_levels)
+    assert torch.equal(full.task.env_origins[N // 2:], half.task.env_origins)
+    full.reset(); half.reset()
+    a = torch.rand((N, 4), device="cuda")
+    for _ in range(8):
+        full.step(a); half.step(a[N // 2:])
+    torch.cuda.synchronize()
+    for bid in (_abi.BUF_POSE, _abi.BUF_QUAT, _abi.BUF_OBS, _abi.BUF_REW, _abi.BUF_COUNTERS):
+        assert torch.equal(full.task.native.buffer(bid)[N // 2:], half.task.native.buffer(bid)), bid
+    full.close(); half.close()
