@@ -88,9 +88,23 @@ def cpu_baseline(n_arenas, seconds_target=12.0):
     env.rollout(steps, _abi.POLICY_RANDOM)
     dt = time.perf_counter() - t0
     env.close()
+    # the same oracle on ONE thread (512 arenas, ~3 s), rate per core
+    n1 = min(n_arenas, 512)
+    one = OracleEnv(build_config(variant="KAMMA_medium", num_envs=n1, seed=42), threads=1)
+    one.reset(42)
+    one.rollout(2, _abi.POLICY_RANDOM)
+    t0 = time.perf_counter()
+    one.rollout(4, _abi.POLICY_RANDOM)
+    steps1 = int(max(4, min(5000, 3.0 / max((time.perf_counter() - t0) / 4, 1e-6))))
+    t0 = time.perf_counter()
+    one.rollout(steps1, _abi.POLICY_RANDOM)
+    dt1 = time.perf_counter() - t0
+    one.close()
     return {"value": n * steps / dt, "unit": "env-steps/s", "cores": cores, "kind": "port",
             "sample": f"{n} arenas x {steps} policy steps of the same KAMMA_medium task (in-oracle random actions, "
-                      f"no actor), OpenMP over arenas, {dt:.1f} s"}
+                      f"no actor), OpenMP over arenas, {dt:.1f} s",
+            "single_thread": {"value": n1 * steps1 / dt1, "cores": 1,
+                              "sample": f"{n1} arenas x {steps1} policy steps, {dt1:.1f} s"}}
 
 
 def main():
