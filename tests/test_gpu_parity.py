@@ -238,3 +238,29 @@ def test_runtime_iteration_count_instantiations(env_vars, terrain, monkeypatch):
     compare(dev, orc, f"{env_vars} iterations=3 terrain={terrain}", exact_float=True)
     dev.rollout(6, _abi.POLICY_RANDOM); orc.rollout(6, _abi.POLICY_RANDOM)
     compare(dev, orc, "fused", exact_float=True)
+
+
+def test_second_reset_with_another_seed():
+    """ois_reset in the middle of a run: everything restarts (counters, sums, statistics, impulse
+    cache), the episode stream follows the new seed, parameters set by ois_randomize_params stay"""
+    N = 150
+    cfg, dev, orc = make_pair(variant="KAMMA_medium", num_envs=N, seed=1)
+    dev.randomize_params(0.6, 0.9, [-0.2, 0.2]); orc.randomize_params(0.6, 0.9, [-0.2, 0.2])
+    dev.reset(1); orc.reset(1)
+    rng = np.random.default_rng(1)
+    for t in range(5):
+        a = rng.uniform(0, 1, size=(N, 4)).astype(np.float32)
+        dev.step(torch.from_numpy(a).cuda()); orc.step(a)
+    first = dev.buffer(_abi.BUF_POSE).clone()
+    dev.reset(99); orc.reset(99)
+    compare(dev, orc, "after the second reset", exact_float=True)
+    assert not torch.equal(dev.buffer(_abi.BUF_POSE), first)
+    assert (dev.buffer(_abi.BUF_COUNTERS)[:, 1] == 0).all() and (dev.buffer(_abi.BUF_COUNTERS)[:, 2] == 1).all()
+    torch.cuda.synchronize()
+    assert np.array_equal(dev.buffer(_abi.BUF_PARAMS).cpu().numpy(), orc.buffer(_abi.BUF_PARAMS))
+    for t in range(5):
+        a = rng.uniform(0, 1, size=(N, 4)).astype(np.float32)
+        dev.step(torch.from_numpy(a).cuda()); orc.step(a)
+    compare(dev, orc, "steps after the second reset", exact_float=True)
+    sd, so = dev.stats(), orc.stats()
+    assert sd.episodes == so.episodes == 0 and sd.steps == so.steps == 5 * N
