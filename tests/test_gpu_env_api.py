@@ -161,3 +161,19 @@ def test_step_is_capturable_in_a_hip_graph():
     torch.cuda.synchronize()
     for bid in (_abi.BUF_OBS, _abi.BUF_REW, _abi.BUF_POSE, _abi.BUF_QUAT, _abi.BUF_COUNTERS, _abi.BUF_SUMS_B):
         assert torch.equal(eager.buffer(bid), graphed.buffer(bid)), bid
+
+
+def test_example_loop_runs(tmp_path):
+    """examples/kaddpg_loop.py: env + device memory + sampling + tracker end to end"""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("kaddpg_loop", os.path.join(os.path.dirname(os.path.dirname(__file__)),
+                                                                            "examples", "kaddpg_loop.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    assert mod.main(["--num-envs", "512", "--timesteps", "120", "--memory-size", "8", "--batch-size", "1024",
+                     "--logdir", str(tmp_path)]) == 0
+    from options_in_simulation_amd.tracking import timeseries_from_events
+    ev = [f for f in os.listdir(tmp_path) if f.startswith("events.out.tfevents")]
+    steps, cols = timeseries_from_events(os.path.join(tmp_path, ev[0]))
+    assert steps == [30, 60, 90, 120] and np.isfinite(cols["current_v"]).all()
+    assert os.path.exists(os.path.join(tmp_path, "reward_components_env0_timeseries.csv"))
