@@ -151,3 +151,21 @@ def test_no_kernel_reads_the_dispatch_packet(tmp_path):
             assert ".amdhsa_private_segment_fixed_size 0" in body, f"{name} uses scratch"
             if "step_kernel" in name:
                 assert ".amdhsa_group_segment_fixed_size 0" in body, f"{name}: a private array was promoted to LDS"
+
+
+def test_new_entry_points_reject_bad_arguments_without_a_gpu(lib):
+    """replay / gae / terrain entry points: argument checks come before any HIP call"""
+    assert lib.ois_replay_bytes(None, 4) == 0
+    assert lib.ois_replay_attach(None, 4, None, 0) == _abi.EINVAL
+    assert lib.ois_replay_sample(None, None, 1, None, None, None, None, None, None) == _abi.EINVAL
+    i, f = C.c_int(), C.c_int()
+    assert lib.ois_replay_cursor(None, C.byref(i), C.byref(f)) == _abi.EINVAL
+    assert lib.ois_terrain_attach(None, None, None, None, None, None) == _abi.EINVAL
+    assert lib.ois_height_scan(None, None, None) == _abi.EINVAL
+    assert lib.ois_gae_scratch_bytes(0) == 0 and lib.ois_gae_scratch_bytes(65536) == (2 * 1024 + 1) * 8
+    one = C.c_void_p(8)  # never dereferenced: every call below fails its checks first
+    assert lib.ois_gae(7, 4, 4, one, one, one, one, 0.99, 0.95, 0, one, one, None, 0, None) == _abi.EINVAL  # unknown mode
+    assert lib.ois_gae(0, 0, 4, one, one, one, one, 0.99, 0.95, 0, one, one, None, 0, None) == _abi.EINVAL  # T = 0
+    assert lib.ois_gae(0, 4, 4, None, one, one, one, 0.99, 0.95, 0, one, one, None, 0, None) == _abi.EINVAL  # null tensor
+    assert lib.ois_gae(0, 4, 4, one, one, one, one, 0.99, 0.95, 1, one, one, None, 0, None) == _abi.ENOMEM  # normalize without scratch
+    assert b"scratch" in lib.ois_last_error()
