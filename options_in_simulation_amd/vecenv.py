@@ -158,9 +158,27 @@ class NativeEnv:
         return st
 
     def env0_diag(self) -> np.ndarray:
+        if getattr(self, "_logs_step", -1) == self.policy_steps:
+            return self._logs[1]
         out = np.zeros(_abi.ENV0_DIAG_LEN, np.float32)
         _native.check(self.L.ois_env0_diag(self.h, out.ctypes.data_as(C.POINTER(C.c_float)), _stream_ptr(self.device)))
         return out
+
+    def host_logs(self) -> Tuple[np.ndarray, np.ndarray]:
+        """(episode_info[32], env0_diag[32]) of the current step on the host with ONE
+        synchronisation: the finalisation kernels are enqueued, then the two adjacent 128-byte
+        blocks come over in a single copy. A trainer that reads both every step
+        (base_KA_DDPG.py:184-262) otherwise drains the pipeline twice."""
+        if getattr(self, "_logs_step", -1) != self.policy_steps:
+            info, diag = self.episode_info(), self._views[_abi.BUF_ENV0_DIAG]
+            base = self.workspace.data_ptr()
+            lo = min(info.data_ptr(), diag.data_ptr()) - base
+            hi = max(info.data_ptr(), diag.data_ptr()) - base + 4 * _abi.ENV0_DIAG_LEN
+            blob = self.workspace[lo:hi].cpu().numpy().view(np.float32)
+            i0, d0 = (info.data_ptr() - base - lo) // 4, (diag.data_ptr() - base - lo) // 4
+            self._logs = (blob[i0:i0 + _abi.EPISODE_INFO_LEN].copy(), blob[d0:d0 + _abi.ENV0_DIAG_LEN].copy())
+            self._logs_step = self.policy_steps
+        return self._logs
 
     def attach_terrain(self, terrain, levels_types: np.ndarray, curriculum: Optional[bool] = None,
                        threshold_low: float = 0.3, threshold_high: float = 5.0, max_level: Optional[int] = None):
@@ -271,8 +289,11 @@ class _LazyEpisodeInfo(dict):
         if self._done:
             return
         self._done = True
-        vec = self._native.episode_info()
-        vec = vec.cpu() if self._on_host else vec.clone()
+        if self._on_host:
+            vec = torch.from_numpy(self._native.host_logs()[0])  # shares its one copy with observed_components
+            self._native._infos_read = True  # tells observed_components to fetch both blocks at once from now on
+        else:
+            vec = self._native.episode_info().clone()
         for slot, key in _abi.EPISODE_INFO_KEYS.items():
             dict.__setitem__(self, key, vec[slot])
         for key in _abi.EPISODE_INFO_ZERO_KEYS:
@@ -395,7 +416,9 @@ class TorqueDistributionTask:
     @property
     def observed_components(self) -> Dict[str, float]:
         if self._diag_step != self.native.policy_steps:
-            d = self.native.env0_diag().astype(np.float64)
+            # a loop that also reads infos["episode"] every step gets both blocks in one copy
+            combined = getattr(self.native, "_infos_read", False) and self.infos_on_host
+            d = (self.native.host_logs()[1] if combined else self.native.env0_diag()).astype(np.float64)
             g2, rew = d[19], d[27]
 
             def perc(x, scale):

@@ -177,3 +177,29 @@ def test_example_loop_runs(tmp_path):
     steps, cols = timeseries_from_events(os.path.join(tmp_path, ev[0]))
     assert steps == [30, 60, 90, 120] and np.isfinite(cols["current_v"]).all()
     assert os.path.exists(os.path.join(tmp_path, "reward_components_env0_timeseries.csv"))
+
+
+def test_combined_host_logs_equal_the_separate_reads():
+    """task.observed_components and infos['episode'] share one device-to-host copy once a loop
+    reads both (NativeEnv.host_logs): same values as the two separate entry points"""
+    from options_in_simulation_amd import VecEnv
+    env = VecEnv(num_envs=300, device="cuda:0", variant="KAMMA_eval", seed=9)
+    env.reset()
+    for t in range(120):
+        _, _, _, _, infos = env.step(torch.rand((300, 4), device="cuda"))
+        if t < 100 and t % 7:
+            continue
+        oc = dict(env.task.observed_components)          # first: diag path (combined after the first infos read)
+        ep = {k: float(v) for k, v in infos["episode"].items()}
+        n = env.task.native
+        direct_info = n.episode_info().cpu().numpy()
+        n._logs_step = -1                                # force the plain ois_env0_diag path
+        direct_diag = n.env0_diag()
+        assert oc["env0_desired_v"] == float(direct_diag[0]) and oc["env0_episode_count"] == int(direct_diag[8])
+        assert oc["env0_torque_apl_rr"] == float(direct_diag[12])
+        for slot, key in _abi.EPISODE_INFO_KEYS.items():
+            a, b = ep[key], float(direct_info[slot])
+            assert a == b or (np.isnan(a) and np.isnan(b)), key
+        assert all(v.device.type == "cpu" for v in infos["episode"].values())
+    assert getattr(env.task.native, "_infos_read", False)
+    env.close()
