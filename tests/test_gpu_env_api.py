@@ -163,6 +163,15 @@ def test_step_is_capturable_in_a_hip_graph():
         assert torch.equal(eager.buffer(bid), graphed.buffer(bid)), bid
 
 
+def test_ppo_example_runs():
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("ppo_rollout", os.path.join(os.path.dirname(os.path.dirname(__file__)),
+                                                                            "examples", "ppo_rollout.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    assert mod.main(["--num-envs", "256", "--rollouts", "8", "--updates", "2"]) == 0
+
+
 def test_example_loop_runs(tmp_path):
     """examples/kaddpg_loop.py: env + device memory + sampling + tracker end to end"""
     import importlib.util
