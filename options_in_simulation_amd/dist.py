@@ -9,7 +9,7 @@ KAMMA.py:480-488). Backend "nccl" is RCCL on ROCm; "gloo" is used by the CPU tes
 """
 from __future__ import annotations
 
-from typing import List, Optional, Tuple
+from typing import Dict, List, Tuple
 
 import torch
 import torch.distributed as dist
@@ -67,3 +67,39 @@ def merge_stats(parts: List[_abi.OisStats]) -> dict:
             "return_min": min(p.return_min for p in parts if p.episodes),
             "return_max": max(p.return_max for p in parts if p.episodes),
             "return_std": var ** 0.5, "length_mean": sum(p.length_sum for p in parts) / n}
+
+
+def gather_episode_info(info, num_envs: int, device=None, group=None) -> Dict[str, float]:
+    """Global ``extras["episode"]`` (KAMMA.py:480-488) from the per-rank vectors of
+    ``ois_episode_info`` with ONE all-gather of 33 floats per rank: the per-key means of the
+    most recent reset event are re-weighted by each rank's count of resetting arenas (ranks whose
+    newest event is older than the global newest do not contribute), ``terrain_level`` by the
+    ranks' arena counts, gamma is taken from a contributing rank."""
+    vec = torch.as_tensor(info, dtype=torch.float64).flatten().cpu()
+    mine = torch.cat([vec[:_abi.EPISODE_INFO_LEN], torch.tensor([float(num_envs)], dtype=torch.float64)])
+    if dist.is_available() and dist.is_initialized():
+        backend = dist.get_backend(group)
+        dev = torch.device("cpu") if backend == "gloo" else (device or torch.device("cuda", torch.cuda.current_device()))
+        world = dist.get_world_size(group)
+        out = torch.empty(world * mine.numel(), dtype=torch.float64, device=dev)
+        dist.all_gather_into_tensor(out, mine.to(dev), group=group)
+        rows = out.view(world, -1).cpu()
+    else:
+        rows = mine.view(1, -1)
+    step = rows[:, _abi.EI_STEP]
+    cnt = torch.where(step == step.max(), rows[:, _abi.EI_COUNT], torch.zeros_like(step))
+    total = float(cnt.sum())
+    merged: Dict[str, float] = {}
+    keys = dict(_abi.EPISODE_INFO_KEYS)
+    keys.update(_abi.EPISODE_INFO_EVAL_KEYS)
+    lead = int(torch.argmax(cnt))
+    for slot, key in keys.items():
+        if key in ("gamma_1 action assist", "gamma_2 reward assist"):
+            merged[key] = float(rows[lead, slot])
+        elif key == "terrain_level":
+            merged[key] = float((rows[:, slot] * rows[:, -1]).sum() / rows[:, -1].sum())
+        else:
+            merged[key] = float((rows[:, slot] * cnt).sum() / total) if total > 0 else float("nan")
+    merged["count"] = total
+    merged["step"] = float(step.max())
+    return merged

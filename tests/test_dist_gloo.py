@@ -11,7 +11,7 @@ import torch.distributed as dist
 import torch.multiprocessing as mp
 
 from options_in_simulation_amd import _abi, build_config
-from options_in_simulation_amd.dist import gather_stats, merge_stats, shard_range
+from options_in_simulation_amd.dist import gather_episode_info, gather_stats, merge_stats, shard_range
 
 
 def test_shard_range_partitions():
@@ -43,7 +43,9 @@ def _worker(rank, world, port, total, steps, out_dir):
     assert len(parts) == world
     merged = merge_stats(parts)
     np.save(os.path.join(out_dir, f"state_{rank}.npy"), env.buffer(_abi.BUF_POSE))
+    info = gather_episode_info(env.episode_info(), hi - lo)
     if rank == 0:
+        np.save(os.path.join(out_dir, "info.npy"), np.array([info[k] for k in sorted(info)]))
         np.save(os.path.join(out_dir, "merged.npy"), np.array([merged["episodes"], merged["return_mean"], merged["return_min"],
                                                                  merged["return_max"], merged["steps"], merged["length_mean"]]))
     dist.barrier()
@@ -65,6 +67,16 @@ def test_two_rank_sharded_run_matches_single_process(tmp_path):
     assert merged[1] == pytest.approx(st.return_sum / st.episodes, rel=1e-5)
     assert merged[2] == pytest.approx(st.return_min, rel=1e-6) and merged[3] == pytest.approx(st.return_max, rel=1e-6)
     assert merged[4] == total * steps and merged[5] == 99.0
+    # the merged extras of the two shards = the extras of the unsharded run (same reset event)
+    ei = full.episode_info()
+    ref = {key: float(ei[slot]) for slot, key in _abi.EPISODE_INFO_KEYS.items()}
+    ref["count"], ref["step"] = float(ei[_abi.EI_COUNT]), float(ei[_abi.EI_STEP])
+    for slot, key in _abi.EPISODE_INFO_EVAL_KEYS.items():
+        ref[key] = float(ei[slot])
+    got = dict(zip(sorted(ref), np.load(tmp_path / "info.npy")))
+    assert got["count"] == ref["count"] > 0 and got["step"] == ref["step"]
+    for key in ref:
+        assert got[key] == pytest.approx(ref[key], rel=1e-5, abs=1e-6, nan_ok=True), key
 
 
 def test_gather_without_process_group_is_identity():
@@ -74,3 +86,6 @@ def test_gather_without_process_group_is_identity():
     m = merge_stats([st])
     assert m["return_mean"] == -2.0
     assert merge_stats([_abi.OisStats()])["return_mean"] is None
+    vec = np.zeros(_abi.EPISODE_INFO_LEN); vec[_abi.EI_COUNT], vec[_abi.EI_STEP], vec[8], vec[16] = 4, 99, -2.5, 0.75
+    one = gather_episode_info(vec, 16)
+    assert one["rew_Final reward"] == -2.5 and one["gamma_1 action assist"] == 0.75 and one["count"] == 4 and one["step"] == 99
