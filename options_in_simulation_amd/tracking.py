@@ -117,7 +117,8 @@ def _fields(buf: bytes) -> Iterator[Tuple[int, int, object]]:
 def read_events(path: str) -> List[Tuple[int, float, Dict[str, float]]]:
     """[(step, wall_time, {tag: value})] of an event file; verifies both CRCs of every record."""
     out = []
-    data = open(path, "rb").read()
+    with open(path, "rb") as f:
+        data = f.read()
     i = 0
     while i < len(data):
         header = data[i:i + 8]
