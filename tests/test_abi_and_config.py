@@ -13,6 +13,11 @@ from options_in_simulation_amd.config import VARIANTS, composite_body
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
+def _read(path):
+    with open(path) as f:
+        return f.read()
+
+
 @pytest.fixture(scope="module")
 def lib():
     from options_in_simulation_amd import _native
@@ -23,7 +28,7 @@ def lib():
 
 
 def test_library_exports_every_symbol_of_the_header(lib):
-    header = open(os.path.join(ROOT, "include", "ois.h")).read()
+    header = _read(os.path.join(ROOT, "include", "ois.h"))
     declared = set(re.findall(r"\b(ois_[a-z0-9_]+)\s*\(", header))
     declared -= {"ois_env"}
     assert declared, "no declarations parsed"
@@ -86,7 +91,7 @@ def test_product_never_imports_the_oracle():
     for dirpath, _, files in os.walk(pkg):
         for f in files:
             if f.endswith((".py", ".h", ".hip", ".c", ".cpp")):
-                txt = open(os.path.join(dirpath, f)).read()
+                txt = _read(os.path.join(dirpath, f))
                 assert not re.search(r"^\s*(from|import)\s+oracle\b", txt, re.M), f      # python import
                 assert not re.search(r'#\s*include\s+["<][^">]*oracle', txt), f          # C include
                 assert "libois_oracle" not in txt and not re.search(r"\borc_[a-z_]+\s*\(", txt), f  # link / call

@@ -40,7 +40,8 @@ def test_event_file_round_trip_and_framing(tmp_path):
     assert ev[1][0] == 800 and ev[1][2] == {"Reward_comp_env0 / v_delta": 0.25}
     assert ev[2][0] == 1600 and ev[2][2] == {"Info / rew_Final reward": -1.5, "Info / terrain_level": 0.0}
     assert ev[3][0] == 2 ** 40 + 7
-    raw = open(w.path, "rb").read()
+    with open(w.path, "rb") as f:
+        raw = f.read()
     (n,) = struct.unpack("<Q", raw[:8])
     assert raw[12:12 + n].endswith(b"brain.Event:2") and raw[12] == 0x09  # field 1, fixed64 wall_time first
     # a flipped payload bit is detected
@@ -91,7 +92,8 @@ def test_env0_tracker_writes_interval_means_and_csv(tmp_path):
     assert by_step[20]["Reward_comp_env0 / desired_v"] == pytest.approx(1.5)
     assert by_step[10]["Info / rew_Final reward"] == pytest.approx(-7.5)         # mean of -5, -10
     assert "Info / vector" not in by_step[10]                                    # only one-element values (:261)
-    rows = list(csv.reader(open(trk.csv_path)))
+    with open(trk.csv_path) as f:
+        rows = list(csv.reader(f))
     assert rows[0] == ["step", "v_delta", "desired_v", "current_v", "omega_delta", "desired_omega", "current_omega"]
     assert [int(r[0]) for r in rows[1:]] == [10, 20, 30] and float(rows[1][3]) == pytest.approx(5.5)
     steps, cols = tr.timeseries_from_events(trk.writer.path)                     # the route artifacts.py takes
@@ -136,7 +138,8 @@ def test_tracking_error_vs_speed_csv(tmp_path):
     assert len(xs) == 9 and xs[0] == pytest.approx(1.0) and xs[4] == pytest.approx(1.5)
     raw = [0, 1, 2, 3, 5, 6, 7, 8, 9]
     assert ys == pytest.approx([np.mean(raw[max(0, k - 2):k + 1]) for k in range(9)])
-    rows = list(csv.reader(open(tmp_path / "tracking_error_vs_speed.csv")))
+    with open(tmp_path / "tracking_error_vs_speed.csv") as f:
+        rows = list(csv.reader(f))
     assert rows[0] == ["speed_m_s", "tracking_error_m_s"] and len(rows) == 10
     w2 = tr.EventFileWriter(str(tmp_path / "b"))
     w2.add_scalar("Info / rew_Tracking error", 0.5, 1); w2.add_scalar("Info / rew_Tracking error", 0.7, 2)
