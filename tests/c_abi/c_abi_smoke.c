@@ -1,0 +1,89 @@
+/* The C ABI of include/ois.h used from plain C, without Python or torch: hipMalloc'ed
+ * workspace and actions, create -> reset -> steps -> rollout -> buffers -> stats -> state
+ * save / load -> destroy. Built and run by tests/test_gpu_env_api.py::test_c_abi_from_plain_c.
+ *   hipcc -x c -o c_abi_smoke c_abi_smoke.c -I../../include -L<lib dir> -lois_hip -Wl,-rpath,<lib dir>
+ */
+#include <hip/hip_runtime_api.h>
+#include <math.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include "ois.h"
+
+#define CHECK(x)                                                                              \
+  do {                                                                                        \
+    int rc_ = (x);                                                                            \
+    if (rc_ != 0) { fprintf(stderr, "%s -> %d: %s\n", #x, rc_, ois_last_error()); return 1; } \
+  } while (0)
+#define HIP(x)                                                                                        \
+  do {                                                                                                \
+    hipError_t e_ = (x);                                                                              \
+    if (e_ != hipSuccess) { fprintf(stderr, "%s: %s\n", #x, hipGetErrorString(e_)); return 1; }       \
+  } while (0)
+
+int main(void) {
+  const int N = 1000;
+  ois_config cfg;
+  CHECK(ois_config_default(&cfg));
+  cfg.num_envs = N;
+  cfg.seed = 5;
+  if (ois_abi_version() != OIS_ABI_VERSION) { fprintf(stderr, "ABI mismatch\n"); return 1; }
+  size_t bytes = ois_workspace_bytes(&cfg);
+  if (bytes == 0) { fprintf(stderr, "bad config: %s\n", ois_last_error()); return 1; }
+  void* ws = NULL;
+  HIP(hipMalloc(&ws, bytes));
+  hipStream_t stream;
+  HIP(hipStreamCreate(&stream));
+  ois_env* env = NULL;
+  CHECK(ois_create(&cfg, 0, ws, bytes, &env));
+  if (ois_step(env, (const float*)ws, stream) != OIS_ESTATE) { fprintf(stderr, "step before reset not refused\n"); return 1; }
+  CHECK(ois_reset(env, 5, stream));
+
+  float* h_act = (float*)malloc(sizeof(float) * N * 4);
+  for (int i = 0; i < N * 4; ++i) h_act[i] = (float)((i * 37) % 100) / 100.0f;
+  float* d_act = NULL;
+  HIP(hipMalloc((void**)&d_act, sizeof(float) * N * 4));
+  HIP(hipMemcpyAsync(d_act, h_act, sizeof(float) * N * 4, hipMemcpyHostToDevice, stream));
+  for (int t = 0; t < 5; ++t) CHECK(ois_step(env, d_act, stream));
+  float* d_sum = NULL;
+  HIP(hipMalloc((void**)&d_sum, sizeof(float) * N));
+  CHECK(ois_rollout(env, 100, OIS_POLICY_RANDOM, NULL, d_sum, stream)); /* crosses the timeout at step 99 */
+
+  void* p = NULL;
+  size_t n = 0;
+  CHECK(ois_buffer(env, OIS_BUF_OBS, &p, &n));
+  if (n != sizeof(float) * N * 6 || (char*)p < (char*)ws || (char*)p + n > (char*)ws + bytes) { fprintf(stderr, "obs buffer not inside the workspace\n"); return 1; }
+  float* h_obs = (float*)malloc(n);
+  HIP(hipMemcpyAsync(h_obs, p, n, hipMemcpyDeviceToHost, stream));
+  CHECK(ois_buffer(env, OIS_BUF_COUNTERS, &p, &n));
+  int* h_cnt = (int*)malloc(n);
+  HIP(hipMemcpyAsync(h_cnt, p, n, hipMemcpyDeviceToHost, stream));
+  float* h_sum = (float*)malloc(sizeof(float) * N);
+  HIP(hipMemcpyAsync(h_sum, d_sum, sizeof(float) * N, hipMemcpyDeviceToHost, stream));
+  ois_stats st;
+  CHECK(ois_stats_fetch(env, &st, 0, stream)); /* synchronises the stream */
+  for (int i = 0; i < N * 6; ++i)
+    if (!isfinite(h_obs[i])) { fprintf(stderr, "non-finite observation\n"); return 1; }
+  for (int i = 0; i < N; ++i) {
+    if (h_cnt[4 * i + 1] != 105 || h_cnt[4 * i + 2] != 2 || h_cnt[4 * i + 0] != 105 - 99) { fprintf(stderr, "counters of arena %d: %d %d %d\n", i, h_cnt[4 * i], h_cnt[4 * i + 1], h_cnt[4 * i + 2]); return 1; }
+    if (!isfinite(h_sum[i])) { fprintf(stderr, "non-finite reward sum\n"); return 1; }
+  }
+  if (st.episodes != (double)N || st.steps != (double)N * 105.0) { fprintf(stderr, "stats: %f episodes, %f steps\n", st.episodes, st.steps); return 1; }
+
+  size_t sb = ois_state_bytes(env);
+  void* blob = malloc(sb);
+  CHECK(ois_save_state(env, blob, sb, stream));
+  CHECK(ois_rollout(env, 3, OIS_POLICY_ZERO, NULL, NULL, stream));
+  CHECK(ois_load_state(env, blob, sb, stream));
+  CHECK(ois_buffer(env, OIS_BUF_COUNTERS, &p, &n));
+  HIP(hipMemcpy(h_cnt, p, n, hipMemcpyDeviceToHost));
+  if (h_cnt[1] != 105) { fprintf(stderr, "state not restored\n"); return 1; }
+
+  if (ois_rollout(env, 0, OIS_POLICY_ZERO, NULL, NULL, stream) != OIS_EINVAL) { fprintf(stderr, "k = 0 not refused\n"); return 1; }
+  ois_destroy(env);
+  HIP(hipFree(d_act)); HIP(hipFree(d_sum)); HIP(hipFree(ws));
+  free(h_act); free(h_obs); free(h_cnt); free(h_sum); free(blob);
+  printf("c abi ok: %d arenas, %.0f episodes, mean return %.3f\n", N, st.episodes, st.return_sum / st.episodes);
+  return 0;
+}

@@ -212,3 +212,22 @@ def test_combined_host_logs_equal_the_separate_reads():
         assert all(v.device.type == "cpu" for v in infos["episode"].values())
     assert getattr(env.task.native, "_infos_read", False)
     env.close()
+
+
+def test_c_abi_from_plain_c(tmp_path):
+    """tests/c_abi/c_abi_smoke.c: the boundary of include/ois.h driven from a C11 program built
+    with gcc (no Python, no torch types): hipMalloc'ed workspace and actions, step / rollout /
+    buffers / stats / state blob, error codes."""
+    import shutil
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    libdir = os.path.join(root, "options_in_simulation_amd", "lib")
+    if not (shutil.which("gcc") and os.path.exists("/opt/rocm/include/hip/hip_runtime_api.h")):
+        pytest.skip("gcc or the HIP headers are missing")
+    exe = str(tmp_path / "c_abi_smoke")
+    subprocess.run(["gcc", "-std=c11", "-O1", "-D__HIP_PLATFORM_AMD__", "-I/opt/rocm/include", "-I" + os.path.join(root, "include"),
+                    "-o", exe, os.path.join(root, "tests", "c_abi", "c_abi_smoke.c"), "-L" + libdir, "-lois_hip", "-L/opt/rocm/lib",
+                    "-lamdhip64", "-Wl,-rpath," + libdir, "-Wl,-rpath,/opt/rocm/lib", "-lm"], check=True, capture_output=True)
+    res = subprocess.run([exe], capture_output=True, text=True, timeout=120)
+    assert res.returncode == 0, res.stdout + res.stderr
+    assert "c abi ok: 1000 arenas, 1000 episodes" in res.stdout
