@@ -25,6 +25,39 @@ from .vecenv import NativeEnv, VecEnv
 KERNEL_TENSORS = ("states", "actions", "rewards", "next_states", "terminated")
 
 
+def indices_without_replacement(size: int, batch_size: int, device, generator=None) -> torch.Tensor:
+    """``torch.randperm(size)[:batch_size]`` in distribution (a uniformly random ``batch_size``-subset
+    in uniformly random order) without permuting the whole memory — the reference's FIFOMemory
+    (``train_kaddpg_4d_nofifo_random_RLIL.py:139``) holds 35 000 samples of one arena, the same
+    35 000 rows of 65 536 arenas are 2.3 G samples, whose permutation would be 18 GB per call.
+
+    The first ``batch_size`` DISTINCT values of an i.i.d. uniform stream are exactly such a
+    subset. ``2 * batch_size`` candidates are drawn, later duplicates are masked out (stable sort
+    by value, compare neighbours), the survivors are compacted in stream order with a prefix sum;
+    all shapes are fixed, nothing synchronises. It is used when ``8 * batch_size <= size``: then
+    fewer than ``batch_size`` distinct candidates among ``2 * batch_size`` draws would need more
+    than half of them to collide with at most 1/4 occupancy — no realistic probability — and the
+    buffer is pre-filled with the leading candidates so that even then the result is in range.
+    Denser requests fall back to ``randperm``."""
+    if batch_size > size:
+        raise ValueError(f"cannot draw {batch_size} distinct samples out of {size}")
+    if 8 * batch_size > size:
+        return torch.randperm(size, dtype=torch.long, device=device, generator=generator)[:batch_size]
+    m = 2 * batch_size
+    cand = torch.randint(0, size, (m,), device=device, generator=generator)
+    srt, order = torch.sort(cand, stable=True)          # equal values keep their stream order
+    dup_sorted = torch.zeros(m, dtype=torch.bool, device=device)
+    dup_sorted[1:] = srt[1:] == srt[:-1]                # every occurrence after the first
+    first = torch.ones(m, dtype=torch.bool, device=device)
+    first[order] = ~dup_sorted                          # back to stream positions
+    rank = torch.cumsum(first, 0) - 1                   # index among the distinct values, in stream order
+    target = torch.where(first & (rank < batch_size), rank, torch.full_like(rank, batch_size))
+    out = torch.empty(batch_size + 1, dtype=torch.long, device=device)
+    out[:batch_size] = cand[:batch_size]
+    out.scatter_(0, target, cand)                       # slot batch_size collects everything unused
+    return out[:batch_size]
+
+
 class DeviceFIFOMemory:
     def __init__(self, env: "VecEnv | NativeEnv", memory_size: int, replacement: bool = False):
         native = env.task.native if isinstance(env, VecEnv) else env
@@ -100,17 +133,16 @@ class DeviceFIFOMemory:
         return [self._gather(names, indexes)]
 
     def sample(self, names: Sequence[str], batch_size: int, mini_batches: int = 1) -> List[List[torch.Tensor]]:
-        """FIFOMemory.sample (train_kaddpg_4d_nofifo_random_RLIL.py:112-145). Without replacement
-        (the scripts' setting) the indexes are ``randperm(len(self))[:batch_size]`` as there — at
-        a million stored samples that permutation is 240 µs per call against 25 µs for the whole
-        call with ``replacement=True`` (tools/memory_sample_probe.py); the gather itself is one launch."""
+        """FIFOMemory.sample (train_kaddpg_4d_nofifo_random_RLIL.py:112-145): ``batch_size`` indexes
+        with or without replacement (the scripts use ``replacement=False``), then the gather — one
+        launch here."""
         size = len(self)
         if size == 0:
             raise RuntimeError("the memory is empty")
         if self.replacement:
             indexes = torch.randint(0, size, (batch_size,), device=self.device)
         else:
-            indexes = torch.randperm(size, dtype=torch.long, device=self.device)[:batch_size]
+            indexes = indices_without_replacement(size, batch_size, self.device)
         self.sampling_indexes = indexes
         return self.sample_by_index(names, indexes, mini_batches)
 

@@ -89,6 +89,40 @@ def test_terminated_rows_carry_post_reset_observation():
     assert not np.array_equal(mem["states"][98][:, 0:2], mem["next_states"][98][:, 0:2])
 
 
+def test_indices_without_replacement_is_the_first_distinct_prefix_of_the_stream():
+    """the sampler behind DeviceFIFOMemory.sample(replacement=False): distinct, in range, exactly
+    the first batch_size distinct values of the i.i.d. candidate stream (which is what makes it
+    equal in distribution to randperm(size)[:batch_size]), uniform over the memory"""
+    torch = pytest.importorskip("torch")
+    from options_in_simulation_amd.replay import indices_without_replacement
+    for size, b in ((1000, 100), (64, 8), (10 ** 9, 4096), (50, 6)):
+        g = torch.Generator().manual_seed(size + b)
+        idx = indices_without_replacement(size, b, "cpu", generator=g)
+        assert idx.shape == (b,) and idx.dtype == torch.long
+        assert int(idx.min()) >= 0 and int(idx.max()) < size and len(torch.unique(idx)) == b
+        g2 = torch.Generator().manual_seed(size + b)
+        stream = torch.randint(0, size, (2 * b,), generator=g2).tolist()
+        seen, firsts = set(), []
+        for v in stream:
+            if v not in seen:
+                seen.add(v); firsts.append(v)
+        assert idx.tolist() == firsts[:b]
+    # a small memory forces collisions: still the distinct prefix
+    g = torch.Generator().manual_seed(0)
+    counts = torch.zeros(40)
+    first_pos = torch.zeros(40)
+    for _ in range(4000):
+        idx = indices_without_replacement(40, 5, "cpu", generator=g)
+        assert len(set(idx.tolist())) == 5
+        counts[idx] += 1; first_pos[idx[0]] += 1
+    assert (counts - 500).abs().max() < 5 * (500 * 0.875) ** 0.5       # every index equally likely (5 sigma)
+    assert (first_pos - 100).abs().max() < 5 * 100 ** 0.5              # and equally likely to come first
+    # dense requests use randperm; impossible ones are refused
+    assert sorted(indices_without_replacement(10, 10, "cpu").tolist()) == list(range(10))
+    with pytest.raises(ValueError):
+        indices_without_replacement(5, 6, "cpu")
+
+
 # ------------------------------------------------------------------------------------- gpu
 torch = pytest.importorskip("torch")
 
