@@ -80,6 +80,9 @@ def default_task_cfg(script_overrides: bool = True) -> Dict[str, Any]:
         env["control"]["damping"] = 0.005
         env["terrain"]["staticFriction"] = 0.85
         env["terrain"]["dynamicFriction"] = 0.85
+        mat = cfg["task"]["sim"].setdefault("default_physics_material", {})
+        mat["static_friction"] = 0.85    # train_kamma_4d_nofifo_random_RLIL.py:88-89 (the key the scripts patch)
+        mat["dynamic_friction"] = 0.85
         env["randomCommandVelocityRanges"]["linear_x"] = [1.0, 2.0]
     return cfg
 
@@ -253,7 +256,12 @@ def build_config(task_cfg: Optional[Dict[str, Any]] = None, variant: str = "KAMM
     c.wheel_radius = float(ctrl.get("wheel_radius", ROBOT["wheel_radius"]))  # KAMMA.py:79
     c.wheel_spin_inertia = ROBOT["wheel_inertia"]
     c.wheel_damping = ROBOT["wheel_damping"]
-    c.friction = float(terrain.get("staticFriction", 0.85))       # train_*.py:66-67
+    # wheel-ground friction: the knob the scripts turn is sim.default_physics_material.static_friction
+    # (train_*.py:66-67, 88-89); terrain.staticFriction (KAMMA.py:51) belongs to the commented-out
+    # terrain mesh. The ground plane's own material and PhysX's combine mode are third-party and
+    # not visible here (docs/SPEC.md section 3: physics parity unpinned).
+    mat = sim.get("default_physics_material", {})
+    c.friction = float(mat["static_friction"]) if "static_friction" in mat else float(terrain.get("staticFriction", 0.85))
     c.baumgarte = ROBOT["baumgarte"]
     physx = sim.get("physx", {})
     c.max_depenetration_velocity = float(physx.get("max_depenetration_velocity", 100.0))  # KAMMA.py:105

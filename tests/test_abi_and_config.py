@@ -118,7 +118,7 @@ def test_task_cfg_surface_and_variants():
         build_config(variant="KAMMA", not_a_field=1)
     # patched keys flow through (what train_*.py:63-91 do)
     cfg["task"]["env"]["control"]["stiffness"] = 0.05
-    cfg["task"]["env"]["terrain"]["staticFriction"] = 0.6
+    cfg["task"]["sim"]["default_physics_material"]["static_friction"] = 0.6   # the key the train scripts patch (:88)
     cfg["task"]["env"]["learn"]["episodeLength_s"] = 5.0
     p = build_config(cfg, variant="KAMMA", num_envs=1)
     assert p.Kp == np.float32(0.05) and p.friction == np.float32(0.6) and p.max_episode_length == 50
