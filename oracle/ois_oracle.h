@@ -17,8 +17,15 @@
  *     anywhere in the reference): PARITY UNPINNED. The model is defined by docs/SPEC.md §3;
  *     parity is oracle <-> HIP kernel only.
  *   - RNG: Philox4x32-10 (Salmon et al., SC'11; Random123 v1.14 known-answer vectors are
- *     checked in tests/test_oracle_rng.py). The reference uses torch's global generator,
+ *     checked in tests/test_oracle_rng_physics.py). The reference uses torch's global generator,
  *     which cannot be reproduced counter-for-counter; draw ORDER follows KAMMA.py.
+ *   - either side of the step, also reference-followed and pinned the same way (torch
+ *     transcriptions, bit-exact): orc_gae (src/my_agents/ppo.py:345-358, ppoc.py:325-336 ->
+ *     refmath_gae.npz), orc_get_heights (KAMMA.py:872-899 -> refmath_heights.npz); the
+ *     transition-memory rows follow train_kaddpg_4d_nofifo_random_RLIL.py:105-206 and
+ *     base_KA_DDPG.py:205-224 (no reference vectors: semantics checked by tests/test_replay_memory.py).
+ *   - the wheel contact on the height field and the terrain curriculum (docs/SPEC.md §3.8) are
+ *     build-defined like the rest of the physics: PARITY UNPINNED.
  *
  * The config struct is the product ABI's (include/ois.h) so that one dict drives both.
  */
