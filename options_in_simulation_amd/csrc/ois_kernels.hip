@@ -6,7 +6,8 @@
 // One launch = one (or k) policy step(s) for all arenas: controller -> action mixing ->
 // torque clip -> 20 contact-solver substeps -> termination -> reward -> auto-reset ->
 // observation -> forward-speed projection, state in registers throughout.
-// step_kernel<LPA, PK, TER, NIT>: LPA lanes per arena (1 = a lane owns an arena, 2 = a lane pair
+// step_body<LPA, PK, TER, NIT> behind two kernel shells (step_kernel on the plane, step_kernel_terrain
+// on a height field): LPA lanes per arena (1 = a lane owns an arena, 2 = a lane pair
 // shares one), PK packed fp32 over wheel pairs (ois_physics_pk.h), TER wheel contact on a height
 // field, NIT solver iterations unrolled at compile time (0 = run-time count). Also here:
 // reset / params / episode-info / stats / height-scan kernels; ois_gae.hip holds the GAE scan.
@@ -29,9 +30,6 @@ namespace {
 #define OIS_BLOCK 64  // threads per workgroup of the step / reset kernels (one wave)
 #endif
 constexpr int kBlock = OIS_BLOCK;
-#ifndef OIS_STEP_BOUNDS
-#define OIS_STEP_BOUNDS __launch_bounds__(kBlock)
-#endif
 
 // ------------------------------------------------------------------ load / store ------
 OIS_DEV void unpack(const float4 t, float* d) { d[0] = t.x; d[1] = t.y; d[2] = t.z; d[3] = t.w; }
@@ -94,9 +92,8 @@ OIS_DEV void store_arena(const DevConsts& K, const DevBuffers& B, int i, int h, 
 
 // ------------------------------------------------------------------ the step kernel ---
 template <int LPA, bool PK, bool TER, int NIT>
-__global__ OIS_STEP_BOUNDS void step_kernel(DevConsts K, DevBuffers B, const float* __restrict__ actions,
-                                                      float* __restrict__ reward_sum, int N, int ksteps, int policy,
-                                                      int rp_head) {
+OIS_DEV void step_body(const DevConsts& K, const DevBuffers& B, const float* __restrict__ actions,
+                       float* __restrict__ reward_sum, int N, int ksteps, int policy, int rp_head) {
   constexpr int W = 4 / LPA;
   const int tid = blockIdx.x * kBlock + threadIdx.x;
   const int lane = threadIdx.x & 63;
@@ -377,6 +374,28 @@ __global__ OIS_STEP_BOUNDS void step_kernel(DevConsts K, DevBuffers B, const flo
       }
     }
   }
+}
+
+// Two kernel shells around the same body. The plane kernels are held to 256 registers
+// (amdgpu_waves_per_eu(2, 2)): left alone the compiler takes 256 VGPRs + ~30 AGPRs as spill
+// space and one wave fills a SIMD; held to 256 it spills ~24 registers of cold per-step state to
+// scratch instead, two waves fit, and every size gains (measured per policy step, packed: 30.3 ->
+// 29.6 us at 65 536 arenas, 60.9 -> 56.3 at 131 072, 241 -> 219 at 524 288; scalar 92.9 -> 65.8
+// at 131 072). The terrain kernels lose 2-4 % under the same limit (59-110 spills) and keep the
+// default. OIS_STEP_BOUNDS overrides the plane kernels' bounds for experiments.
+#ifndef OIS_STEP_BOUNDS
+#define OIS_STEP_BOUNDS __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(2, 2)))
+#endif
+template <int LPA, bool PK, int NIT>
+__global__ OIS_STEP_BOUNDS void step_kernel(DevConsts K, DevBuffers B, const float* __restrict__ actions,
+                                            float* __restrict__ reward_sum, int N, int ksteps, int policy, int rp_head) {
+  step_body<LPA, PK, false, NIT>(K, B, actions, reward_sum, N, ksteps, policy, rp_head);
+}
+template <bool PK, int NIT>
+__global__ __launch_bounds__(kBlock) void step_kernel_terrain(DevConsts K, DevBuffers B, const float* __restrict__ actions,
+                                                              float* __restrict__ reward_sum, int N, int ksteps, int policy,
+                                                              int rp_head) {
+  step_body<1, PK, true, NIT>(K, B, actions, reward_sum, N, ksteps, policy, rp_head);
 }
 
 // ------------------------------------------------------------------ get_heights -------
@@ -921,19 +940,19 @@ int ois_reset(ois_env* e, uint64_t seed, void* stream) {
 
 static int launch_steps(ois_env* e, int k, int policy, const float* actions, float* reward_sum, void* stream) {
   HIP_TRY(hipSetDevice(e->device));
-#define OIS_LAUNCH(LPA_, PK_, TER_, NIT_)                                                                          \
-  hipLaunchKernelGGL((step_kernel<LPA_, PK_, TER_, NIT_>), dim3((LPA_ * e->N + kBlock - 1) / kBlock), dim3(kBlock), 0, \
-                     (hipStream_t)stream, e->K, e->B, actions, reward_sum, e->N, k, policy, e->rp_head)
+#define OIS_LAUNCH(KERNEL_, LPA_)                                                                                  \
+  hipLaunchKernelGGL((KERNEL_), dim3((LPA_ * e->N + kBlock - 1) / kBlock), dim3(kBlock), 0, (hipStream_t)stream, e->K, \
+                     e->B, actions, reward_sum, e->N, k, policy, e->rp_head)
   // instantiations: lanes per arena (2 = experiment), packed wheel pairs, height-field terrain
   // (ois_terrain_attach refuses LPA = 2), solver iterations unrolled (the default 4) or run-time
   const bool it4 = e->K.iters == 4;
-  if (e->lpa == 2) OIS_LAUNCH(2, false, false, 0);
+  if (e->lpa == 2) OIS_LAUNCH((step_kernel<2, false, 0>), 2);
   else if (e->B.ter.on) {
-    if (e->packed) { if (it4) OIS_LAUNCH(1, true, true, 4); else OIS_LAUNCH(1, true, true, 0); }
-    else           { if (it4) OIS_LAUNCH(1, false, true, 4); else OIS_LAUNCH(1, false, true, 0); }
+    if (e->packed) { if (it4) OIS_LAUNCH((step_kernel_terrain<true, 4>), 1); else OIS_LAUNCH((step_kernel_terrain<true, 0>), 1); }
+    else           { if (it4) OIS_LAUNCH((step_kernel_terrain<false, 4>), 1); else OIS_LAUNCH((step_kernel_terrain<false, 0>), 1); }
   } else {
-    if (e->packed) { if (it4) OIS_LAUNCH(1, true, false, 4); else OIS_LAUNCH(1, true, false, 0); }
-    else           { if (it4) OIS_LAUNCH(1, false, false, 4); else OIS_LAUNCH(1, false, false, 0); }
+    if (e->packed) { if (it4) OIS_LAUNCH((step_kernel<1, true, 4>), 1); else OIS_LAUNCH((step_kernel<1, true, 0>), 1); }
+    else           { if (it4) OIS_LAUNCH((step_kernel<1, false, 4>), 1); else OIS_LAUNCH((step_kernel<1, false, 0>), 1); }
   }
 #undef OIS_LAUNCH
   HIP_TRY(hipGetLastError());
