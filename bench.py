@@ -237,7 +237,7 @@ def main():
                                          "~50 % of the vector peak with packed fp32"},
                          "note": "HBM is not the limiter: the kernel is fp32-VALU issue bound (20 substeps x 4-iteration "
                                  "contact solve = 14.6k VALU instructions per env-step, 469 of every 729 packed; one wave "
-                                 "per SIMD at any arena count because the kernel needs ~256 VGPRs); see roofline.valu and "
+                                 "per SIMD at 65 536 arenas: 1024 waves on 1024 SIMDs); see roofline.valu and "
                                  "DESIGN.md section 4"},
             "env_only_env_steps_per_s": N / (kernel_ms * 1e-3),
         }

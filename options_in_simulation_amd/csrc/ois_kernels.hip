@@ -879,10 +879,10 @@ int ois_create(const ois_config* cfg, int device, void* workspace_device, size_t
     // tests; no terrain, no unrolled-iteration variant).
     const char* w = getenv("OIS_LANES_PER_ARENA");
     e->lpa = (w && w[0] == '2') ? 2 : 1;
-    // Packed fp32 over wheel pairs is the default at every size: both step kernels need ~256
-    // VGPRs, so a SIMD holds one wave of either and a lone wave issues a v_pk_fma_f32 as fast as
-    // a v_fma_f32 (measured per policy step, fused: 30.5 vs 46.7 us at 65 536 arenas, 60.8 vs
-    // 92.7 us at 131 072, 242 vs 368 us at 524 288). OIS_PACKED=0 selects the scalar kernel.
+    // Packed fp32 over wheel pairs is the default at every size: half the VALU instructions per
+    // substep (729 vs ~1 490), and the advantage holds with one wave per SIMD (30.5 vs 46.7 us
+    // per policy step at 65 536 arenas) as with two (57 vs 66 us at 131 072, 220 vs ~260 us at
+    // 524 288). OIS_PACKED=0 selects the scalar kernel.
     const char* pk = getenv("OIS_PACKED");
     e->packed = pk ? (pk[0] == '1') : true;
   }

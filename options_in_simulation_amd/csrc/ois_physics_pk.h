@@ -3,12 +3,13 @@
 // Same operations in the same order as substep<EXACT, 1> (ois_physics.h), so the results are
 // bit-identical; only the instruction selection differs: the wheels of an axle — (fl, fr) and (rl, rr) — ride
 // in the two halves of float2 operands, which hipcc lowers to v_pk_fma_f32 / v_pk_mul_f32 /
-// v_pk_add_f32 (IEEE per element). Why it pays: the step kernels need ~256 VGPRs, so a SIMD
-// holds ONE wave of them at any arena count, and a lone wave issues one VALU instruction per
-// ~4-5 cycles whether it is a v_fma_f32 or a v_pk_fma_f32 (tools/valu_rate.hip: 2.0-2.4 ns vs
-// 2.5 ns), so a packed instruction does two wheels for the price of one: 729 instead of ~1 490
-// VALU instructions per substep. (In the earlier 4-lanes-per-arena layout, with 4 waves per
-// SIMD, packed ran at half rate and bought nothing: DESIGN.md §4.)
+// v_pk_add_f32 (IEEE per element). Why it pays: at 65 536 arenas there is one wave per SIMD, and
+// a lone wave issues one VALU instruction per ~4-5 cycles whether it is a v_fma_f32 or a
+// v_pk_fma_f32 (tools/valu_rate.hip: 2.0-2.4 ns vs 2.5 ns), so a packed instruction does two
+// wheels for the price of one: 729 instead of ~1 490 VALU instructions per substep. With two
+// waves per SIMD (more arenas) the gap narrows but stays: 57 vs 66 us per step at 131 072.
+// (In the earlier 4-lanes-per-arena layout, with 4 waves per SIMD, packed ran at half rate and
+// bought nothing: DESIGN.md section 4.)
 #pragma once
 #include "ois_physics.h"
 
