@@ -31,7 +31,7 @@ res["quad_cycles_per_valu_instr"] = res["SQ_ACTIVE_INST_VALU"] / res["SQ_INSTS_V
 res["valu_active_fraction_of_wave_life"] = res["SQ_ACTIVE_INST_VALU"] / res["SQ_WAVE_CYCLES"]
 res["clock_GHz_est"] = 4.0 * res["SQ_WAVE_CYCLES"] / max(1.0, res["SQ_WAVES"]) / res["dispatch_ns"]
 res["note"] = ("SQ_* cycle counters are in quad-cycles (4 shader cycles); fused rollout of 20 policy steps per dispatch, "
-               "65536 arenas, step_kernel<1,true,false,4>; one --pmc pass per counter")
+               "65536 arenas, step_kernel<1,true,4>; one --pmc pass per counter")
 json.dump(res, open(f"{OUT}/{R}_pmc_sq.json", "w"), indent=1)
 print(json.dumps(res))
 PY
