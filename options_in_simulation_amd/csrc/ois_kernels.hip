@@ -376,20 +376,29 @@ OIS_DEV void step_body(const DevConsts& K, const DevBuffers& B, const float* __r
   }
 }
 
-// Two kernel shells around the same body. The plane kernels are held to 256 registers
-// (amdgpu_waves_per_eu(2, 2)): left alone the compiler takes 256 VGPRs + ~30 AGPRs as spill
-// space and one wave fills a SIMD; held to 256 it spills ~24 registers of cold per-step state to
-// scratch instead, two waves fit, and every size gains (measured per policy step, packed: 30.3 ->
-// 29.6 us at 65 536 arenas, 60.9 -> 56.3 at 131 072, 241 -> 219 at 524 288; scalar 92.9 -> 65.8
-// at 131 072). The terrain kernels lose 2-4 % under the same limit (59-110 spills) and keep the
-// default. OIS_STEP_BOUNDS overrides the plane kernels' bounds for experiments.
-#ifndef OIS_STEP_BOUNDS
-#define OIS_STEP_BOUNDS __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(2, 2)))
-#endif
+// Kernel shells around the same body. The plane kernel exists twice:
+//  * step_kernel     — the compiler's own register budget: 256 VGPRs + ~30 AGPRs of spill space,
+//    no scratch; one wave fills a SIMD. Launched while the arenas give at most one wave per SIMD
+//    anyway (N <= 65 536 on the 1024 SIMDs of an MI355X).
+//  * step_kernel_w2  — held to 256 registers (amdgpu_waves_per_eu(2, 2)): ~24 registers of cold
+//    per-step state go to scratch instead and two waves fit on a SIMD. Launched above that size
+//    (measured per policy step, packed: 60.9 -> 56.3 us at 131 072 arenas, 241 -> 219 at 524 288;
+//    scalar 92.9 -> 65.8 at 131 072).
+// At 65 536 arenas the two are equal in an env-only loop (30.3 vs 29.6 us per fused step), but
+// behind the actor's GEMMs the scratch traffic of the second is cold: 67.7 vs 44.5 us per launch
+// under rocprofv3 (profiles/r1_waves_ab.txt), hence the size rule. OIS_STEP_WAVES=1|2 overrides it.
+// The terrain kernels lose 2-4 % under the limit (59-110 spills) and always keep the default.
 template <int LPA, bool PK, int NIT>
-__global__ OIS_STEP_BOUNDS void step_kernel(DevConsts K, DevBuffers B, const float* __restrict__ actions,
-                                            float* __restrict__ reward_sum, int N, int ksteps, int policy, int rp_head) {
+__global__ __launch_bounds__(kBlock) void step_kernel(DevConsts K, DevBuffers B, const float* __restrict__ actions,
+                                                      float* __restrict__ reward_sum, int N, int ksteps, int policy,
+                                                      int rp_head) {
   step_body<LPA, PK, false, NIT>(K, B, actions, reward_sum, N, ksteps, policy, rp_head);
+}
+template <bool PK, int NIT>
+__global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(2, 2)))
+void step_kernel_w2(DevConsts K, DevBuffers B, const float* __restrict__ actions, float* __restrict__ reward_sum, int N,
+                    int ksteps, int policy, int rp_head) {
+  step_body<1, PK, false, NIT>(K, B, actions, reward_sum, N, ksteps, policy, rp_head);
 }
 template <bool PK, int NIT>
 __global__ __launch_bounds__(kBlock) void step_kernel_terrain(DevConsts K, DevBuffers B, const float* __restrict__ actions,
@@ -769,6 +778,7 @@ struct ois_env {
   int N, device, grid;
   int lpa;  // lanes per arena of the step kernel (1 | 2)
   bool packed;  // LPA = 1 only: per-wheel math on v_pk_*_f32 (ois_physics_pk.h)
+  bool waves2;  // plane kernel shell held to 256 registers (step_kernel_w2), chosen by arena count
   uint64_t seed;  // seed of the last ois_reset (RNG key of the episode stream)
   bool reset_done;
   double steps_done;
@@ -885,6 +895,13 @@ int ois_create(const ois_config* cfg, int device, void* workspace_device, size_t
     // 524 288). OIS_PACKED=0 selects the scalar kernel.
     const char* pk = getenv("OIS_PACKED");
     e->packed = pk ? (pk[0] == '1') : true;
+    // Plane kernel shell (see step_kernel / step_kernel_w2): the 256-register one only where a
+    // second wave per SIMD exists to be had, i.e. more arenas than one wave per SIMD covers.
+    int simds = 1024;
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, device) == hipSuccess && prop.multiProcessorCount > 0) simds = 4 * prop.multiProcessorCount;
+    const char* wv = getenv("OIS_STEP_WAVES");
+    e->waves2 = wv ? (wv[0] == '2') : ((long)e->N > (long)simds * kBlock);
   }
   e->seed = cfg->seed;
   e->reset_done = false;
@@ -950,6 +967,9 @@ static int launch_steps(ois_env* e, int k, int policy, const float* actions, flo
   else if (e->B.ter.on) {
     if (e->packed) { if (it4) OIS_LAUNCH((step_kernel_terrain<true, 4>), 1); else OIS_LAUNCH((step_kernel_terrain<true, 0>), 1); }
     else           { if (it4) OIS_LAUNCH((step_kernel_terrain<false, 4>), 1); else OIS_LAUNCH((step_kernel_terrain<false, 0>), 1); }
+  } else if (e->waves2) {
+    if (e->packed) { if (it4) OIS_LAUNCH((step_kernel_w2<true, 4>), 1); else OIS_LAUNCH((step_kernel_w2<true, 0>), 1); }
+    else           { if (it4) OIS_LAUNCH((step_kernel_w2<false, 4>), 1); else OIS_LAUNCH((step_kernel_w2<false, 0>), 1); }
   } else {
     if (e->packed) { if (it4) OIS_LAUNCH((step_kernel<1, true, 4>), 1); else OIS_LAUNCH((step_kernel<1, true, 0>), 1); }
     else           { if (it4) OIS_LAUNCH((step_kernel<1, false, 4>), 1); else OIS_LAUNCH((step_kernel<1, false, 0>), 1); }

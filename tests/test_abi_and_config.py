@@ -136,8 +136,8 @@ def test_no_kernel_reads_the_dispatch_packet(tmp_path):
     compiler promoted a run-time-indexed private array to LDS and linearises the thread id from
     the packet's workgroup size) pays ~13 us per launch on MI355X (tools/lds_launch_probe.hip,
     DESIGN.md section 4). No kernel of the library may enable the dispatch-pointer SGPRs; scratch is
-    only allowed (<= 256 B per lane) in the plane step kernels, which are deliberately held to 256
-    registers so that two waves fit a SIMD."""
+    only allowed (<= 256 B per lane) in step_kernel_w2, the plane shell deliberately held to 256
+    registers so that two waves fit a SIMD (launched only above one wave per SIMD of arenas)."""
     import shutil
     import subprocess
     hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
@@ -155,8 +155,8 @@ def test_no_kernel_reads_the_dispatch_packet(tmp_path):
         for name, body in kernels:
             assert ".amdhsa_user_sgpr_dispatch_ptr 0" in body, f"{name} reads the dispatch packet"
             scratch = int(re.search(r"\.amdhsa_private_segment_fixed_size (\d+)", body).group(1))
-            plane_step = "step_kernelILi1" in name  # held to 256 registers on purpose: cold per-step state spills
-            assert scratch <= (256 if plane_step else 0), f"{name} uses {scratch} B of scratch per lane"
+            held = "step_kernel_w2" in name  # held to 256 registers on purpose: cold per-step state spills
+            assert scratch <= (256 if held else 0), f"{name} uses {scratch} B of scratch per lane"
             if "step_kernel" in name:
                 assert ".amdhsa_group_segment_fixed_size 0" in body, f"{name}: a private array was promoted to LDS"
 

@@ -161,11 +161,13 @@ def test_error_paths():
         NativeEnv(bad, "cuda:0")
 
 
-@pytest.mark.parametrize("env_vars", [{"OIS_PACKED": "0"}, {"OIS_PACKED": "1"}, {"OIS_LANES_PER_ARENA": "2"}],
-                         ids=["scalar", "packed", "lane-pair"])
+@pytest.mark.parametrize("env_vars", [{"OIS_PACKED": "0"}, {"OIS_PACKED": "1"}, {"OIS_LANES_PER_ARENA": "2"},
+                                      {"OIS_PACKED": "0", "OIS_STEP_WAVES": "2"}, {"OIS_PACKED": "1", "OIS_STEP_WAVES": "2"}],
+                         ids=["scalar", "packed", "lane-pair", "scalar-256reg", "packed-256reg"])
 def test_every_kernel_instantiation_is_bit_identical_to_the_oracle(env_vars, monkeypatch):
-    """step_kernel<1,false>, <1,true> and <2,false> share one arithmetic (docs/SPEC.md); the
-    library picks by size, the environment variables (read at ois_create) force each one."""
+    """step_kernel<1,false>, <1,true>, <2,false> and the 256-register shells step_kernel_w2 (the
+    default above 65 536 arenas) share one arithmetic (docs/SPEC.md); the library picks by size,
+    the environment variables (read at ois_create) force each one."""
     for k, v in env_vars.items():
         monkeypatch.setenv(k, v)
     N = 300
@@ -211,7 +213,8 @@ def test_non_finite_outcome_guard_parity(env_vars, monkeypatch):
     compare(dev, orc, f"{env_vars} after the guard", exact_float=True)
 
 
-@pytest.mark.parametrize("env_vars", [{"OIS_PACKED": "0"}, {"OIS_PACKED": "1"}], ids=["scalar", "packed"])
+@pytest.mark.parametrize("env_vars", [{"OIS_PACKED": "0"}, {"OIS_PACKED": "1"}, {"OIS_PACKED": "1", "OIS_STEP_WAVES": "2"}],
+                         ids=["scalar", "packed", "packed-256reg"])
 @pytest.mark.parametrize("terrain", [False, True], ids=["plane", "field"])
 def test_runtime_iteration_count_instantiations(env_vars, terrain, monkeypatch):
     """solver_iterations != 4 selects the NIT = 0 kernels (run-time loop instead of the unrolled
