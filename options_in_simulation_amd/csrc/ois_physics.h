@@ -32,6 +32,22 @@ struct PhysT {
   float fwx[4], fwy[4], fh[4], fr00, fr10, fr01, fr11;
 };
 
+// 1.0f / d, correctly rounded, for finite d with 2^-40 <= |d| < 2^40: the refinement chain of the
+// compiler's own fdiv expansion (v_rcp_f32 + 6 fma) without its v_div_scale / v_div_fmas /
+// v_div_fixup, which only act at the exponent extremes: 7 instructions instead of 12, and the
+// chain packs (ois_physics_pk.h). Bit-identical to the IEEE quotient the oracle computes on every
+// float of that range (tools/exact_rcp_check.hip: 671 M values, exhaustive; tests/test_gpu_parity.py).
+// The contact-row diagonals it is used on are >= 1 / (4 m) > 0 for any finite geometry; NaN stays NaN.
+OIS_DEV float exact_rcp(float d) {
+  const float r0 = __builtin_amdgcn_rcpf(d);
+  const float e = __builtin_fmaf(-d, r0, 1.0f);
+  const float r1 = __builtin_fmaf(e, r0, r0);
+  const float g = __builtin_fmaf(-d, r1, 1.0f);
+  const float q = __builtin_fmaf(g, r1, r1);
+  const float h = __builtin_fmaf(-d, q, 1.0f);
+  return __builtin_fmaf(h, r1, q);
+}
+
 // One Newton step from the previous substep's value: mul/fma only, bit-reproducible.
 OIS_DEV float newton_rcp(float m, float k) {  // m ~ 1/k -> m (2 - k m)
   const float e = __builtin_fmaf(-k, m, 1.0f);
@@ -173,9 +189,9 @@ OIS_DEV void substep(const DevConsts& K, const DevTerrain& T, int wheel0, PhysT<
     const float kn = __builtin_fmaf(an[k][2], Jan[k][2], __builtin_fmaf(an[k][1], Jan[k][1], __builtin_fmaf(an[k][0], Jan[k][0], K.im4)));
     const float k1 = __builtin_fmaf(a1[k][2], Ja1[k][2], __builtin_fmaf(a1[k][1], Ja1[k][1], __builtin_fmaf(a1[k][0], Ja1[k][0], K.im4))) + K.rw2_over_Is;
     const float k2 = __builtin_fmaf(a2[k][2], Ja2[k][2], __builtin_fmaf(a2[k][1], Ja2[k][1], __builtin_fmaf(a2[k][0], Ja2[k][0], K.im4)));
-    mn[k] = REX ? 1.0f / kn : newton_rcp(mn[k], kn);
-    m1[k] = REX ? 1.0f / k1 : newton_rcp(m1[k], k1);
-    m2[k] = REX ? 1.0f / k2 : newton_rcp(m2[k], k2);
+    mn[k] = REX ? exact_rcp(kn) : newton_rcp(mn[k], kn);
+    m1[k] = REX ? exact_rcp(k1) : newton_rcp(m1[k], k1);
+    m2[k] = REX ? exact_rcp(k2) : newton_rcp(m2[k], k2);
   }
   const float vnx = K.im4 * nb[0], vny = K.im4 * nb[1], vnz = K.im4 * nb[2];
   const float v1x = K.im4 * t1x, v1z = K.im4 * t1z;

@@ -38,6 +38,16 @@ OIS_DEV f2 clamp2(f2 x, f2 lim) {
   r.y = __builtin_amdgcn_fmed3f(x.y, -lim.y, lim.y);
   return r;
 }
+OIS_DEV f2 exact_rcp2(f2 d) {  // exact_rcp (ois_physics.h) on both halves: 2 v_rcp_f32 + 6 v_pk_fma_f32
+  f2 r0;
+  r0.x = __builtin_amdgcn_rcpf(d.x); r0.y = __builtin_amdgcn_rcpf(d.y);
+  const f2 e = fma2(-d, r0, 1.0f);
+  const f2 r1 = fma2(e, r0, r0);
+  const f2 g = fma2(-d, r1, 1.0f);
+  const f2 q = fma2(g, r1, r1);
+  const f2 h = fma2(-d, q, 1.0f);
+  return fma2(h, r1, q);
+}
 OIS_DEV f2 newton_rcp2(f2 m, f2 k) {
   const f2 e = fma2(-k, m, 1.0f);
   return fma2(m, e, m);
@@ -119,9 +129,7 @@ OIS_DEV void substep_pk(const DevConsts& K, const DevTerrain& T, PhysT<1>& S) {
     const f2 k1 = fma2(a1[j][2], Ja1[j][2], fma2(a1[j][1], Ja1[j][1], fma2(a1[j][0], Ja1[j][0], K.im4))) + K.rw2_over_Is;
     const f2 k2 = fma2(a2[j][2], Ja2[j][2], fma2(a2[j][1], Ja2[j][1], fma2(a2[j][0], Ja2[j][0], K.im4)));
     if (REX) {
-      mn[j].x = 1.0f / kn.x; mn[j].y = 1.0f / kn.y;
-      m1[j].x = 1.0f / k1.x; m1[j].y = 1.0f / k1.y;
-      m2[j].x = 1.0f / k2.x; m2[j].y = 1.0f / k2.y;
+      mn[j] = exact_rcp2(kn); m1[j] = exact_rcp2(k1); m2[j] = exact_rcp2(k2);
     } else {
       mn[j] = newton_rcp2(mn[j], kn);
       m1[j] = newton_rcp2(m1[j], k1);

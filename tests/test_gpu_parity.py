@@ -5,6 +5,7 @@ counters. The kernel and the oracle spell the same float32 operation order (expl
 -ffp-contract=off), so most checks here are in fact exact; where a test says rtol it is the
 north_star's 1e-5.
 """
+import os
 import numpy as np
 import pytest
 
@@ -267,3 +268,21 @@ def test_second_reset_with_another_seed():
     compare(dev, orc, "steps after the second reset", exact_float=True)
     sd, so = dev.stats(), orc.stats()
     assert sd.episodes == so.episodes == 0 and sd.steps == so.steps == 5 * N
+
+
+def test_lean_exact_reciprocal_is_the_ieee_quotient(tmp_path):
+    """exact_rcp / exact_rcp2 (ois_physics.h, ois_physics_pk.h): v_rcp_f32 + the refinement chain
+    of the compiler's fdiv expansion, without its exponent-extreme handling. The oracle computes
+    1.0f / k; the kernels must give the same bits: exhaustive over every float in [2^-40, 2^40)
+    and the negatives (tools/exact_rcp_check.hip, scalar and packed forms)."""
+    import shutil
+    import subprocess
+    hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    if not os.path.exists(hipcc):
+        pytest.skip("hipcc not available")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = str(tmp_path / "rcpchk")
+    subprocess.run([hipcc, "-O3", "--offload-arch=gfx950", "-ffp-contract=off", "-w", "-o", exe,
+                    os.path.join(root, "tools", "exact_rcp_check.hip")], check=True, capture_output=True)
+    res = subprocess.run([exe], capture_output=True, text=True, timeout=300)
+    assert res.returncode == 0 and " 0 mismatches" in res.stdout, res.stdout + res.stderr
