@@ -31,10 +31,10 @@ ALGO_BYTES_PER_ENV_STEP = 352.0
 HBM_PEAK_GBS = 8000.0             # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
 # secondary ceiling (SURVEY.md §8(d) asks to say which one binds): fp32 vector peak, and the
 # arithmetic one env-step performs, counted from the ISA of the packed step kernel's substep loop
-# (729 VALU instructions = 313 v_pk_fma + 156 v_pk_add/mul + scalar ops = 1 790 FLOP per
+# (691 VALU instructions = 217 v_pk_fma + 143 v_pk_add/mul + 331 scalar ops = 1 563 FLOP per
 # arena-substep; x 20 substeps; pre/post-physics not counted)
 FP32_VECTOR_PEAK_TFLOPS = 157.3   # MI355X_MICROARCH.md
-FLOP_PER_ENV_STEP = 20 * 1790.0
+FLOP_PER_ENV_STEP = 20 * 1563.0
 ARENAS_PER_GPU = 65536
 
 
@@ -233,11 +233,11 @@ def main():
                          "valu": {"achieved": FLOP_PER_ENV_STEP * N / (kernel_ms * 1e-3) / 1e12, "peak": FP32_VECTOR_PEAK_TFLOPS,
                                   "unit": "TFLOP/s", "frac": FLOP_PER_ENV_STEP * N / (kernel_ms * 1e-3) / 1e12 / FP32_VECTOR_PEAK_TFLOPS,
                                   "flop_per_env_step": FLOP_PER_ENV_STEP,
-                                  "how": "ISA instruction mix of the substep loop x 20 substeps (20 substeps x 1 790 FLOP); "
+                                  "how": "ISA instruction mix of the substep loop x 20 substeps (20 substeps x 1 563 FLOP); "
                                          "one wave per SIMD issues one VALU instruction per ~4-5 cycles, i.e. at most "
                                          "~50 % of the vector peak with packed fp32"},
                          "note": "HBM is not the limiter: the kernel is fp32-VALU issue bound (20 substeps x 4-iteration "
-                                 "contact solve = 14.6k VALU instructions per env-step, 469 of every 729 packed; one wave "
+                                 "contact solve = 13.8k VALU instructions per env-step, 360 of every 691 packed; one wave "
                                  "per SIMD at 65 536 arenas: 1024 waves on 1024 SIMDs); see roofline.valu and "
                                  "DESIGN.md section 4"},
             "env_only_env_steps_per_s": N / (kernel_ms * 1e-3),

@@ -727,6 +727,7 @@ void derive(const ois_config* c, DevConsts* K) {
   K->gdt = c->gravity * c->sim_dt;
   K->half_dt = 0.5f * c->sim_dt;
   K->im4 = 4.0f / c->body_mass;
+  K->imq = 0.25f * K->im4;  // exact: the inverse mass seen by the average over the 4 contacts
   K->J4x = 4.0f / c->body_inertia[0];
   K->J4y = 4.0f / c->body_inertia[1];
   K->J4z = 4.0f / c->body_inertia[2];

@@ -103,7 +103,7 @@ OIS_DEV void terrain_plane(const DevConsts& K, const PhysT<LPA>& S, float* n, fl
   const float ny = __builtin_fmaf(g1, S.fr01, -(S.fr00 * g2));
   const float nz = __builtin_fmaf(S.fr00, S.fr11, -(S.fr10 * S.fr01));
   const float nn = fmaxf(__builtin_fmaf(nz, nz, __builtin_fmaf(ny, ny, nx * nx)), 1e-12f);
-  float inv = 1.0f / sqrtf(nn);
+  float inv = exact_rcp(sqrtf(nn));  // 1e-12 <= nn: inside exact_rcp's range
   if (nz < 0.0f) inv = -inv;  // rolled over (body z points down): the ground's normal still points up
   n[0] = nx * inv; n[1] = ny * inv; n[2] = nz * inv;
 #pragma unroll
@@ -155,7 +155,7 @@ OIS_DEV void substep(const DevConsts& K, const DevTerrain& T, int wheel0, PhysT<
   float s2 = __builtin_fmaf(nb[2], nb[2], nb[0] * nb[0]);
   s2 = fmaxf(s2, 1e-12f);
   constexpr bool REX = EXACT || TER;  // on a height field the geometry may jump: exact reciprocals every substep
-  const float inv_s = REX ? 1.0f / sqrtf(s2) : newton_rsqrt(S.inv_s, s2);
+  const float inv_s = REX ? exact_rcp(sqrtf(s2)) : newton_rsqrt(S.inv_s, s2);  // s2 >= 1e-12
   S.inv_s = inv_s;
   const float dx = -(nb[0] * inv_s), dz = -(nb[2] * inv_s);
   const float t1x = -dz, t1z = dx;
@@ -193,76 +193,77 @@ OIS_DEV void substep(const DevConsts& K, const DevTerrain& T, int wheel0, PhysT<
     m1[k] = REX ? exact_rcp(k1) : newton_rcp(m1[k], k1);
     m2[k] = REX ? exact_rcp(k2) : newton_rcp(m2[k], k2);
   }
-  const float vnx = K.im4 * nb[0], vny = K.im4 * nb[1], vnz = K.im4 * nb[2];
-  const float v1x = K.im4 * t1x, v1z = K.im4 * t1z;
-  const float v2x = K.im4 * t2x, v2y = K.im4 * t2y, v2z = K.im4 * t2z;
-  float vx[W], vy[W], vz[W], ox[W], oy[W], oz[W];
+  // Chassis linear velocity: the contact frame (n, t1, t2) is orthonormal and the split inverse
+  // mass is a scalar, so an impulse along one row never changes the linear part of another row's
+  // velocity: no private copies of v_b; a row reads the shared v_b and the averaging pass adds
+  // (1/m) * frame * (sum of the pass's impulses over the 4 contacts) (docs/SPEC.md 3.5).
+  const float qnx = K.imq * nb[0], qny = K.imq * nb[1], qnz = K.imq * nb[2];
+  const float q1x = K.imq * t1x, q1z = K.imq * t1z;
+  const float q2x = K.imq * t2x, q2y = K.imq * t2y, q2z = K.imq * t2z;
+  float ox[W], oy[W], oz[W];
   // warm start: one mass-split averaging pass with the cached impulses
-  OIS_WH vx[k] = __builtin_fmaf(S.l2[k], v2x, __builtin_fmaf(S.l1[k], v1x, __builtin_fmaf(S.ln[k], vnx, vb[0])));
-  OIS_WH vy[k] = __builtin_fmaf(S.l2[k], v2y, __builtin_fmaf(S.ln[k], vny, vb[1]));
-  OIS_WH vz[k] = __builtin_fmaf(S.l2[k], v2z, __builtin_fmaf(S.l1[k], v1z, __builtin_fmaf(S.ln[k], vnz, vb[2])));
   OIS_WH ox[k] = __builtin_fmaf(S.l2[k], Ja2[k][0], __builtin_fmaf(S.l1[k], Ja1[k][0], __builtin_fmaf(S.ln[k], Jan[k][0], wb[0])));
   OIS_WH oy[k] = __builtin_fmaf(S.l2[k], Ja2[k][1], __builtin_fmaf(S.l1[k], Ja1[k][1], __builtin_fmaf(S.ln[k], Jan[k][1], wb[1])));
   OIS_WH oz[k] = __builtin_fmaf(S.l2[k], Ja2[k][2], __builtin_fmaf(S.l1[k], Ja1[k][2], __builtin_fmaf(S.ln[k], Jan[k][2], wb[2])));
   OIS_WH S.spin[k] = __builtin_fmaf(-K.rw_over_Is, S.l1[k], S.spin[k]);
-  vb[0] = average4<LPA>(vx); vb[1] = average4<LPA>(vy); vb[2] = average4<LPA>(vz);
+  {
+    const float Sn = sum_wheels<LPA>(S.ln), S1 = sum_wheels<LPA>(S.l1), S2 = sum_wheels<LPA>(S.l2);
+    vb[0] = __builtin_fmaf(S2, q2x, __builtin_fmaf(S1, q1x, __builtin_fmaf(Sn, qnx, vb[0])));
+    vb[1] = __builtin_fmaf(S2, q2y, __builtin_fmaf(Sn, qny, vb[1]));
+    vb[2] = __builtin_fmaf(S2, q2z, __builtin_fmaf(S1, q1z, __builtin_fmaf(Sn, qnz, vb[2])));
+  }
   wb[0] = average4<LPA>(ox); wb[1] = average4<LPA>(oy); wb[2] = average4<LPA>(oz);
   const int iters = NIT > 0 ? NIT : K.iters;
 #pragma unroll
   for (int it = 0; it < iters; ++it) {
-    float u[W], dl[W], nw[W], lim[W];
-    // normal row
+    float u[W], dl[W], nw[W], lim[W], dn[W], d1[W];
+    // linear part of the three row velocities, shared by the four contacts
     const float unv = __builtin_fmaf(nb[2], vb[2], __builtin_fmaf(nb[1], vb[1], nb[0] * vb[0]));
+    const float u1v = __builtin_fmaf(t1z, vb[2], t1x * vb[0]);
+    const float u2v = __builtin_fmaf(t2z, vb[2], __builtin_fmaf(t2y, vb[1], t2x * vb[0]));
+    // normal row
     OIS_WH u[k] = __builtin_fmaf(an[k][0], wb[0], unv);
     OIS_WH u[k] = __builtin_fmaf(an[k][1], wb[1], u[k]);
     OIS_WH u[k] = __builtin_fmaf(an[k][2], wb[2], u[k]);
     OIS_WH dl[k] = (b[k] - u[k]) * mn[k];
     OIS_WH nw[k] = fmaxf(S.ln[k] + dl[k], 0.0f);
-    OIS_WH dl[k] = nw[k] - S.ln[k];
+    OIS_WH dn[k] = nw[k] - S.ln[k];
     OIS_WH S.ln[k] = nw[k];
-    OIS_WH vx[k] = __builtin_fmaf(dl[k], vnx, vb[0]);
-    OIS_WH vz[k] = __builtin_fmaf(dl[k], vnz, vb[2]);
-    OIS_WH ox[k] = __builtin_fmaf(dl[k], Jan[k][0], wb[0]);
-    OIS_WH oy[k] = __builtin_fmaf(dl[k], Jan[k][1], wb[1]);
-    OIS_WH oz[k] = __builtin_fmaf(dl[k], Jan[k][2], wb[2]);
-    OIS_WH vy[k] = __builtin_fmaf(dl[k], vny, vb[1]);
+    OIS_WH ox[k] = __builtin_fmaf(dn[k], Jan[k][0], wb[0]);
+    OIS_WH oy[k] = __builtin_fmaf(dn[k], Jan[k][1], wb[1]);
+    OIS_WH oz[k] = __builtin_fmaf(dn[k], Jan[k][2], wb[2]);
     OIS_WH lim[k] = S.mu * S.ln[k];
     // longitudinal row (couples the wheel spin)
-    OIS_WH u[k] = t1x * vx[k];
-    OIS_WH u[k] = __builtin_fmaf(t1z, vz[k], u[k]);
-    OIS_WH u[k] = __builtin_fmaf(a1[k][0], ox[k], u[k]);
+    OIS_WH u[k] = __builtin_fmaf(a1[k][0], ox[k], u1v);
     OIS_WH u[k] = __builtin_fmaf(a1[k][1], oy[k], u[k]);
     OIS_WH u[k] = __builtin_fmaf(a1[k][2], oz[k], u[k]);
     OIS_WH u[k] = __builtin_fmaf(-K.rw, S.spin[k], u[k]);
     OIS_WH dl[k] = -(u[k] * m1[k]);
     OIS_WH nw[k] = fminf(fmaxf(S.l1[k] + dl[k], -lim[k]), lim[k]);
-    OIS_WH dl[k] = nw[k] - S.l1[k];
+    OIS_WH d1[k] = nw[k] - S.l1[k];
     OIS_WH S.l1[k] = nw[k];
-    OIS_WH vx[k] = __builtin_fmaf(dl[k], v1x, vx[k]);
-    OIS_WH vz[k] = __builtin_fmaf(dl[k], v1z, vz[k]);
-    OIS_WH ox[k] = __builtin_fmaf(dl[k], Ja1[k][0], ox[k]);
-    OIS_WH oy[k] = __builtin_fmaf(dl[k], Ja1[k][1], oy[k]);
-    OIS_WH oz[k] = __builtin_fmaf(dl[k], Ja1[k][2], oz[k]);
-    OIS_WH S.spin[k] = __builtin_fmaf(-K.rw_over_Is, dl[k], S.spin[k]);
+    OIS_WH ox[k] = __builtin_fmaf(d1[k], Ja1[k][0], ox[k]);
+    OIS_WH oy[k] = __builtin_fmaf(d1[k], Ja1[k][1], oy[k]);
+    OIS_WH oz[k] = __builtin_fmaf(d1[k], Ja1[k][2], oz[k]);
+    OIS_WH S.spin[k] = __builtin_fmaf(-K.rw_over_Is, d1[k], S.spin[k]);
     // lateral row
-    OIS_WH u[k] = t2x * vx[k];
-    OIS_WH u[k] = __builtin_fmaf(t2y, vy[k], u[k]);
-    OIS_WH u[k] = __builtin_fmaf(t2z, vz[k], u[k]);
-    OIS_WH u[k] = __builtin_fmaf(a2[k][0], ox[k], u[k]);
+    OIS_WH u[k] = __builtin_fmaf(a2[k][0], ox[k], u2v);
     OIS_WH u[k] = __builtin_fmaf(a2[k][1], oy[k], u[k]);
     OIS_WH u[k] = __builtin_fmaf(a2[k][2], oz[k], u[k]);
     OIS_WH dl[k] = -(u[k] * m2[k]);
     OIS_WH nw[k] = fminf(fmaxf(S.l2[k] + dl[k], -lim[k]), lim[k]);
     OIS_WH dl[k] = nw[k] - S.l2[k];
     OIS_WH S.l2[k] = nw[k];
-    OIS_WH vx[k] = __builtin_fmaf(dl[k], v2x, vx[k]);
-    OIS_WH vy[k] = __builtin_fmaf(dl[k], v2y, vy[k]);
-    OIS_WH vz[k] = __builtin_fmaf(dl[k], v2z, vz[k]);
     OIS_WH ox[k] = __builtin_fmaf(dl[k], Ja2[k][0], ox[k]);
     OIS_WH oy[k] = __builtin_fmaf(dl[k], Ja2[k][1], oy[k]);
     OIS_WH oz[k] = __builtin_fmaf(dl[k], Ja2[k][2], oz[k]);
     // mass-splitting average over the 4 contacts
-    vb[0] = average4<LPA>(vx); vb[1] = average4<LPA>(vy); vb[2] = average4<LPA>(vz);
+    {
+      const float Sn = sum_wheels<LPA>(dn), S1 = sum_wheels<LPA>(d1), S2 = sum_wheels<LPA>(dl);
+      vb[0] = __builtin_fmaf(S2, q2x, __builtin_fmaf(S1, q1x, __builtin_fmaf(Sn, qnx, vb[0])));
+      vb[1] = __builtin_fmaf(S2, q2y, __builtin_fmaf(Sn, qny, vb[1]));
+      vb[2] = __builtin_fmaf(S2, q2z, __builtin_fmaf(S1, q1z, __builtin_fmaf(Sn, qnz, vb[2])));
+    }
     wb[0] = average4<LPA>(ox); wb[1] = average4<LPA>(oy); wb[2] = average4<LPA>(oz);
   }
   // linear velocity back to the world frame, velocity caps (origin_v18.py:65-70), integrate

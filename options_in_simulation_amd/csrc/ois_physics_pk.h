@@ -91,7 +91,7 @@ OIS_DEV void substep_pk(const DevConsts& K, const DevTerrain& T, PhysT<1>& S) {
   float s2 = __builtin_fmaf(nb[2], nb[2], nb[0] * nb[0]);
   s2 = fmaxf(s2, 1e-12f);
   constexpr bool REX = EXACT || TER;
-  const float inv_s = REX ? 1.0f / sqrtf(s2) : newton_rsqrt(S.inv_s, s2);
+  const float inv_s = REX ? exact_rcp(sqrtf(s2)) : newton_rsqrt(S.inv_s, s2);  // s2 >= 1e-12
   S.inv_s = inv_s;
   const float dx = -(nb[0] * inv_s), dz = -(nb[2] * inv_s);
   const float t1x = -dz, t1z = dx;
@@ -136,76 +136,74 @@ OIS_DEV void substep_pk(const DevConsts& K, const DevTerrain& T, PhysT<1>& S) {
       m2[j] = newton_rcp2(m2[j], k2);
     }
   }
-  const float vnx = K.im4 * nb[0], vny = K.im4 * nb[1], vnz = K.im4 * nb[2];
-  const float v1x = K.im4 * t1x, v1z = K.im4 * t1z;
-  const float v2x = K.im4 * t2x, v2y = K.im4 * t2y, v2z = K.im4 * t2z;
-  f2 vx[2], vy[2], vz[2], ox[2], oy[2], oz[2];
+  // shared chassis linear velocity, impulse sums in the averaging pass (see substep<> in ois_physics.h)
+  const float qnx = K.imq * nb[0], qny = K.imq * nb[1], qnz = K.imq * nb[2];
+  const float q1x = K.imq * t1x, q1z = K.imq * t1z;
+  const float q2x = K.imq * t2x, q2y = K.imq * t2y, q2z = K.imq * t2z;
+  f2 ox[2], oy[2], oz[2];
   // warm start: one mass-split averaging pass with the cached impulses
-  OIS_PR vx[j] = fma2(l2[j], v2x, fma2(l1[j], v1x, fma2(ln[j], vnx, vb[0])));
-  OIS_PR vy[j] = fma2(l2[j], v2y, fma2(ln[j], vny, vb[1]));
-  OIS_PR vz[j] = fma2(l2[j], v2z, fma2(l1[j], v1z, fma2(ln[j], vnz, vb[2])));
   OIS_PR ox[j] = fma2(l2[j], Ja2[j][0], fma2(l1[j], Ja1[j][0], fma2(ln[j], Jan[j][0], wb[0])));
   OIS_PR oy[j] = fma2(l2[j], Ja2[j][1], fma2(l1[j], Ja1[j][1], fma2(ln[j], Jan[j][1], wb[1])));
   OIS_PR oz[j] = fma2(l2[j], Ja2[j][2], fma2(l1[j], Ja1[j][2], fma2(ln[j], Jan[j][2], wb[2])));
   OIS_PR spin[j] = fma2(-K.rw_over_Is, l1[j], spin[j]);
-  vb[0] = 0.25f * sum4(vx); vb[1] = 0.25f * sum4(vy); vb[2] = 0.25f * sum4(vz);
+  {
+    const float Sn = sum4(ln), S1 = sum4(l1), S2 = sum4(l2);
+    vb[0] = __builtin_fmaf(S2, q2x, __builtin_fmaf(S1, q1x, __builtin_fmaf(Sn, qnx, vb[0])));
+    vb[1] = __builtin_fmaf(S2, q2y, __builtin_fmaf(Sn, qny, vb[1]));
+    vb[2] = __builtin_fmaf(S2, q2z, __builtin_fmaf(S1, q1z, __builtin_fmaf(Sn, qnz, vb[2])));
+  }
   wb[0] = 0.25f * sum4(ox); wb[1] = 0.25f * sum4(oy); wb[2] = 0.25f * sum4(oz);
   const int iters = NIT > 0 ? NIT : K.iters;
 #pragma unroll
   for (int it = 0; it < iters; ++it) {
-    f2 u[2], dl[2], nw[2], lim[2];
-    // normal row
+    f2 u[2], dl[2], nw[2], lim[2], dn[2], d1[2];
+    // linear part of the three row velocities, shared by the four contacts
     const float unv = __builtin_fmaf(nb[2], vb[2], __builtin_fmaf(nb[1], vb[1], nb[0] * vb[0]));
+    const float u1v = __builtin_fmaf(t1z, vb[2], t1x * vb[0]);
+    const float u2v = __builtin_fmaf(t2z, vb[2], __builtin_fmaf(t2y, vb[1], t2x * vb[0]));
+    // normal row
     OIS_PR u[j] = fma2(an[j][0], wb[0], unv);
     OIS_PR u[j] = fma2(an[j][1], wb[1], u[j]);
     OIS_PR u[j] = fma2(an[j][2], wb[2], u[j]);
     OIS_PR dl[j] = (b[j] - u[j]) * mn[j];
     OIS_PR nw[j] = max2(ln[j] + dl[j], (f2)(0.0f));
-    OIS_PR dl[j] = nw[j] - ln[j];
+    OIS_PR dn[j] = nw[j] - ln[j];
     OIS_PR ln[j] = nw[j];
-    OIS_PR vx[j] = fma2(dl[j], vnx, vb[0]);
-    OIS_PR vz[j] = fma2(dl[j], vnz, vb[2]);
-    OIS_PR ox[j] = fma2(dl[j], Jan[j][0], wb[0]);
-    OIS_PR oy[j] = fma2(dl[j], Jan[j][1], wb[1]);
-    OIS_PR oz[j] = fma2(dl[j], Jan[j][2], wb[2]);
-    OIS_PR vy[j] = fma2(dl[j], vny, vb[1]);
+    OIS_PR ox[j] = fma2(dn[j], Jan[j][0], wb[0]);
+    OIS_PR oy[j] = fma2(dn[j], Jan[j][1], wb[1]);
+    OIS_PR oz[j] = fma2(dn[j], Jan[j][2], wb[2]);
     OIS_PR lim[j] = S.mu * ln[j];
     // longitudinal row (couples the wheel spin)
-    OIS_PR u[j] = t1x * vx[j];
-    OIS_PR u[j] = fma2(t1z, vz[j], u[j]);
-    OIS_PR u[j] = fma2(a1[j][0], ox[j], u[j]);
+    OIS_PR u[j] = fma2(a1[j][0], ox[j], u1v);
     OIS_PR u[j] = fma2(a1[j][1], oy[j], u[j]);
     OIS_PR u[j] = fma2(a1[j][2], oz[j], u[j]);
     OIS_PR u[j] = fma2(-K.rw, spin[j], u[j]);
     OIS_PR dl[j] = -(u[j] * m1[j]);
     OIS_PR nw[j] = clamp2(l1[j] + dl[j], lim[j]);
-    OIS_PR dl[j] = nw[j] - l1[j];
+    OIS_PR d1[j] = nw[j] - l1[j];
     OIS_PR l1[j] = nw[j];
-    OIS_PR vx[j] = fma2(dl[j], v1x, vx[j]);
-    OIS_PR vz[j] = fma2(dl[j], v1z, vz[j]);
-    OIS_PR ox[j] = fma2(dl[j], Ja1[j][0], ox[j]);
-    OIS_PR oy[j] = fma2(dl[j], Ja1[j][1], oy[j]);
-    OIS_PR oz[j] = fma2(dl[j], Ja1[j][2], oz[j]);
-    OIS_PR spin[j] = fma2(-K.rw_over_Is, dl[j], spin[j]);
+    OIS_PR ox[j] = fma2(d1[j], Ja1[j][0], ox[j]);
+    OIS_PR oy[j] = fma2(d1[j], Ja1[j][1], oy[j]);
+    OIS_PR oz[j] = fma2(d1[j], Ja1[j][2], oz[j]);
+    OIS_PR spin[j] = fma2(-K.rw_over_Is, d1[j], spin[j]);
     // lateral row
-    OIS_PR u[j] = t2x * vx[j];
-    OIS_PR u[j] = fma2(t2y, vy[j], u[j]);
-    OIS_PR u[j] = fma2(t2z, vz[j], u[j]);
-    OIS_PR u[j] = fma2(a2[j][0], ox[j], u[j]);
+    OIS_PR u[j] = fma2(a2[j][0], ox[j], u2v);
     OIS_PR u[j] = fma2(a2[j][1], oy[j], u[j]);
     OIS_PR u[j] = fma2(a2[j][2], oz[j], u[j]);
     OIS_PR dl[j] = -(u[j] * m2[j]);
     OIS_PR nw[j] = clamp2(l2[j] + dl[j], lim[j]);
     OIS_PR dl[j] = nw[j] - l2[j];
     OIS_PR l2[j] = nw[j];
-    OIS_PR vx[j] = fma2(dl[j], v2x, vx[j]);
-    OIS_PR vy[j] = fma2(dl[j], v2y, vy[j]);
-    OIS_PR vz[j] = fma2(dl[j], v2z, vz[j]);
     OIS_PR ox[j] = fma2(dl[j], Ja2[j][0], ox[j]);
     OIS_PR oy[j] = fma2(dl[j], Ja2[j][1], oy[j]);
     OIS_PR oz[j] = fma2(dl[j], Ja2[j][2], oz[j]);
     // mass-splitting average over the 4 contacts
-    vb[0] = 0.25f * sum4(vx); vb[1] = 0.25f * sum4(vy); vb[2] = 0.25f * sum4(vz);
+    {
+      const float Sn = sum4(dn), S1 = sum4(d1), S2 = sum4(dl);
+      vb[0] = __builtin_fmaf(S2, q2x, __builtin_fmaf(S1, q1x, __builtin_fmaf(Sn, qnx, vb[0])));
+      vb[1] = __builtin_fmaf(S2, q2y, __builtin_fmaf(Sn, qny, vb[1]));
+      vb[2] = __builtin_fmaf(S2, q2z, __builtin_fmaf(S1, q1z, __builtin_fmaf(Sn, qnz, vb[2])));
+    }
     wb[0] = 0.25f * sum4(ox); wb[1] = 0.25f * sum4(oy); wb[2] = 0.25f * sum4(oz);
   }
   OIS_PR {

@@ -334,6 +334,7 @@ void orc_reset_draws(const ois_config* cfg, const float u[8], float pos3[3], flo
 typedef struct {
   float dt, inv_dt, gdt, half_dt;
   float im4;         /* 4 / body_mass (mass-splitting factor 4 = contacts per chassis) */
+  float imq;         /* 0.25 * im4 (exact): inverse mass seen by the average over the 4 contacts */
   float J4[3];       /* 4 / body_inertia */
   float dt_over_Is, dt_over_Iy, rw, rw_over_Is, rw2_over_Is;
   float beta_inv_dt, vdep, maxw, maxw2, damping;
@@ -348,6 +349,7 @@ static void derive(const ois_config* c, derived* D) {
   D->gdt = c->gravity * c->sim_dt;
   D->half_dt = 0.5f * c->sim_dt;
   D->im4 = 4.0f / c->body_mass;
+  D->imq = 0.25f * D->im4;
   for (int k = 0; k < 3; ++k) D->J4[k] = 4.0f / c->body_inertia[k];
   D->dt_over_Is = c->sim_dt / c->wheel_spin_inertia;
   D->dt_over_Iy = c->sim_dt / c->body_inertia[1];
@@ -547,63 +549,73 @@ static void substep(const derived* D, float mu, const float n_in[3], const float
     m1[k] = rex ? 1.0f / k1 : newton_rcp(m1[k], k1);
     m2[k] = rex ? 1.0f / k2 : newton_rcp(m2[k], k2);
   }
-  float vnx = D->im4 * nb[0], vny = D->im4 * nb[1], vnz = D->im4 * nb[2];
-  float v1x = D->im4 * t1x, v1z = D->im4 * t1z;
-  float v2x = D->im4 * t2x, v2y = D->im4 * t2y, v2z = D->im4 * t2z;
+  /* chassis linear velocity: the contact frame (n, t1, t2) is orthonormal and the split inverse
+   * mass is a scalar, so an impulse along one row never changes the linear part of another
+   * row's velocity. The private copies of v_b are therefore never formed: a row reads the shared
+   * v_b, and the averaging pass adds (1/m) * frame * (sum of this pass's impulses) (SPEC 3.5). */
+  float qnx = D->imq * nb[0], qny = D->imq * nb[1], qnz = D->imq * nb[2];
+  float q1x = D->imq * t1x, q1z = D->imq * t1z;
+  float q2x = D->imq * t2x, q2y = D->imq * t2y, q2z = D->imq * t2z;
 
   /* warm start: re-apply the impulses accumulated in the previous substep (they persist
    * across policy steps in OIS_BUF_LAMBDA_*), as one more mass-split averaging pass */
   {
-    float vl[4][3], wl[4][3];
+    float wl[4][3];
     for (int k = 0; k < 4; ++k) {
-      vl[k][0] = fmaf(l2[k], v2x, fmaf(l1[k], v1x, fmaf(ln[k], vnx, vb[0])));
-      vl[k][1] = fmaf(l2[k], v2y, fmaf(ln[k], vny, vb[1]));
-      vl[k][2] = fmaf(l2[k], v2z, fmaf(l1[k], v1z, fmaf(ln[k], vnz, vb[2])));
       for (int j = 0; j < 3; ++j) wl[k][j] = fmaf(l2[k], Ja2[k][j], fmaf(l1[k], Ja1[k][j], fmaf(ln[k], Jan[k][j], wb[j])));
       spin[k] = fmaf(-D->rw_over_Is, l1[k], spin[k]);
     }
-    for (int j = 0; j < 3; ++j) {
-      vb[j] = 0.25f * ((vl[0][j] + vl[1][j]) + (vl[2][j] + vl[3][j]));
-      wb[j] = 0.25f * ((wl[0][j] + wl[1][j]) + (wl[2][j] + wl[3][j]));
-    }
+    float Sn = (ln[0] + ln[1]) + (ln[2] + ln[3]);
+    float S1 = (l1[0] + l1[1]) + (l1[2] + l1[3]);
+    float S2 = (l2[0] + l2[1]) + (l2[2] + l2[3]);
+    vb[0] = fmaf(S2, q2x, fmaf(S1, q1x, fmaf(Sn, qnx, vb[0])));
+    vb[1] = fmaf(S2, q2y, fmaf(Sn, qny, vb[1]));
+    vb[2] = fmaf(S2, q2z, fmaf(S1, q1z, fmaf(Sn, qnz, vb[2])));
+    for (int j = 0; j < 3; ++j) wb[j] = 0.25f * ((wl[0][j] + wl[1][j]) + (wl[2][j] + wl[3][j]));
   }
   for (int it = 0; it < D->iters; ++it) {
-    float vl[4][3], wl[4][3];
+    float wl[4][3], dn[4], d1[4], d2[4];
+    /* linear part of the three row velocities, shared by the four contacts */
+    float unv = fmaf(nb[2], vb[2], fmaf(nb[1], vb[1], nb[0] * vb[0]));
+    float u1v = fmaf(t1z, vb[2], t1x * vb[0]);
+    float u2v = fmaf(t2z, vb[2], fmaf(t2y, vb[1], t2x * vb[0]));
     for (int k = 0; k < 4; ++k) {
-      float vx = vb[0], vy = vb[1], vz = vb[2], ox = wb[0], oy = wb[1], oz = wb[2];
+      float ox = wb[0], oy = wb[1], oz = wb[2];
       /* normal row */
-      float u = fmaf(an[k][2], oz, fmaf(an[k][1], oy, fmaf(an[k][0], ox, fmaf(nb[2], vz, fmaf(nb[1], vy, nb[0] * vx)))));
+      float u = fmaf(an[k][2], oz, fmaf(an[k][1], oy, fmaf(an[k][0], ox, unv)));
       float dl = (b[k] - u) * mn[k];
       float nw = fmaxf(ln[k] + dl, 0.0f);
       dl = nw - ln[k];
       ln[k] = nw;
-      vx = fmaf(dl, vnx, vx); vy = fmaf(dl, vny, vy); vz = fmaf(dl, vnz, vz);
+      dn[k] = dl;
       ox = fmaf(dl, Jan[k][0], ox); oy = fmaf(dl, Jan[k][1], oy); oz = fmaf(dl, Jan[k][2], oz);
       float lim = mu * ln[k];
       /* longitudinal row (couples the wheel spin) */
-      u = fmaf(-D->rw, spin[k], fmaf(a1[k][2], oz, fmaf(a1[k][1], oy, fmaf(a1[k][0], ox, fmaf(t1z, vz, t1x * vx)))));
+      u = fmaf(-D->rw, spin[k], fmaf(a1[k][2], oz, fmaf(a1[k][1], oy, fmaf(a1[k][0], ox, u1v))));
       dl = -(u * m1[k]);
       nw = fminf(fmaxf(l1[k] + dl, -lim), lim);
       dl = nw - l1[k];
       l1[k] = nw;
-      vx = fmaf(dl, v1x, vx); vz = fmaf(dl, v1z, vz);
+      d1[k] = dl;
       ox = fmaf(dl, Ja1[k][0], ox); oy = fmaf(dl, Ja1[k][1], oy); oz = fmaf(dl, Ja1[k][2], oz);
       spin[k] = fmaf(-D->rw_over_Is, dl, spin[k]);
       /* lateral row */
-      u = fmaf(a2[k][2], oz, fmaf(a2[k][1], oy, fmaf(a2[k][0], ox, fmaf(t2z, vz, fmaf(t2y, vy, t2x * vx)))));
+      u = fmaf(a2[k][2], oz, fmaf(a2[k][1], oy, fmaf(a2[k][0], ox, u2v)));
       dl = -(u * m2[k]);
       nw = fminf(fmaxf(l2[k] + dl, -lim), lim);
       dl = nw - l2[k];
       l2[k] = nw;
-      vx = fmaf(dl, v2x, vx); vy = fmaf(dl, v2y, vy); vz = fmaf(dl, v2z, vz);
+      d2[k] = dl;
       ox = fmaf(dl, Ja2[k][0], ox); oy = fmaf(dl, Ja2[k][1], oy); oz = fmaf(dl, Ja2[k][2], oz);
-      vl[k][0] = vx; vl[k][1] = vy; vl[k][2] = vz;
       wl[k][0] = ox; wl[k][1] = oy; wl[k][2] = oz;
     }
-    for (int j = 0; j < 3; ++j) {
-      vb[j] = 0.25f * ((vl[0][j] + vl[1][j]) + (vl[2][j] + vl[3][j]));
-      wb[j] = 0.25f * ((wl[0][j] + wl[1][j]) + (wl[2][j] + wl[3][j]));
-    }
+    float Sn = (dn[0] + dn[1]) + (dn[2] + dn[3]);
+    float S1 = (d1[0] + d1[1]) + (d1[2] + d1[3]);
+    float S2 = (d2[0] + d2[1]) + (d2[2] + d2[3]);
+    vb[0] = fmaf(S2, q2x, fmaf(S1, q1x, fmaf(Sn, qnx, vb[0])));
+    vb[1] = fmaf(S2, q2y, fmaf(Sn, qny, vb[1]));
+    vb[2] = fmaf(S2, q2z, fmaf(S1, q1z, fmaf(Sn, qnz, vb[2])));
+    for (int j = 0; j < 3; ++j) wb[j] = 0.25f * ((wl[0][j] + wl[1][j]) + (wl[2][j] + wl[3][j]));
   }
   /* back to the world frame, velocity caps (origin_v18.py:65-70), integrate */
   rot(R, vb, v);

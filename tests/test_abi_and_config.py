@@ -156,7 +156,12 @@ def test_no_kernel_reads_the_dispatch_packet(tmp_path):
             assert ".amdhsa_user_sgpr_dispatch_ptr 0" in body, f"{name} reads the dispatch packet"
             scratch = int(re.search(r"\.amdhsa_private_segment_fixed_size (\d+)", body).group(1))
             held = "step_kernel_w2" in name  # held to 256 registers on purpose: cold per-step state spills
-            assert scratch <= (256 if held else 0), f"{name} uses {scratch} B of scratch per lane"
+            # elsewhere no instruction may touch scratch; the backend may still leave a dead spill
+            # slot in the descriptor (36 B in step_kernel<1,true,4>: no access, no measured cost)
+            code = text[text.index(name + ":"):text.index(".amdhsa_kernel " + name)]
+            touches = re.findall(r"^\s+(scratch_\w+|buffer_(?:load|store)\w*)", code, flags=re.M)
+            assert held or not touches, f"{name} accesses scratch: {sorted(set(touches))}"
+            assert scratch <= (256 if held else 64), f"{name} uses {scratch} B of scratch per lane"
             if "step_kernel" in name:
                 assert ".amdhsa_group_segment_fixed_size 0" in body, f"{name}: a private array was promoted to LDS"
 
