@@ -883,17 +883,17 @@ int ois_create(const ois_config* cfg, int device, void* workspace_device, size_t
   e->grid = (e->N + kBlock - 1) / kBlock;
   {
     // Lanes per arena. Measured on MI355X at 65 536 arenas: a lane pair per arena
-    // (2 waves per SIMD, 31 DPP adds per substep) runs a fused rollout in 45 us per policy step and
+    // (2 waves per SIMD, 31 DPP adds per substep) ran a fused rollout in 45 us per policy step and
     // a single-step launch in 68 us, against 30.5 us / 42 us for one lane per arena with packed
-    // wheel pairs. One lane per arena is the default; OIS_LANES_PER_ARENA=2 selects the pair
+    // wheel pairs (27.5 / 38 us since the solver shares the chassis' linear velocity). One lane per arena is the default; OIS_LANES_PER_ARENA=2 selects the pair
     // layout (an experiment kept because it is bit-identical to the oracle and covered by the
     // tests; no terrain, no unrolled-iteration variant).
     const char* w = getenv("OIS_LANES_PER_ARENA");
     e->lpa = (w && w[0] == '2') ? 2 : 1;
-    // Packed fp32 over wheel pairs is the default at every size: half the VALU instructions per
-    // substep (729 vs ~1 490), and the advantage holds with one wave per SIMD (30.5 vs 46.7 us
-    // per policy step at 65 536 arenas) as with two (57 vs 66 us at 131 072, 220 vs ~260 us at
-    // 524 288). OIS_PACKED=0 selects the scalar kernel.
+    // Packed fp32 over wheel pairs is the default at every size: two thirds of the VALU instructions
+    // per substep (691 vs 1 081), and the advantage holds with one wave per SIMD (32.7 vs 41.4 us
+    // per policy step at 65 536 arenas, tools/terrain_probe.py) as with two (131 072 arenas and up).
+    // OIS_PACKED=0 selects the scalar kernel.
     const char* pk = getenv("OIS_PACKED");
     e->packed = pk ? (pk[0] == '1') : true;
     // Plane kernel shell (see step_kernel / step_kernel_w2): the 256-register one only where a
