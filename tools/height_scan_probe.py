@@ -1,0 +1,23 @@
+"""ois_height_scan alone (profiling target): 65 536 arenas on the 6 x 2-tile field, random poses after 60 steps"""
+import os, sys, json
+import numpy as np
+import torch
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from options_in_simulation_amd import _abi, build_config
+from options_in_simulation_amd import terrain as tg
+from options_in_simulation_amd.vecenv import NativeEnv
+N = int(sys.argv[1]) if len(sys.argv) > 1 else 65536
+reps = int(sys.argv[2]) if len(sys.argv) > 2 else 20
+T = tg.Terrain({"numLevels": 6, "numTerrains": 2, "mapLength": 10.0, "mapWidth": 10.0}, N, seed=0)
+env = NativeEnv(build_config(variant="KAMMA_eval", num_envs=N, seed=1), "cuda:0")
+env.attach_terrain(T, T.sample_levels_types(N, rng=np.random.RandomState(0)))
+env.reset(1)
+env.rollout(60, _abi.POLICY_RANDOM)
+scan = torch.empty((N, 140), device="cuda")
+env.height_scan(scan); torch.cuda.synchronize()
+e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+e0.record()
+for _ in range(reps):
+    env.height_scan(scan)
+e1.record(); torch.cuda.synchronize()
+print(json.dumps({"arenas": N, "height_scan_us": e0.elapsed_time(e1) * 1e3 / reps, "checksum": float(scan.double().sum())}))
