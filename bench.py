@@ -61,6 +61,23 @@ def usable_cores():
     return max(1, min(n, int(os.environ.get("OIS_CPU_THREADS", "16"))))
 
 
+def measured_copy_gbs(torch, device, mb=1024, reps=10):
+    """what a plain device copy achieves on this GPU (read + write bytes / time), the practical
+    ceiling SURVEY.md section 8(d) asks to quote beside the 8 TB/s spec peak (tools/copy_bw.hip is the
+    same measurement with an in-repo kernel: profiles/r1_copy_bw.txt)."""
+    n = (mb << 20) // 4
+    src = torch.ones(n, dtype=torch.float32, device=device)
+    dst = torch.empty_like(src)
+    dst.copy_(src)
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(reps):
+        dst.copy_(src)
+    e1.record()
+    torch.cuda.synchronize(device)
+    return 2.0 * n * 4 * reps / (e0.elapsed_time(e1) * 1e-3) / 1e9
+
+
 def pmc_traffic(n_arenas):
     """HBM bytes per step_kernel launch from the committed PMC run (bench.py cannot collect
     counters on itself). Only returned when the profile was taken at this arena count."""
@@ -212,6 +229,7 @@ def main():
 
     if rank == 0:
         achieved = ALGO_BYTES_PER_ENV_STEP * N / (kernel_ms * 1e-3) / 1e9
+        copy_gbs = measured_copy_gbs(torch, device)  # after the timed region
         out = {
             "metric": "env-steps/sec at 65 536 parallel arenas; achieved HBM GB/s vs roofline",
             "value": value, "unit": "env-steps/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -228,6 +246,8 @@ def main():
                          "frac": achieved / HBM_PEAK_GBS, "traffic": None if args.terrain else pmc_traffic(N),
                          "kernel": "step_kernel", "kernel_ms": kernel_ms,
                          "algorithmic_bytes_per_launch": ALGO_BYTES_PER_ENV_STEP * N,
+                         "measured_copy": {"GB/s": copy_gbs, "frac": achieved / copy_gbs,
+                                           "what": "1 GiB device-to-device torch copy on this GPU, read + write bytes / time"},
                          "traffic_source": "profiles/r1_pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, "
                                            "separate passes, FETCH_SIZE x2 per the gfx950 correction)",
                          "valu": {"achieved": FLOP_PER_ENV_STEP * N / (kernel_ms * 1e-3) / 1e12, "peak": FP32_VECTOR_PEAK_TFLOPS,
