@@ -30,6 +30,7 @@ struct PhysT {
   float to[3];             // origin of the arena's terrain tile (only read by the TER instantiations)
   // wheel footprints sampled at the start of the previous substep (TER only, SPEC §3.8)
   float fwx[4], fwy[4], fh[4], fr00, fr10, fr01, fr11;
+  int fpx[4], fpy[4];      // field cell of each stored footprint (gather cache, see terrain_footprints)
 };
 
 // 1.0f / d, correctly rounded, for finite d with 2^-40 <= |d| < 2^40: the refinement chain of the
@@ -63,34 +64,51 @@ OIS_DEV float newton_rsqrt(float r, float s2) {  // r ~ 1/sqrt(s2) -> r (1.5 - 0
 // ground height at world (x, y): get_heights' sampling rule (KAMMA.py:882-893) with the division
 // by horizontal_scale replaced by a multiplication; positions are clamped before the int
 // conversion, so no index can leave the field whatever the state (NaN clamps to 0)
-OIS_DEV float terrain_height(const DevTerrain& T, float x, float y) {
+OIS_DEV void terrain_cell(const DevTerrain& T, float x, float y, int& px, int& py) {
   float fx = (x + T.border) * T.inv_hs, fy = (y + T.border) * T.inv_hs;
   fx = fminf(fmaxf(fx, 0.0f), (float)(T.rows - 2));
   fy = fminf(fmaxf(fy, 0.0f), (float)(T.cols - 2));
-  const int px = (int)fx, py = (int)fy;
+  px = (int)fx; py = (int)fy;
+}
+OIS_DEV float terrain_cell_height(const DevTerrain& T, int px, int py) {
   const int16_t h1 = T.h[(size_t)px * T.cols + py], h2 = T.h[(size_t)(px + 1) * T.cols + (py + 1)];
   return (float)(h1 < h2 ? h1 : h2) * T.vs;
 }
 // footprints of the 4 wheels at the current pose: world xy under the wheel centres and the field
-// height there (8 gathers, issued here, consumed one substep later)
+// height there (8 gathers, issued here, consumed one substep later). A wheel moves at most ~2 cm
+// per substep, so its cell is often the one sampled a substep earlier: those lanes reuse the
+// stored height (same value by construction, the tile origin is fixed inside a policy step)
+// instead of gathering again. All waves reach this point together, so the gathers of a substep
+// are one burst of line requests against L2; thinning it is what shortens the substep.
 struct Footprints {
   float wx[4], wy[4], h[4], r00, r10, r01, r11;
+  int px[4], py[4];
 };
-OIS_DEV void terrain_footprints(const DevConsts& K, const DevTerrain& T, const float* origin, const float* p,
-                                const float* R, Footprints& F) {
+template <bool FRESH, int LPA>
+OIS_DEV void terrain_footprints(const DevConsts& K, const DevTerrain& T, const PhysT<LPA>& S, const float* R, Footprints& F) {
+  const float* origin = S.to;
+  const float* p = S.p;
 #pragma unroll
   for (int k = 0; k < 4; ++k) {
     const float cx = (k & 1) ? -K.wx : K.wx, cy = (k & 2) ? -K.wy : K.wy;
     F.wx[k] = __builtin_fmaf(R[2], K.cz, __builtin_fmaf(R[1], cy, __builtin_fmaf(R[0], cx, p[0])));
     F.wy[k] = __builtin_fmaf(R[5], K.cz, __builtin_fmaf(R[4], cy, __builtin_fmaf(R[3], cx, p[1])));
-    F.h[k] = terrain_height(T, F.wx[k] + origin[0], F.wy[k] + origin[1]) - origin[2];
+    terrain_cell(T, F.wx[k] + origin[0], F.wy[k] + origin[1], F.px[k], F.py[k]);
+    // unchanged cell: the lane re-reads cell (0, 0) instead (one shared line, an L1 hit) and keeps
+    // the stored height; the loads stay unconditional, so nothing waits for them before the latch
+    // (the mask goes through an empty asm so that the compiler cannot turn the blend back into a
+    // branch around the loads, which would put their latency back in front of the solve)
+    int m = (!FRESH && F.px[k] == S.fpx[k] && F.py[k] == S.fpy[k]) ? -1 : 0;
+    asm volatile("" : "+v"(m));
+    const float hh = terrain_cell_height(T, F.px[k] & ~m, F.py[k] & ~m) - origin[2];
+    F.h[k] = __int_as_float((__float_as_int(S.fh[k]) & m) | (__float_as_int(hh) & ~m));
   }
   F.r00 = R[0]; F.r10 = R[3]; F.r01 = R[1]; F.r11 = R[4];
 }
 template <int LPA>
 OIS_DEV void footprints_store(PhysT<LPA>& S, const Footprints& F) {
 #pragma unroll
-  for (int k = 0; k < 4; ++k) { S.fwx[k] = F.wx[k]; S.fwy[k] = F.wy[k]; S.fh[k] = F.h[k]; }
+  for (int k = 0; k < 4; ++k) { S.fwx[k] = F.wx[k]; S.fwy[k] = F.wy[k]; S.fh[k] = F.h[k]; S.fpx[k] = F.px[k]; S.fpy[k] = F.py[k]; }
   S.fr00 = F.r00; S.fr10 = F.r10; S.fr01 = F.r01; S.fr11 = F.r11;
 }
 // plane through the stored footprints: unit normal n (world), off[k] = n . footprint_k
@@ -132,7 +150,7 @@ OIS_DEV void substep(const DevConsts& K, const DevTerrain& T, int wheel0, PhysT<
   if constexpr (TER) {
     // fit the plane to the footprints sampled one substep earlier (the first substep of a policy
     // step samples its own): this substep's 8 gathers stay in flight during the whole solve
-    terrain_footprints(K, T, S.to, S.p, R, cur);
+    terrain_footprints<EXACT>(K, T, S, R, cur);
     if (EXACT) footprints_store(S, cur);
     terrain_plane(K, S, n, off);
   }

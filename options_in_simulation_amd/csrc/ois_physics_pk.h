@@ -62,7 +62,7 @@ OIS_DEV void substep_pk(const DevConsts& K, const DevTerrain& T, PhysT<1>& S) {
   float n[3] = {S.n[0], S.n[1], S.n[2]}, off[4] = {0.0f, 0.0f, 0.0f, 0.0f};
   Footprints cur;
   if constexpr (TER) {  // one-substep-lagged footprints, see substep<> in ois_physics.h
-    terrain_footprints(K, T, S.to, S.p, R, cur);
+    terrain_footprints<EXACT>(K, T, S, R, cur);
     if (EXACT) footprints_store(S, cur);
     terrain_plane(K, S, n, off);
   }
