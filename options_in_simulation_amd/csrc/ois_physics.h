@@ -66,8 +66,10 @@ OIS_DEV float newton_rsqrt(float r, float s2) {  // r ~ 1/sqrt(s2) -> r (1.5 - 0
 // conversion, so no index can leave the field whatever the state (NaN clamps to 0)
 OIS_DEV void terrain_cell(const DevTerrain& T, float x, float y, int& px, int& py) {
   float fx = (x + T.border) * T.inv_hs, fy = (y + T.border) * T.inv_hs;
-  fx = fminf(fmaxf(fx, 0.0f), (float)(T.rows - 2));
-  fy = fminf(fmaxf(fy, 0.0f), (float)(T.cols - 2));
+  // clamp as one v_med3_f32 (a NaN comes out as 0 either way: med3 with a NaN operand is min3,
+  // which skips it, and the int conversion of a NaN is 0 — no index can leave the field)
+  fx = __builtin_amdgcn_fmed3f(fx, 0.0f, (float)(T.rows - 2));
+  fy = __builtin_amdgcn_fmed3f(fy, 0.0f, (float)(T.cols - 2));
   px = (int)fx; py = (int)fy;
 }
 OIS_DEV float terrain_cell_height(const DevTerrain& T, int px, int py) {

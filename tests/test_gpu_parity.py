@@ -189,24 +189,35 @@ def test_every_kernel_instantiation_is_bit_identical_to_the_oracle(env_vars, mon
                          ids=["scalar", "packed", "lane-pair"])
 def test_non_finite_outcome_guard_parity(env_vars, monkeypatch):
     """docs/SPEC.md §3.9: injected NaN / inf velocities -> the arena is reset as fallen, outputs
-    finite, kernel == oracle bit for bit (also for the untouched arenas)."""
+    finite, kernel == oracle bit for bit (also for the untouched arenas). Lane-pair layout on the
+    plane only; the other two also on the height field (NaN positions must not index outside it)."""
     for k, v in env_vars.items():
         monkeypatch.setenv(k, v)
+    for field in ((False,) if "OIS_LANES_PER_ARENA" in env_vars else (False, True)):
+        _guard_case(env_vars, field)
+
+
+def _guard_case(env_vars, field):
+    from options_in_simulation_amd import terrain as tg
     N = 130
     cfg, dev, orc = make_pair(variant="KAMMA_medium", num_envs=N, seed=4)
+    if field:
+        T = tg.Terrain({"numLevels": 2, "numTerrains": 2, "mapLength": 8.0, "mapWidth": 8.0}, N, seed=5)
+        lt = T.sample_levels_types(N, rng=np.random.RandomState(6))
+        dev.attach_terrain(T, lt); orc.attach_terrain(T, lt)
     dev.reset(4); orc.reset(4)
     z = np.zeros((N, 4), np.float32)
     for _ in range(2):
         dev.step(torch.from_numpy(z).cuda()); orc.step(z)
     torch.cuda.synchronize()
     for bid, i, j, val in [(_abi.BUF_LINVEL, 3, 1, np.nan), (_abi.BUF_ANGVEL, 64, 0, np.inf), (_abi.BUF_WHEEL_VEL, 129, 2, -np.inf),
-                           (_abi.BUF_QUAT, 77, 3, np.nan)]:
+                           (_abi.BUF_QUAT, 77, 3, np.nan), (_abi.BUF_POSE, 100, 0, np.nan), (_abi.BUF_POSE, 101, 1, np.inf)]:
         dev.buffer(bid)[i, j] = float(val); orc.buffer(bid)[i, j] = val
     dev.step(torch.from_numpy(z).cuda()); orc.step(z)
     worst = compare(dev, orc, f"{env_vars} guard step", exact_float=True)
     assert np.isfinite(worst)
     done = dev.buffer(_abi.BUF_DONE).cpu().numpy().astype(bool)
-    assert done[[3, 64, 129, 77]].all() and done.sum() == 4
+    assert done[[3, 64, 129, 77, 100, 101]].all() and done.sum() == 6
     for bid in STATE_BUFS:
         assert torch.isfinite(dev.buffer(bid)).all(), bid
     for _ in range(3):
