@@ -56,8 +56,9 @@ extern "C" {
 #endif
 
 /* 2: ois_replay_*, ois_gae, ois_terrain_attach, ois_height_scan, buffers 21-22, a larger workspace
- * (state blobs of version 1 do not load) */
-#define OIS_ABI_VERSION 2
+ * (state blobs of version 1 do not load)
+ * 3: ois_terrain_attach takes the min-field scratch (one gather per height sample) */
+#define OIS_ABI_VERSION 3
 
 /* error codes */
 #define OIS_OK 0
@@ -352,9 +353,15 @@ typedef struct ois_terrain {
 } ois_terrain;
 /* heights_device: int16 [rows, cols]; terrain_origins_device: float [num_levels, num_types, 3];
  * levels_types_host: int32 [N, 2] initial terrain_levels / terrain_types (host memory, copied).
+ * minfield_device: caller-owned int16 [rows, cols] scratch the library fills (on `stream`) with
+ *   m[x][y] = min(h[x][y], h[x+1][y+1])  — the two-sample rule of get_heights (KAMMA.py:889-893)
+ * folded into the field once, so that a footprint or a scan point is ONE gather instead of two
+ * (same values; the indices are clamped to rows - 2 / cols - 2 before use, KAMMA.py:886-887, so
+ * the last row and column are never read). Like the field it must outlive the attachment.
  * Call before ois_reset. terrain == NULL detaches (back to the per-arena plane). */
 int ois_terrain_attach(ois_env* env, const ois_terrain* terrain, const int16_t* heights_device,
-                       const float* terrain_origins_device, const int32_t* levels_types_host, void* stream);
+                       int16_t* minfield_device, const float* terrain_origins_device,
+                       const int32_t* levels_types_host, void* stream);
 /* heights_out_device: float [N, OIS_HEIGHT_POINTS] measured_heights of the current state */
 int ois_height_scan(ois_env* env, float* heights_out_device, void* stream);
 

@@ -80,7 +80,7 @@ def load() -> C.CDLL:
     L.ois_gae.argtypes = [C.c_int, C.c_int, C.c_int, vp, vp, vp, vp, C.c_double, C.c_double, C.c_int, vp, vp, vp,
                           C.c_size_t, vp]
     L.ois_replay_sample.argtypes = [vp, vp, C.c_int, vp, vp, vp, vp, vp, vp]
-    L.ois_terrain_attach.argtypes = [vp, C.POINTER(_abi.OisTerrain), vp, vp, C.POINTER(C.c_int32), vp]
+    L.ois_terrain_attach.argtypes = [vp, C.POINTER(_abi.OisTerrain), vp, vp, vp, C.POINTER(C.c_int32), vp]
     L.ois_height_scan.argtypes = [vp, vp, vp]
     if L.ois_abi_version() != _abi.ABI_VERSION:
         raise NativeLibraryError(

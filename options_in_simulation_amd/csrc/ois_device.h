@@ -50,6 +50,7 @@ struct DevConsts {
 // height-field terrain (include/ois.h ois_terrain_attach); on == 0: the per-arena plane of `params`
 struct DevTerrain {
   const int16_t* h;        // [rows][cols] raw heights (caller-owned)
+  const int16_t* m;        // [rows][cols] min(h[x][y], h[x+1][y+1]), filled at attach (caller-owned scratch)
   const float* origins;    // [levels][types][3] terrain_origins table (caller-owned)
   int rows, cols, ntypes, max_level, curriculum, on;
   float inv_hs, hs, vs, border, thr_lo, thr_hi;

@@ -437,8 +437,18 @@ __global__ __launch_bounds__(256) void height_scan_kernel(DevConsts K, DevBuffer
   fx = fminf(fmaxf(fx, 0.0f), (float)(B.ter.rows - 2));  // :886-887
   fy = fminf(fmaxf(fy, 0.0f), (float)(B.ter.cols - 2));
   const int px = (int)fx, py = (int)fy;
-  const int16_t h1 = B.ter.h[(size_t)px * B.ter.cols + py], h2 = B.ter.h[(size_t)(px + 1) * B.ter.cols + (py + 1)];
-  out[t] = (float)(h1 < h2 ? h1 : h2) * B.ter.vs;  // :889-893
+  out[t] = (float)B.ter.m[(size_t)px * B.ter.cols + py] * B.ter.vs;  // :889-893, the min of the two samples is in the min-field
+}
+
+// m[x][y] = min(h[x][y], h[x+1][y+1]) (last row / column: h itself; never read, see ois.h)
+__global__ __launch_bounds__(256) void minfield_kernel(const int16_t* __restrict__ h, int16_t* __restrict__ m, int rows, int cols) {
+  const size_t t = (size_t)blockIdx.x * 256 + threadIdx.x;
+  if (t >= (size_t)rows * cols) return;
+  const int x = (int)(t / cols), y = (int)(t % cols);
+  const int16_t a = h[t];
+  int16_t b = a;
+  if (x + 1 < rows && y + 1 < cols) b = h[t + cols + 1];
+  m[t] = a < b ? a : b;
 }
 
 // ------------------------------------------------------------------ post_reset --------
@@ -1025,7 +1035,7 @@ int ois_randomize_params(ois_env* e, float mu_lo, float mu_hi, const float* slop
   return OIS_OK;
 }
 
-int ois_terrain_attach(ois_env* e, const ois_terrain* t, const int16_t* heights_device,
+int ois_terrain_attach(ois_env* e, const ois_terrain* t, const int16_t* heights_device, int16_t* minfield_device,
                        const float* terrain_origins_device, const int32_t* levels_types_host, void* stream) {
   if (!e) return fail(OIS_EINVAL, "null env");
   HIP_TRY(hipSetDevice(e->device));
@@ -1039,7 +1049,8 @@ int ois_terrain_attach(ois_env* e, const ois_terrain* t, const int16_t* heights_
   }
   if (t->struct_bytes != sizeof(ois_terrain)) return fail(OIS_EINVAL, "ois_terrain.struct_bytes does not match this library");
   if (t->rows < 2 || t->cols < 2 || !(t->horizontal_scale > 0.0f) || t->num_levels < 1 || t->num_types < 1 ||
-      t->max_level < 0 || t->max_level >= t->num_levels || !heights_device || !terrain_origins_device || !levels_types_host)
+      t->max_level < 0 || t->max_level >= t->num_levels || !heights_device || !minfield_device || !terrain_origins_device ||
+      !levels_types_host)
     return fail(OIS_EINVAL, "bad terrain description");
   if (e->lpa != 1) return fail(OIS_EINVAL, "the terrain contact needs one lane per arena (unset OIS_LANES_PER_ARENA)");
   // per-arena origin = terrain_origins[level, type] (KAMMA.py:397): built on the host from the
@@ -1058,8 +1069,14 @@ int ois_terrain_attach(ois_env* e, const ois_terrain* t, const int16_t* heights_
   HIP_TRY(hipMemcpyAsync(e->B.env_origins, org.data(), f4, hipMemcpyHostToDevice, s));
   HIP_TRY(hipMemcpyAsync(e->B.terrain_idx, idx.data(), f4, hipMemcpyHostToDevice, s));
   HIP_TRY(hipStreamSynchronize(s));
+  {
+    const size_t cells = (size_t)t->rows * (size_t)t->cols;
+    hipLaunchKernelGGL(minfield_kernel, dim3((unsigned)((cells + 255) / 256)), dim3(256), 0, s, heights_device, minfield_device,
+                       t->rows, t->cols);
+    HIP_TRY(hipGetLastError());
+  }
   DevTerrain& T = e->B.ter;
-  T.h = heights_device; T.origins = terrain_origins_device;
+  T.h = heights_device; T.m = minfield_device; T.origins = terrain_origins_device;
   T.rows = t->rows; T.cols = t->cols; T.ntypes = t->num_types; T.max_level = t->max_level;
   T.curriculum = t->curriculum; T.on = 1;
   T.hs = t->horizontal_scale; T.inv_hs = 1.0f / t->horizontal_scale; T.vs = t->vertical_scale; T.border = t->border_size;

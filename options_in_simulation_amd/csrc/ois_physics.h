@@ -73,11 +73,11 @@ OIS_DEV void terrain_cell(const DevTerrain& T, float x, float y, int& px, int& p
   px = (int)fx; py = (int)fy;
 }
 OIS_DEV float terrain_cell_height(const DevTerrain& T, int px, int py) {
-  const int16_t h1 = T.h[(size_t)px * T.cols + py], h2 = T.h[(size_t)(px + 1) * T.cols + (py + 1)];
-  return (float)(h1 < h2 ? h1 : h2) * T.vs;
+  // T.m[x][y] = min(h[x][y], h[x+1][y+1]), built once at ois_terrain_attach: one gather per sample
+  return (float)T.m[(size_t)px * T.cols + py] * T.vs;
 }
 // footprints of the 4 wheels at the current pose: world xy under the wheel centres and the field
-// height there (8 gathers, issued here, consumed one substep later). A wheel moves at most ~2 cm
+// height there (4 gathers of the min-field, issued here, consumed one substep later). A wheel moves at most ~2 cm
 // per substep, so its cell is often the one sampled a substep earlier: those lanes reuse the
 // stored height (same value by construction, the tile origin is fixed inside a policy step)
 // instead of gathering again. All waves reach this point together, so the gathers of a substep

@@ -199,15 +199,16 @@ class NativeEnv:
         t.curriculum = int(bool(cur))
         t.threshold_low, t.threshold_high = float(threshold_low), float(threshold_high)
         t.max_level = int(min(5, t.num_levels - 1) if max_level is None else max_level)  # KAMMA.py:525
+        minfield = torch.empty_like(field)  # scratch the library fills with min(h[x][y], h[x+1][y+1])
         torch.cuda.synchronize(self.device)
         _native.check(self.L.ois_terrain_attach(self.h, C.byref(t), C.c_void_p(field.data_ptr()),
-                                                C.c_void_p(origins.data_ptr()),
+                                                C.c_void_p(minfield.data_ptr()), C.c_void_p(origins.data_ptr()),
                                                 lt.ctypes.data_as(C.POINTER(C.c_int32)), _stream_ptr(self.device)))
-        self._terrain = (field, origins, t)  # the library reads them on every step: keep them alive
+        self._terrain = (field, minfield, origins, t)  # the library reads them on every step: keep them alive
 
     def detach_terrain(self):
         torch.cuda.synchronize(self.device)
-        _native.check(self.L.ois_terrain_attach(self.h, None, None, None, None, _stream_ptr(self.device)))
+        _native.check(self.L.ois_terrain_attach(self.h, None, None, None, None, None, _stream_ptr(self.device)))
         self._terrain = None
 
     def height_scan(self, out: Optional[torch.Tensor] = None) -> torch.Tensor:

@@ -173,7 +173,7 @@ def test_new_entry_points_reject_bad_arguments_without_a_gpu(lib):
     assert lib.ois_replay_sample(None, None, 1, None, None, None, None, None, None) == _abi.EINVAL
     i, f = C.c_int(), C.c_int()
     assert lib.ois_replay_cursor(None, C.byref(i), C.byref(f)) == _abi.EINVAL
-    assert lib.ois_terrain_attach(None, None, None, None, None, None) == _abi.EINVAL
+    assert lib.ois_terrain_attach(None, None, None, None, None, None, None) == _abi.EINVAL
     assert lib.ois_height_scan(None, None, None) == _abi.EINVAL
     assert lib.ois_gae_scratch_bytes(0) == 0 and lib.ois_gae_scratch_bytes(65536) == (2 * 1024 + 1) * 8
     one = C.c_void_p(8)  # never dereferenced: every call below fails its checks first
