@@ -134,6 +134,9 @@ def main():
     ap.add_argument("--log-interval", type=int, default=800)
     ap.add_argument("--no-actor", action="store_true", help="env-only loop (fixed random actions)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--fused", type=int, default=0, metavar="K",
+                    help="env-only, K policy steps per launch with the in-kernel random-torque policy (ois_rollout; "
+                         "BASELINE.json configs[1]'s policy at this arena count): one timed 'step' = one launch of K steps")
     ap.add_argument("--variant", default="KAMMA_medium")
     ap.add_argument("--domain-rand", action="store_true",
                     help="BASELINE.json configs[3]: per-arena friction U(0.5, 1.0) and plane slope from the generator's set")
@@ -187,17 +190,27 @@ def main():
 
     ev_pairs = []
 
+    K_fused = max(0, args.fused)
+    if K_fused:
+        actor = None
+
+    def launch(a):
+        if K_fused:
+            env.rollout(K_fused, _abi.POLICY_RANDOM)
+        else:
+            env.step(a)
+
     def one_step(timed):
         with torch.no_grad():
             a = fixed_actions if actor is None else actor(obs)
         if timed:
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()
-            env.step(a)
+            launch(a)
             e1.record()
             ev_pairs.append((e0, e1))
         else:
-            env.step(a)
+            launch(a)
 
     def barrier():
         if world > 1:
@@ -224,11 +237,12 @@ def main():
         elapsed = float(t.item())
 
     kernel_ms = sum(a.elapsed_time(b) for a, b in ev_pairs) / max(1, len(ev_pairs))
-    total_env_steps = float(N) * world * args.steps
+    per_launch = max(1, K_fused)
+    total_env_steps = float(N) * world * args.steps * per_launch
     value = total_env_steps / elapsed
 
     if rank == 0:
-        achieved = ALGO_BYTES_PER_ENV_STEP * N / (kernel_ms * 1e-3) / 1e9
+        achieved = ALGO_BYTES_PER_ENV_STEP * N * per_launch / (kernel_ms * 1e-3) / 1e9
         copy_gbs = measured_copy_gbs(torch, device)  # after the timed region
         out = {
             "metric": "env-steps/sec at 65 536 parallel arenas; achieved HBM GB/s vs roofline",
@@ -236,22 +250,23 @@ def main():
             "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": f"{N} arenas/GPU, {terrain_note}, {args.variant} task, "
-                                   + ("fixed random actions (env only)" if actor is None else
+                                   + (f"in-kernel random-torque policy, {K_fused} policy steps per launch (env only)" if K_fused else
+                                      "fixed random actions (env only)" if actor is None else
                                       "scripted actor MLP 6-512-512-128-4 (fp32 PyTorch-ROCm) inference in-loop")
                                    + (" [BASELINE.json configs[3]]" if (args.domain_rand or args.terrain) else " [BASELINE.json configs[2]]"),
                        "arenas_per_gpu": N, "substeps_per_step": cfg.decimation + cfg.extra_substeps,
                        "solver_iterations": cfg.solver_iterations, "sharding": f"arenas x{world}, no data-path collective",
                        "stats_allgather_every": args.log_interval},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": None if args.terrain else pmc_traffic(N),
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": None if (args.terrain or K_fused) else pmc_traffic(N),
                          "kernel": "step_kernel", "kernel_ms": kernel_ms,
-                         "algorithmic_bytes_per_launch": ALGO_BYTES_PER_ENV_STEP * N,
+                         "algorithmic_bytes_per_launch": ALGO_BYTES_PER_ENV_STEP * N * per_launch,
                          "measured_copy": {"GB/s": copy_gbs, "frac": achieved / copy_gbs,
                                            "what": "1 GiB device-to-device torch copy on this GPU, read + write bytes / time"},
                          "traffic_source": "profiles/r1_pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, "
                                            "separate passes, FETCH_SIZE x2 per the gfx950 correction)",
-                         "valu": {"achieved": FLOP_PER_ENV_STEP * N / (kernel_ms * 1e-3) / 1e12, "peak": FP32_VECTOR_PEAK_TFLOPS,
-                                  "unit": "TFLOP/s", "frac": FLOP_PER_ENV_STEP * N / (kernel_ms * 1e-3) / 1e12 / FP32_VECTOR_PEAK_TFLOPS,
+                         "valu": {"achieved": FLOP_PER_ENV_STEP * N * per_launch / (kernel_ms * 1e-3) / 1e12, "peak": FP32_VECTOR_PEAK_TFLOPS,
+                                  "unit": "TFLOP/s", "frac": FLOP_PER_ENV_STEP * N * per_launch / (kernel_ms * 1e-3) / 1e12 / FP32_VECTOR_PEAK_TFLOPS,
                                   "flop_per_env_step": FLOP_PER_ENV_STEP,
                                   "how": "ISA instruction mix of the substep loop x 20 substeps (20 substeps x 1 563 FLOP); "
                                          "one wave per SIMD issues one VALU instruction per ~4-5 cycles, i.e. at most "
@@ -260,7 +275,7 @@ def main():
                                  "contact solve = 13.8k VALU instructions per env-step, 360 of every 691 packed; one wave "
                                  "per SIMD at 65 536 arenas: 1024 waves on 1024 SIMDs); see roofline.valu and "
                                  "DESIGN.md section 4"},
-            "env_only_env_steps_per_s": N / (kernel_ms * 1e-3),
+            "env_only_env_steps_per_s": N * per_launch / (kernel_ms * 1e-3),
         }
         if gathered:
             eps = sum(g.episodes for g in gathered)
