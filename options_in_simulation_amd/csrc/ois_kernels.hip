@@ -384,9 +384,9 @@ OIS_DEV void step_body(const DevConsts& K, const DevBuffers& B, const float* __r
 //    per-step state go to scratch instead and two waves fit on a SIMD. Launched above that size
 //    (measured per policy step, packed: 60.9 -> 56.3 us at 131 072 arenas, 241 -> 219 at 524 288;
 //    scalar 92.9 -> 65.8 at 131 072).
-// At 65 536 arenas the two are equal in an env-only loop (30.3 vs 29.6 us per fused step), but
-// behind the actor's GEMMs the scratch traffic of the second is cold: 67.7 vs 44.5 us per launch
-// under rocprofv3 (profiles/r1_waves_ab.txt), hence the size rule. OIS_STEP_WAVES=1|2 overrides it.
+// At 65 536 arenas the two are equal in an env-only loop (38.3 vs 39.2 us per launch), but behind
+// the actor's GEMMs the scratch traffic of the second is cold: 59.3 vs 39.6 us per launch under
+// rocprofv3 (profiles/r1_waves_ab.txt), hence the size rule. OIS_STEP_WAVES=1|2 overrides it.
 // The terrain kernels lose 2-4 % under the limit (59-110 spills) and always keep the default.
 template <int LPA, bool PK, int NIT>
 __global__ __launch_bounds__(kBlock) void step_kernel(DevConsts K, DevBuffers B, const float* __restrict__ actions,
