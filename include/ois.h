@@ -57,8 +57,10 @@ extern "C" {
 
 /* 2: ois_replay_*, ois_gae, ois_terrain_attach, ois_height_scan, buffers 21-22, a larger workspace
  * (state blobs of version 1 do not load)
- * 3: ois_terrain_attach takes the min-field scratch (one gather per height sample) */
-#define OIS_ABI_VERSION 3
+ * 3: ois_terrain_attach takes the min-field scratch (one gather per height sample)
+ * 4: ois_config: wheel_limit_velocity / wheel_limit_damping (two of the reserved words); state blobs of
+ *    version 3 do not load (the solver and the joint model changed, see docs/SPEC.md 3.3, 3.5) */
+#define OIS_ABI_VERSION 4
 
 /* error codes */
 #define OIS_OK 0
@@ -157,7 +159,10 @@ typedef struct ois_config {
   float max_depenetration_velocity; /* 100                         KAMMA.py:105 */
   float max_angular_velocity; /* 64 rad/s                          origin_v18.py:70 */
   int32_t solver_iterations;  /* 4                                 KAMMA.py:96-97 */
-  int32_t reserved_[8];
+  float wheel_limit_velocity; /* joint velocity limit [rad/s]: <limit velocity="10"/> urdf:117,125,133,141 */
+  float wheel_limit_damping;  /* resistance above the limit [N m s/rad], CALIBRATED with wheel_damping
+                                 (docs/SPEC.md section 3.3, tests/golden/ref_stats.json); 0 = no limit */
+  int32_t reserved_[6];
 } ois_config;
 
 /* Buffer ids for ois_buffer(). Shapes are row-major; N = num_envs. */
@@ -247,6 +252,15 @@ int ois_step(ois_env* env, const float* actions_device, void* stream);
  * reward_sum_device (optional, may be NULL): float [N], receives the sum of the k rewards. */
 int ois_rollout(ois_env* env, int k, int policy, const float* actions_device,
                 float* reward_sum_device, void* stream);
+
+/* Kernel-only timing of the step launches (measurement aid, no reference counterpart). Between
+ * begin and end every ois_step / ois_rollout launch carries a start and a stop event on its own
+ * dispatch packet (hipExtLaunchKernel), so the elapsed time is the kernel's begin -> end as
+ * rocprofv3 --kernel-trace reports it: no launch gap, no marker packets between kernels. end
+ * synchronises with the last profiled launch and returns the summed kernel time and the launch
+ * count. Not for use under HIP-graph capture. */
+int ois_profile_begin(ois_env* env);
+int ois_profile_end(ois_env* env, double* kernel_ms_total, long long* launches);
 
 /* Device pointer + size of one buffer (aliases the workspace). */
 int ois_buffer(ois_env* env, int id, void** ptr_device, size_t* bytes);

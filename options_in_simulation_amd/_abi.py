@@ -1,7 +1,7 @@
 """ctypes mirror of include/ois.h (struct layout, enums). Pure data, no library load."""
 import ctypes as C
 
-ABI_VERSION = 3
+ABI_VERSION = 4
 
 OK, EINVAL, ENOMEM, EHIP, ESTATE = 0, -1, -2, -3, -4
 
@@ -120,7 +120,9 @@ class OisConfig(C.Structure):
         ("max_depenetration_velocity", C.c_float),
         ("max_angular_velocity", C.c_float),
         ("solver_iterations", C.c_int32),
-        ("reserved_", C.c_int32 * 8),
+        ("wheel_limit_velocity", C.c_float),
+        ("wheel_limit_damping", C.c_float),
+        ("reserved_", C.c_int32 * 6),
     ]
 
 

@@ -31,7 +31,7 @@ constexpr int kGroup = 16;  // arenas per reduction group of the reset-event rec
 struct DevConsts {
   // physics (docs/SPEC.md §3)
   float dt, inv_dt, gdt, half_dt, im4, imq, J4x, J4y, J4z, dt_over_Is, dt_over_Iy, rw, rw_over_Is,
-      rw2_over_Is, beta_inv_dt, vdep, maxw, maxw2, damping, wx, wy, cz, com_height;
+      rw2_over_Is, beta_inv_dt, vdep, maxw, maxw2, damping, wlim, climit, wx, wy, cz, com_height;
   float inv4wx, inv4wy;  // 1 / (4 wx), 1 / (4 wy): footprint-plane fit of the terrain contact (SPEC §3.8)
   int iters, nsub;
   // task (KAMMA.py constants, see include/ois.h)

@@ -12,6 +12,7 @@
 // field, NIT solver iterations unrolled at compile time (0 = run-time count). Also here:
 // reset / params / episode-info / stats / height-scan kernels; ois_gae.hip holds the GAE scan.
 #include <hip/hip_runtime.h>
+#include <hip/hip_ext.h>
 
 #include <cmath>
 #include <cstdio>
@@ -46,17 +47,19 @@ OIS_DEV void store_wheels(float4* base, int arena, int h, const float* s) {
 
 template <int LPA>
 OIS_DEV void load_arena(const DevConsts& K, const DevBuffers& B, int i, int h, ArenaT<LPA>& S) {
-  const float4 po = B.pose[i], qu = B.quat[i], lv = B.linvel[i], av = B.angvel[i], cm = B.commands[i];
-  const float4 pr = B.params[i], sa = B.sums_a[i], sb = B.sums_b[i];
+  // issued in the order of first use (vector loads return in order, so a later row never holds up an
+  // earlier one): controller inputs, then what the first substep reads, the episode sums last
+  // (only read after the 20 substeps)
+  const float4 cm = B.commands[i], po = B.pose[i], av = B.angvel[i];
   const int4 ct = B.counters[i];
+  const float4 qu = B.quat[i], lv = B.linvel[i], pr = B.params[i];
+  unpack(cm, S.cmd);
   S.p[0] = po.x; S.p[1] = po.y; S.p[2] = po.z; S.vfwd = po.w;
+  S.w[0] = av.x; S.w[1] = av.y; S.w[2] = av.z; S.prev_ang = av.w;
+  S.ep_buf = ct.x; S.sim_steps = ct.y; S.ep_count = ct.z;
   unpack(qu, S.q);
   S.v[0] = lv.x; S.v[1] = lv.y; S.v[2] = lv.z; S.prev_lin = lv.w;
-  S.w[0] = av.x; S.w[1] = av.y; S.w[2] = av.z; S.prev_ang = av.w;
-  unpack(cm, S.cmd);
-  S.ep_buf = ct.x; S.sim_steps = ct.y; S.ep_count = ct.z;
   S.mu = pr.x; S.n[0] = pr.y; S.n[1] = pr.z; S.n[2] = pr.w;
-  unpack(sa, S.sa); unpack(sb, S.sb);
   load_wheels<LPA>(B.wheel_vel, i, h, S.jv);
   load_wheels<LPA>(B.lam_n, i, h, S.ln);
   load_wheels<LPA>(B.lam_l, i, h, S.l1);
@@ -68,16 +71,18 @@ OIS_DEV void load_arena(const DevConsts& K, const DevBuffers& B, int i, int h, A
     for (int k = 0; k < 4; ++k) S.sc[k] = 0.0f;
     for (int k = 0; k < ArenaT<LPA>::WPL; ++k) S.wt[k] = 0.0f;
   }
+  const float4 sa = B.sums_a[i], sb = B.sums_b[i];
+  unpack(sa, S.sa); unpack(sb, S.sb);
 }
 
 template <int LPA>
-OIS_DEV void store_arena(const DevConsts& K, const DevBuffers& B, int i, int h, const ArenaT<LPA>& S) {
+OIS_DEV void store_arena(const DevConsts& K, const DevBuffers& B, int i, int h, const ArenaT<LPA>& S, bool cmd_dirty) {
   if (h == 0) {  // chassis rows are replicated in the lane pair: one lane writes them
     B.pose[i] = make_float4(S.p[0], S.p[1], S.p[2], S.vfwd);
     B.quat[i] = make_float4(S.q[0], S.q[1], S.q[2], S.q[3]);
     B.linvel[i] = make_float4(S.v[0], S.v[1], S.v[2], S.prev_lin);
     B.angvel[i] = make_float4(S.w[0], S.w[1], S.w[2], S.prev_ang);
-    B.commands[i] = make_float4(S.cmd[0], S.cmd[1], S.cmd[2], S.cmd[3]);
+    if (cmd_dirty) B.commands[i] = make_float4(S.cmd[0], S.cmd[1], S.cmd[2], S.cmd[3]);  // only reset_idx writes commands
     B.counters[i] = make_int4(S.ep_buf, S.sim_steps, S.ep_count, 0);
     B.sums_a[i] = make_float4(S.sa[0], S.sa[1], S.sa[2], S.sa[3]);
     B.sums_b[i] = make_float4(S.sb[0], S.sb[1], S.sb[2], S.sb[3]);
@@ -108,6 +113,7 @@ OIS_DEV void step_body(const DevConsts& K, const DevBuffers& B, const float* __r
   ArenaT<LPA> S;
   load_arena<LPA>(K, B, la, h, S);
   float rsum = 0.0f;
+  bool cmd_dirty = false;
   // terrain tile of this arena (origin xyz; level / type for the curriculum)
   float tor[3] = {0.0f, 0.0f, 0.0f};
   int tlevel = 0, ttype = 0;
@@ -310,6 +316,7 @@ OIS_DEV void step_body(const DevConsts& K, const DevBuffers& B, const float* __r
       }
     }
     if (reset) reset_arena<LPA>(K, gid, wheel0, gamma1, gamma2, S, rc);
+    cmd_dirty |= reset;
     if (!valid) contrib_identity(rc);
     // get_observations (:833); desired_* are views of commands -> post-reset values; clamp: rl_task.py:99
     const float co = K.clip_obs;
@@ -365,7 +372,7 @@ OIS_DEV void step_body(const DevConsts& K, const DevBuffers& B, const float* __r
     if (m != 0ull) group_record<LPA>(B, arena / kGroup, lane, group_any<LPA>(m, lane), rc, S.sim_steps, true);
   }
   if (valid) {
-    store_arena<LPA>(K, B, arena, h, S);
+    store_arena<LPA>(K, B, arena, h, S, cmd_dirty);
     if (reward_sum != nullptr && h == 0) reward_sum[arena] = rsum;
     if constexpr (TER) {
       if (B.ter.curriculum) {
@@ -726,6 +733,9 @@ int validate(const ois_config* c) {
   if (c->mix_mode != OIS_MIX_SWITCH && c->mix_mode != OIS_MIX_BLEND) return fail(OIS_EINVAL, "bad mix_mode");
   if (c->cmd_sampler < 0 || c->cmd_sampler > OIS_CMD_EVAL) return fail(OIS_EINVAL, "bad cmd_sampler");
   if (!(c->max_sim_steps > 0.0f)) return fail(OIS_EINVAL, "max_sim_steps must be positive");
+  if (!(c->baumgarte > 0.0f && c->baumgarte < 1.0f)) return fail(OIS_EINVAL, "baumgarte must be in (0, 1)");
+  if (!(c->wheel_damping >= 0.0f) || !(c->wheel_limit_damping >= 0.0f) || !(c->wheel_limit_velocity >= 0.0f))
+    return fail(OIS_EINVAL, "wheel joint resistance constants must be >= 0");
   return OIS_OK;
 }
 
@@ -751,6 +761,8 @@ void derive(const ois_config* c, DevConsts* K) {
   K->maxw = c->max_angular_velocity;
   K->maxw2 = c->max_angular_velocity * c->max_angular_velocity;
   K->damping = c->wheel_damping;
+  K->wlim = c->wheel_limit_velocity;
+  K->climit = c->wheel_limit_damping;
   K->wx = c->wheel_pos[0];
   K->wy = c->wheel_pos[1];
   K->cz = c->wheel_pos[2] - c->com_height;
@@ -798,6 +810,12 @@ struct ois_env {
   size_t rp_off[OIS_RP_COUNT_], rp_bytes[OIS_RP_COUNT_];
   int rp_head;
   bool rp_filled;
+  // ois_profile_*: start / stop events attached to the step kernel's own dispatch packets
+  bool prof_on;
+  std::vector<hipEvent_t> prof_ev;  // pairs; [2 i] start, [2 i + 1] stop
+  size_t prof_used;                 // pairs handed to launches since ois_profile_begin
+  double prof_ms;                   // kernel time of pairs already folded in (pool wrap-around)
+  long long prof_launches;
 };
 
 namespace {
@@ -858,7 +876,8 @@ int ois_config_default(ois_config* c) {
   c->com_height = (float)com;
   c->wheel_pos[0] = (float)wx; c->wheel_pos[1] = (float)wy; c->wheel_pos[2] = (float)wz;
   c->wheel_radius = 0.1175f; c->wheel_spin_inertia = 0.01f;
-  c->wheel_damping = 0.125f;  // calibrated, not parity
+  // calibrated on the shipped training log, not parity (tools/calibrate_physics.py, tests/golden/ref_stats.json)
+  c->wheel_damping = 0.0f; c->wheel_limit_velocity = 10.0f /* urdf:117 */; c->wheel_limit_damping = 0.6f;
   c->friction = 0.85f; c->baumgarte = 0.2f; c->max_depenetration_velocity = 100.0f;
   c->max_angular_velocity = 64.0f; c->solver_iterations = 4;
   return OIS_OK;
@@ -935,6 +954,7 @@ int ois_create(const ois_config* cfg, int device, void* workspace_device, size_t
   B.env_origins = (float4*)(w + L.off[OIS_BUF_ENV_ORIGINS]); B.terrain_idx = (int4*)(w + L.off[OIS_BUF_TERRAIN_IDX]);
   std::memset(&B.ter, 0, sizeof B.ter);
   e->rp_mem = nullptr; e->rp_head = 0; e->rp_filled = false;
+  e->prof_on = false; e->prof_used = 0; e->prof_ms = 0.0; e->prof_launches = 0;
   // default per-arena parameters: mu = cfg.friction, flat plane n = +z
   hipError_t he = hipMemsetAsync(e->ws, 0, L.total, nullptr);
   if (he == hipSuccess) {
@@ -951,7 +971,34 @@ int ois_create(const ois_config* cfg, int device, void* workspace_device, size_t
   return OIS_OK;
 }
 
-void ois_destroy(ois_env* env) { delete env; }
+void ois_destroy(ois_env* env) {
+  if (!env) return;
+  for (hipEvent_t ev : env->prof_ev) (void)hipEventDestroy(ev);
+  delete env;
+}
+
+int ois_profile_begin(ois_env* e) {
+  if (!e) return fail(OIS_EINVAL, "null env");
+  e->prof_on = true; e->prof_used = 0; e->prof_ms = 0.0; e->prof_launches = 0;
+  return OIS_OK;
+}
+
+int ois_profile_end(ois_env* e, double* kernel_ms_total, long long* launches) {
+  if (!e || !kernel_ms_total || !launches) return fail(OIS_EINVAL, "null argument");
+  if (!e->prof_on) return fail(OIS_ESTATE, "ois_profile_end without ois_profile_begin");
+  HIP_TRY(hipSetDevice(e->device));
+  const size_t live = e->prof_used < e->prof_ev.size() / 2 ? e->prof_used : e->prof_ev.size() / 2;
+  double ms_total = e->prof_ms;
+  for (size_t i = 0; i < live; ++i) {
+    float ms = 0.0f;
+    HIP_TRY(hipEventSynchronize(e->prof_ev[2 * i + 1]));
+    HIP_TRY(hipEventElapsedTime(&ms, e->prof_ev[2 * i], e->prof_ev[2 * i + 1]));
+    ms_total += ms;
+  }
+  *kernel_ms_total = ms_total; *launches = e->prof_launches;
+  e->prof_on = false; e->prof_used = 0; e->prof_ms = 0.0; e->prof_launches = 0;
+  return OIS_OK;
+}
 
 int ois_reset(ois_env* e, uint64_t seed, void* stream) {
   if (!e) return fail(OIS_EINVAL, "null env");
@@ -966,11 +1013,45 @@ int ois_reset(ois_env* e, uint64_t seed, void* stream) {
   return OIS_OK;
 }
 
+// next (start, stop) event pair of the profiling pool; a wrapped pool folds its oldest pair in first
+static int prof_next_pair(ois_env* e, hipEvent_t* a, hipEvent_t* b) {
+  constexpr size_t kPairs = 4096;
+  const size_t i = e->prof_used % kPairs;
+  if (e->prof_used >= kPairs) {  // reuse: the pair was recorded kPairs launches ago
+    float ms = 0.0f;
+    HIP_TRY(hipEventSynchronize(e->prof_ev[2 * i + 1]));
+    HIP_TRY(hipEventElapsedTime(&ms, e->prof_ev[2 * i], e->prof_ev[2 * i + 1]));
+    e->prof_ms += ms;
+  } else if (e->prof_ev.size() < 2 * (i + 1)) {
+    hipEvent_t x, y;
+    HIP_TRY(hipEventCreate(&x));
+    HIP_TRY(hipEventCreate(&y));
+    e->prof_ev.push_back(x); e->prof_ev.push_back(y);
+  }
+  *a = e->prof_ev[2 * i]; *b = e->prof_ev[2 * i + 1];
+  e->prof_used += 1; e->prof_launches += 1;
+  return OIS_OK;
+}
+
 static int launch_steps(ois_env* e, int k, int policy, const float* actions, float* reward_sum, void* stream) {
   HIP_TRY(hipSetDevice(e->device));
-#define OIS_LAUNCH(KERNEL_, LPA_)                                                                                  \
-  hipLaunchKernelGGL((KERNEL_), dim3((LPA_ * e->N + kBlock - 1) / kBlock), dim3(kBlock), 0, (hipStream_t)stream, e->K, \
-                     e->B, actions, reward_sum, e->N, k, policy, e->rp_head)
+  hipEvent_t ev0 = nullptr, ev1 = nullptr;
+  if (e->prof_on) {
+    int rc = prof_next_pair(e, &ev0, &ev1);
+    if (rc != OIS_OK) return rc;
+  }
+  // with profiling on, the events ride on the kernel's dispatch packet: their elapsed time is the
+  // kernel's own begin -> end, what rocprofv3 --kernel-trace reports (no launch gap, no marker packets)
+#define OIS_LAUNCH(KERNEL_, LPA_)                                                                                      \
+  do {                                                                                                                 \
+    const dim3 grid_((LPA_ * e->N + kBlock - 1) / kBlock), block_(kBlock);                                             \
+    if (e->prof_on)                                                                                                    \
+      hipExtLaunchKernelGGL((KERNEL_), grid_, block_, 0, (hipStream_t)stream, ev0, ev1, 0, e->K, e->B, actions,         \
+                            reward_sum, e->N, k, policy, e->rp_head);                                                  \
+    else                                                                                                               \
+      hipLaunchKernelGGL((KERNEL_), grid_, block_, 0, (hipStream_t)stream, e->K, e->B, actions, reward_sum, e->N, k,    \
+                         policy, e->rp_head);                                                                          \
+  } while (0)
   // instantiations: lanes per arena (2 = experiment), packed wheel pairs, height-field terrain
   // (ois_terrain_attach refuses LPA = 2), solver iterations unrolled (the default 4) or run-time
   const bool it4 = e->K.iters == 4;

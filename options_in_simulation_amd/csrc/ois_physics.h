@@ -166,7 +166,8 @@ OIS_DEV void substep(const DevConsts& K, const DevTerrain& T, int wheel0, PhysT<
   float Tq[W];
   OIS_WH {
     const float jv = S.spin[k] - wb[1];
-    Tq[k] = __builtin_fmaf(-K.damping, jv, S.tau[k]);
+    const float over = jv - __builtin_amdgcn_fmed3f(jv, -K.wlim, K.wlim);  // signed excess over the joint velocity limit
+    Tq[k] = __builtin_fmaf(-K.climit, over, __builtin_fmaf(-K.damping, jv, S.tau[k]));
     S.spin[k] = __builtin_fmaf(K.dt_over_Is, Tq[k], S.spin[k]);
   }
   const float Tsum = sum_wheels<LPA>(Tq);
@@ -193,7 +194,7 @@ OIS_DEV void substep(const DevConsts& K, const DevTerrain& T, int wheel0, PhysT<
     const float cy = (gk & 2) ? -K.wy : K.wy;
     const float rx = __builtin_fmaf(K.rw, dx, cx), ry = cy, rz = __builtin_fmaf(K.rw, dz, cz);
     const float gap = (TER ? np - off[k] : np) + __builtin_fmaf(nb[2], rz, __builtin_fmaf(nb[1], ry, nb[0] * rx));
-    b[k] = gap >= 0.0f ? -(gap * K.inv_dt) : fminf(-(gap * K.beta_inv_dt), K.vdep);
+    b[k] = __builtin_fminf(__builtin_fminf(-(gap * K.inv_dt), -(gap * K.beta_inv_dt)), K.vdep);  // = gap >= 0 ? -gap/dt : min(-beta gap/dt, vdep) for 0 < beta < 1
     an[k][0] = __builtin_fmaf(ry, nb[2], -(rz * nb[1]));
     an[k][1] = __builtin_fmaf(rz, nb[0], -(rx * nb[2]));
     an[k][2] = __builtin_fmaf(rx, nb[1], -(ry * nb[0]));
@@ -214,12 +215,13 @@ OIS_DEV void substep(const DevConsts& K, const DevTerrain& T, int wheel0, PhysT<
     m2[k] = REX ? exact_rcp(k2) : newton_rcp(m2[k], k2);
   }
   // Chassis linear velocity: the contact frame (n, t1, t2) is orthonormal and the split inverse
-  // mass is a scalar, so an impulse along one row never changes the linear part of another row's
-  // velocity: no private copies of v_b; a row reads the shared v_b and the averaging pass adds
-  // (1/m) * frame * (sum of the pass's impulses over the 4 contacts) (docs/SPEC.md 3.5).
-  const float qnx = K.imq * nb[0], qny = K.imq * nb[1], qnz = K.imq * nb[2];
-  const float q1x = K.imq * t1x, q1z = K.imq * t1z;
-  const float q2x = K.imq * t2x, q2y = K.imq * t2y, q2z = K.imq * t2z;
+  // mass is a scalar, so an impulse along one row changes only that row's own component of the
+  // linear velocity: the solve carries the three projections (un, u1, u2) of v_b on the frame; a
+  // row reads its component, the averaging pass adds (1/m) * (sum of the pass's impulses of that
+  // row), and v_b is rebuilt from the frame once, after the last pass (docs/SPEC.md 3.5).
+  float un = __builtin_fmaf(nb[2], vb[2], __builtin_fmaf(nb[1], vb[1], nb[0] * vb[0]));
+  float u1 = __builtin_fmaf(t1z, vb[2], t1x * vb[0]);
+  float u2 = __builtin_fmaf(t2z, vb[2], __builtin_fmaf(t2y, vb[1], t2x * vb[0]));
   float ox[W], oy[W], oz[W];
   // warm start: one mass-split averaging pass with the cached impulses
   OIS_WH ox[k] = __builtin_fmaf(S.l2[k], Ja2[k][0], __builtin_fmaf(S.l1[k], Ja1[k][0], __builtin_fmaf(S.ln[k], Jan[k][0], wb[0])));
@@ -228,25 +230,18 @@ OIS_DEV void substep(const DevConsts& K, const DevTerrain& T, int wheel0, PhysT<
   OIS_WH S.spin[k] = __builtin_fmaf(-K.rw_over_Is, S.l1[k], S.spin[k]);
   {
     const float Sn = sum_wheels<LPA>(S.ln), S1 = sum_wheels<LPA>(S.l1), S2 = sum_wheels<LPA>(S.l2);
-    vb[0] = __builtin_fmaf(S2, q2x, __builtin_fmaf(S1, q1x, __builtin_fmaf(Sn, qnx, vb[0])));
-    vb[1] = __builtin_fmaf(S2, q2y, __builtin_fmaf(Sn, qny, vb[1]));
-    vb[2] = __builtin_fmaf(S2, q2z, __builtin_fmaf(S1, q1z, __builtin_fmaf(Sn, qnz, vb[2])));
+    un = __builtin_fmaf(K.imq, Sn, un); u1 = __builtin_fmaf(K.imq, S1, u1); u2 = __builtin_fmaf(K.imq, S2, u2);
   }
   wb[0] = average4<LPA>(ox); wb[1] = average4<LPA>(oy); wb[2] = average4<LPA>(oz);
   const int iters = NIT > 0 ? NIT : K.iters;
 #pragma unroll
   for (int it = 0; it < iters; ++it) {
     float u[W], dl[W], nw[W], lim[W], dn[W], d1[W];
-    // linear part of the three row velocities, shared by the four contacts
-    const float unv = __builtin_fmaf(nb[2], vb[2], __builtin_fmaf(nb[1], vb[1], nb[0] * vb[0]));
-    const float u1v = __builtin_fmaf(t1z, vb[2], t1x * vb[0]);
-    const float u2v = __builtin_fmaf(t2z, vb[2], __builtin_fmaf(t2y, vb[1], t2x * vb[0]));
     // normal row
-    OIS_WH u[k] = __builtin_fmaf(an[k][0], wb[0], unv);
+    OIS_WH u[k] = __builtin_fmaf(an[k][0], wb[0], un);
     OIS_WH u[k] = __builtin_fmaf(an[k][1], wb[1], u[k]);
     OIS_WH u[k] = __builtin_fmaf(an[k][2], wb[2], u[k]);
-    OIS_WH dl[k] = (b[k] - u[k]) * mn[k];
-    OIS_WH nw[k] = fmaxf(S.ln[k] + dl[k], 0.0f);
+    OIS_WH nw[k] = fmaxf(__builtin_fmaf(b[k] - u[k], mn[k], S.ln[k]), 0.0f);
     OIS_WH dn[k] = nw[k] - S.ln[k];
     OIS_WH S.ln[k] = nw[k];
     OIS_WH ox[k] = __builtin_fmaf(dn[k], Jan[k][0], wb[0]);
@@ -254,12 +249,11 @@ OIS_DEV void substep(const DevConsts& K, const DevTerrain& T, int wheel0, PhysT<
     OIS_WH oz[k] = __builtin_fmaf(dn[k], Jan[k][2], wb[2]);
     OIS_WH lim[k] = S.mu * S.ln[k];
     // longitudinal row (couples the wheel spin)
-    OIS_WH u[k] = __builtin_fmaf(a1[k][0], ox[k], u1v);
+    OIS_WH u[k] = __builtin_fmaf(a1[k][0], ox[k], u1);
     OIS_WH u[k] = __builtin_fmaf(a1[k][1], oy[k], u[k]);
     OIS_WH u[k] = __builtin_fmaf(a1[k][2], oz[k], u[k]);
     OIS_WH u[k] = __builtin_fmaf(-K.rw, S.spin[k], u[k]);
-    OIS_WH dl[k] = -(u[k] * m1[k]);
-    OIS_WH nw[k] = fminf(fmaxf(S.l1[k] + dl[k], -lim[k]), lim[k]);
+    OIS_WH nw[k] = fminf(fmaxf(__builtin_fmaf(-u[k], m1[k], S.l1[k]), -lim[k]), lim[k]);
     OIS_WH d1[k] = nw[k] - S.l1[k];
     OIS_WH S.l1[k] = nw[k];
     OIS_WH ox[k] = __builtin_fmaf(d1[k], Ja1[k][0], ox[k]);
@@ -267,11 +261,10 @@ OIS_DEV void substep(const DevConsts& K, const DevTerrain& T, int wheel0, PhysT<
     OIS_WH oz[k] = __builtin_fmaf(d1[k], Ja1[k][2], oz[k]);
     OIS_WH S.spin[k] = __builtin_fmaf(-K.rw_over_Is, d1[k], S.spin[k]);
     // lateral row
-    OIS_WH u[k] = __builtin_fmaf(a2[k][0], ox[k], u2v);
+    OIS_WH u[k] = __builtin_fmaf(a2[k][0], ox[k], u2);
     OIS_WH u[k] = __builtin_fmaf(a2[k][1], oy[k], u[k]);
     OIS_WH u[k] = __builtin_fmaf(a2[k][2], oz[k], u[k]);
-    OIS_WH dl[k] = -(u[k] * m2[k]);
-    OIS_WH nw[k] = fminf(fmaxf(S.l2[k] + dl[k], -lim[k]), lim[k]);
+    OIS_WH nw[k] = fminf(fmaxf(__builtin_fmaf(-u[k], m2[k], S.l2[k]), -lim[k]), lim[k]);
     OIS_WH dl[k] = nw[k] - S.l2[k];
     OIS_WH S.l2[k] = nw[k];
     OIS_WH ox[k] = __builtin_fmaf(dl[k], Ja2[k][0], ox[k]);
@@ -280,12 +273,14 @@ OIS_DEV void substep(const DevConsts& K, const DevTerrain& T, int wheel0, PhysT<
     // mass-splitting average over the 4 contacts
     {
       const float Sn = sum_wheels<LPA>(dn), S1 = sum_wheels<LPA>(d1), S2 = sum_wheels<LPA>(dl);
-      vb[0] = __builtin_fmaf(S2, q2x, __builtin_fmaf(S1, q1x, __builtin_fmaf(Sn, qnx, vb[0])));
-      vb[1] = __builtin_fmaf(S2, q2y, __builtin_fmaf(Sn, qny, vb[1]));
-      vb[2] = __builtin_fmaf(S2, q2z, __builtin_fmaf(S1, q1z, __builtin_fmaf(Sn, qnz, vb[2])));
+      un = __builtin_fmaf(K.imq, Sn, un); u1 = __builtin_fmaf(K.imq, S1, u1); u2 = __builtin_fmaf(K.imq, S2, u2);
     }
     wb[0] = average4<LPA>(ox); wb[1] = average4<LPA>(oy); wb[2] = average4<LPA>(oz);
   }
+  // v_b from its projections on the (orthonormal) contact frame; t1 has no y component
+  vb[0] = __builtin_fmaf(t2x, u2, __builtin_fmaf(t1x, u1, nb[0] * un));
+  vb[1] = __builtin_fmaf(t2y, u2, nb[1] * un);
+  vb[2] = __builtin_fmaf(t2z, u2, __builtin_fmaf(t1z, u1, nb[2] * un));
   // linear velocity back to the world frame, velocity caps (origin_v18.py:65-70), integrate
   rot(R, vb, S.v);
   const float w2 = __builtin_fmaf(wb[2], wb[2], __builtin_fmaf(wb[1], wb[1], wb[0] * wb[0]));

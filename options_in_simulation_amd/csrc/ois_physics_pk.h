@@ -82,7 +82,8 @@ OIS_DEV void substep_pk(const DevConsts& K, const DevTerrain& T, PhysT<1>& S) {
   f2 Tq[2];
   OIS_PR {
     const f2 jv = spin[j] - wb[1];
-    Tq[j] = fma2(-K.damping, jv, tau[j]);
+    const f2 over = jv - clamp2(jv, (f2)(K.wlim));  // signed excess over the joint velocity limit
+    Tq[j] = fma2(-K.climit, over, fma2(-K.damping, jv, tau[j]));
     spin[j] = fma2(K.dt_over_Is, Tq[j], spin[j]);
   }
   const float Tsum = sum4(Tq);
@@ -109,9 +110,10 @@ OIS_DEV void substep_pk(const DevConsts& K, const DevTerrain& T, PhysT<1>& S) {
     const float rx = __builtin_fmaf(K.rw, dx, cx);
     // gap = np + fma(nb2, rz, fma(nb1, ry, nb0 * rx))
     const f2 gap = (TER ? np - ld2(off, j) : (f2)(np)) + fma2(nb[2], (f2)(rz), fma2(nb[1], ry, nb[0] * rx));
+    const f2 bA = -(gap * K.inv_dt), bB = -(gap * K.beta_inv_dt);  // min3 = the case split of substep<> (0 < beta < 1)
     f2 bb;
-    bb.x = gap.x >= 0.0f ? -(gap.x * K.inv_dt) : fminf(-(gap.x * K.beta_inv_dt), K.vdep);
-    bb.y = gap.y >= 0.0f ? -(gap.y * K.inv_dt) : fminf(-(gap.y * K.beta_inv_dt), K.vdep);
+    bb.x = __builtin_fminf(__builtin_fminf(bA.x, bB.x), K.vdep);
+    bb.y = __builtin_fminf(__builtin_fminf(bA.y, bB.y), K.vdep);
     b[j] = bb;
     an[j][0] = fma2(ry, nb[2], -(rz * nb[1]));
     an[j][1] = (f2)(__builtin_fmaf(rz, nb[0], -(rx * nb[2])));
@@ -136,10 +138,10 @@ OIS_DEV void substep_pk(const DevConsts& K, const DevTerrain& T, PhysT<1>& S) {
       m2[j] = newton_rcp2(m2[j], k2);
     }
   }
-  // shared chassis linear velocity, impulse sums in the averaging pass (see substep<> in ois_physics.h)
-  const float qnx = K.imq * nb[0], qny = K.imq * nb[1], qnz = K.imq * nb[2];
-  const float q1x = K.imq * t1x, q1z = K.imq * t1z;
-  const float q2x = K.imq * t2x, q2y = K.imq * t2y, q2z = K.imq * t2z;
+  // the solve carries the projections (un, u1, u2) of v_b on the contact frame (see substep<> in ois_physics.h)
+  float un = __builtin_fmaf(nb[2], vb[2], __builtin_fmaf(nb[1], vb[1], nb[0] * vb[0]));
+  float u1 = __builtin_fmaf(t1z, vb[2], t1x * vb[0]);
+  float u2 = __builtin_fmaf(t2z, vb[2], __builtin_fmaf(t2y, vb[1], t2x * vb[0]));
   f2 ox[2], oy[2], oz[2];
   // warm start: one mass-split averaging pass with the cached impulses
   OIS_PR ox[j] = fma2(l2[j], Ja2[j][0], fma2(l1[j], Ja1[j][0], fma2(ln[j], Jan[j][0], wb[0])));
@@ -148,25 +150,18 @@ OIS_DEV void substep_pk(const DevConsts& K, const DevTerrain& T, PhysT<1>& S) {
   OIS_PR spin[j] = fma2(-K.rw_over_Is, l1[j], spin[j]);
   {
     const float Sn = sum4(ln), S1 = sum4(l1), S2 = sum4(l2);
-    vb[0] = __builtin_fmaf(S2, q2x, __builtin_fmaf(S1, q1x, __builtin_fmaf(Sn, qnx, vb[0])));
-    vb[1] = __builtin_fmaf(S2, q2y, __builtin_fmaf(Sn, qny, vb[1]));
-    vb[2] = __builtin_fmaf(S2, q2z, __builtin_fmaf(S1, q1z, __builtin_fmaf(Sn, qnz, vb[2])));
+    un = __builtin_fmaf(K.imq, Sn, un); u1 = __builtin_fmaf(K.imq, S1, u1); u2 = __builtin_fmaf(K.imq, S2, u2);
   }
   wb[0] = 0.25f * sum4(ox); wb[1] = 0.25f * sum4(oy); wb[2] = 0.25f * sum4(oz);
   const int iters = NIT > 0 ? NIT : K.iters;
 #pragma unroll
   for (int it = 0; it < iters; ++it) {
     f2 u[2], dl[2], nw[2], lim[2], dn[2], d1[2];
-    // linear part of the three row velocities, shared by the four contacts
-    const float unv = __builtin_fmaf(nb[2], vb[2], __builtin_fmaf(nb[1], vb[1], nb[0] * vb[0]));
-    const float u1v = __builtin_fmaf(t1z, vb[2], t1x * vb[0]);
-    const float u2v = __builtin_fmaf(t2z, vb[2], __builtin_fmaf(t2y, vb[1], t2x * vb[0]));
     // normal row
-    OIS_PR u[j] = fma2(an[j][0], wb[0], unv);
+    OIS_PR u[j] = fma2(an[j][0], wb[0], un);
     OIS_PR u[j] = fma2(an[j][1], wb[1], u[j]);
     OIS_PR u[j] = fma2(an[j][2], wb[2], u[j]);
-    OIS_PR dl[j] = (b[j] - u[j]) * mn[j];
-    OIS_PR nw[j] = max2(ln[j] + dl[j], (f2)(0.0f));
+    OIS_PR nw[j] = max2(fma2(b[j] - u[j], mn[j], ln[j]), (f2)(0.0f));
     OIS_PR dn[j] = nw[j] - ln[j];
     OIS_PR ln[j] = nw[j];
     OIS_PR ox[j] = fma2(dn[j], Jan[j][0], wb[0]);
@@ -174,12 +169,11 @@ OIS_DEV void substep_pk(const DevConsts& K, const DevTerrain& T, PhysT<1>& S) {
     OIS_PR oz[j] = fma2(dn[j], Jan[j][2], wb[2]);
     OIS_PR lim[j] = S.mu * ln[j];
     // longitudinal row (couples the wheel spin)
-    OIS_PR u[j] = fma2(a1[j][0], ox[j], u1v);
+    OIS_PR u[j] = fma2(a1[j][0], ox[j], u1);
     OIS_PR u[j] = fma2(a1[j][1], oy[j], u[j]);
     OIS_PR u[j] = fma2(a1[j][2], oz[j], u[j]);
     OIS_PR u[j] = fma2(-K.rw, spin[j], u[j]);
-    OIS_PR dl[j] = -(u[j] * m1[j]);
-    OIS_PR nw[j] = clamp2(l1[j] + dl[j], lim[j]);
+    OIS_PR nw[j] = clamp2(fma2(-u[j], m1[j], l1[j]), lim[j]);
     OIS_PR d1[j] = nw[j] - l1[j];
     OIS_PR l1[j] = nw[j];
     OIS_PR ox[j] = fma2(d1[j], Ja1[j][0], ox[j]);
@@ -187,11 +181,10 @@ OIS_DEV void substep_pk(const DevConsts& K, const DevTerrain& T, PhysT<1>& S) {
     OIS_PR oz[j] = fma2(d1[j], Ja1[j][2], oz[j]);
     OIS_PR spin[j] = fma2(-K.rw_over_Is, d1[j], spin[j]);
     // lateral row
-    OIS_PR u[j] = fma2(a2[j][0], ox[j], u2v);
+    OIS_PR u[j] = fma2(a2[j][0], ox[j], u2);
     OIS_PR u[j] = fma2(a2[j][1], oy[j], u[j]);
     OIS_PR u[j] = fma2(a2[j][2], oz[j], u[j]);
-    OIS_PR dl[j] = -(u[j] * m2[j]);
-    OIS_PR nw[j] = clamp2(l2[j] + dl[j], lim[j]);
+    OIS_PR nw[j] = clamp2(fma2(-u[j], m2[j], l2[j]), lim[j]);
     OIS_PR dl[j] = nw[j] - l2[j];
     OIS_PR l2[j] = nw[j];
     OIS_PR ox[j] = fma2(dl[j], Ja2[j][0], ox[j]);
@@ -200,12 +193,14 @@ OIS_DEV void substep_pk(const DevConsts& K, const DevTerrain& T, PhysT<1>& S) {
     // mass-splitting average over the 4 contacts
     {
       const float Sn = sum4(dn), S1 = sum4(d1), S2 = sum4(dl);
-      vb[0] = __builtin_fmaf(S2, q2x, __builtin_fmaf(S1, q1x, __builtin_fmaf(Sn, qnx, vb[0])));
-      vb[1] = __builtin_fmaf(S2, q2y, __builtin_fmaf(Sn, qny, vb[1]));
-      vb[2] = __builtin_fmaf(S2, q2z, __builtin_fmaf(S1, q1z, __builtin_fmaf(Sn, qnz, vb[2])));
+      un = __builtin_fmaf(K.imq, Sn, un); u1 = __builtin_fmaf(K.imq, S1, u1); u2 = __builtin_fmaf(K.imq, S2, u2);
     }
     wb[0] = 0.25f * sum4(ox); wb[1] = 0.25f * sum4(oy); wb[2] = 0.25f * sum4(oz);
   }
+  // v_b from its projections on the (orthonormal) contact frame; t1 has no y component
+  vb[0] = __builtin_fmaf(t2x, u2, __builtin_fmaf(t1x, u1, nb[0] * un));
+  vb[1] = __builtin_fmaf(t2y, u2, nb[1] * un);
+  vb[2] = __builtin_fmaf(t2z, u2, __builtin_fmaf(t1z, u1, nb[2] * un));
   OIS_PR {
     st2(S.spin, j, clamp2(spin[j], (f2)(K.maxw)));
     st2(S.ln, j, ln[j]); st2(S.l1, j, l1[j]); st2(S.l2, j, l2[j]);

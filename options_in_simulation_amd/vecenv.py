@@ -142,6 +142,16 @@ class NativeEnv:
         _native.check(self.L.ois_rollout(self.h, int(k), int(policy), a_ptr, r_ptr, _stream_ptr(self.device)))
         self.policy_steps += int(k)
 
+    def profile_begin(self):
+        """start kernel-only timing of the step launches (include/ois.h ois_profile_begin)"""
+        _native.check(self.L.ois_profile_begin(self.h))
+
+    def profile_end(self) -> Tuple[float, int]:
+        """(summed kernel milliseconds, launches) since profile_begin; synchronises"""
+        ms, n = C.c_double(), C.c_longlong()
+        _native.check(self.L.ois_profile_end(self.h, C.byref(ms), C.byref(n)))
+        return ms.value, n.value
+
     def randomize_params(self, mu_lo: float, mu_hi: float, slopes=()):
         s = np.ascontiguousarray(slopes, dtype=np.float32)
         ptr = s.ctypes.data_as(C.POINTER(C.c_float)) if s.size else None

@@ -338,6 +338,7 @@ typedef struct {
   float J4[3];       /* 4 / body_inertia */
   float dt_over_Is, dt_over_Iy, rw, rw_over_Is, rw2_over_Is;
   float beta_inv_dt, vdep, maxw, maxw2, damping;
+  float wlim, climit;   /* joint velocity limit and the resistance above it (SPEC 3.3) */
   float cx[4], cy[4], cz; /* wheel centres relative to the composite COM, order fl, rl, fr, rr */
   float inv4wx, inv4wy;   /* 1 / (4 |x|), 1 / (4 |y|) of the wheel centres: footprint-plane fit (SPEC §3.8) */
   int iters;
@@ -361,6 +362,8 @@ static void derive(const ois_config* c, derived* D) {
   D->maxw = c->max_angular_velocity;
   D->maxw2 = c->max_angular_velocity * c->max_angular_velocity;
   D->damping = c->wheel_damping;
+  D->wlim = c->wheel_limit_velocity;
+  D->climit = c->wheel_limit_damping;
   /* env order fl, rl, fr, rr (KAMMA.py:157, 623); URDF: left = +y, front = +x (urdf:112-142) */
   const float sx[4] = {1.0f, -1.0f, 1.0f, -1.0f};
   const float sy[4] = {1.0f, 1.0f, -1.0f, -1.0f};
@@ -502,7 +505,8 @@ static void substep(const derived* D, float mu, const float n_in[3], const float
   float T[4];
   for (int k = 0; k < 4; ++k) {
     float jv = spin[k] - wb[1];
-    T[k] = fmaf(-D->damping, jv, tau[k]);
+    float over = jv - fminf(fmaxf(jv, -D->wlim), D->wlim); /* signed excess over the joint velocity limit */
+    T[k] = fmaf(-D->climit, over, fmaf(-D->damping, jv, tau[k]));
     spin[k] = fmaf(D->dt_over_Is, T[k], spin[k]);
   }
   float Tsum = (T[0] + T[1]) + (T[2] + T[3]);
@@ -527,7 +531,9 @@ static void substep(const derived* D, float mu, const float n_in[3], const float
     float cx = D->cx[k], cy = D->cy[k], cz = D->cz;
     float rx = fmaf(D->rw, dx, cx), ry = cy, rz = fmaf(D->rw, dz, cz);
     float gap = (TR ? np - off[k] : np) + fmaf(nb[2], rz, fmaf(nb[1], ry, nb[0] * rx));
-    b[k] = gap >= 0.0f ? -(gap * D->inv_dt) : fminf(-(gap * D->beta_inv_dt), D->vdep);
+    /* gap >= 0: -gap/dt (speculative contact); gap < 0: min(-beta gap/dt, vdep). With 0 < beta < 1 the
+     * first is the smaller of the two products exactly when gap >= 0, so both cases are one min3 */
+    b[k] = fminf(fminf(-(gap * D->inv_dt), -(gap * D->beta_inv_dt)), D->vdep);
     an[k][0] = fmaf(ry, nb[2], -(rz * nb[1]));
     an[k][1] = fmaf(rz, nb[0], -(rx * nb[2]));
     an[k][2] = fmaf(rx, nb[1], -(ry * nb[0]));
@@ -549,13 +555,14 @@ static void substep(const derived* D, float mu, const float n_in[3], const float
     m1[k] = rex ? 1.0f / k1 : newton_rcp(m1[k], k1);
     m2[k] = rex ? 1.0f / k2 : newton_rcp(m2[k], k2);
   }
-  /* chassis linear velocity: the contact frame (n, t1, t2) is orthonormal and the split inverse
-   * mass is a scalar, so an impulse along one row never changes the linear part of another
-   * row's velocity. The private copies of v_b are therefore never formed: a row reads the shared
-   * v_b, and the averaging pass adds (1/m) * frame * (sum of this pass's impulses) (SPEC 3.5). */
-  float qnx = D->imq * nb[0], qny = D->imq * nb[1], qnz = D->imq * nb[2];
-  float q1x = D->imq * t1x, q1z = D->imq * t1z;
-  float q2x = D->imq * t2x, q2y = D->imq * t2y, q2z = D->imq * t2z;
+  /* Chassis linear velocity: the contact frame (n, t1, t2) is orthonormal and the split inverse
+   * mass is a scalar, so an impulse along one row changes only that row's own linear velocity
+   * component. The solve therefore carries the three PROJECTIONS (un, u1, u2) of v_b on the frame
+   * instead of v_b: a row reads its component, the averaging pass adds (1/m) * (sum of the pass's
+   * impulses of that row), and v_b is rebuilt from the frame once, after the last pass (SPEC 3.5). */
+  float un = fmaf(nb[2], vb[2], fmaf(nb[1], vb[1], nb[0] * vb[0]));
+  float u1 = fmaf(t1z, vb[2], t1x * vb[0]);
+  float u2 = fmaf(t2z, vb[2], fmaf(t2y, vb[1], t2x * vb[0]));
 
   /* warm start: re-apply the impulses accumulated in the previous substep (they persist
    * across policy steps in OIS_BUF_LAMBDA_*), as one more mass-split averaging pass */
@@ -568,41 +575,32 @@ static void substep(const derived* D, float mu, const float n_in[3], const float
     float Sn = (ln[0] + ln[1]) + (ln[2] + ln[3]);
     float S1 = (l1[0] + l1[1]) + (l1[2] + l1[3]);
     float S2 = (l2[0] + l2[1]) + (l2[2] + l2[3]);
-    vb[0] = fmaf(S2, q2x, fmaf(S1, q1x, fmaf(Sn, qnx, vb[0])));
-    vb[1] = fmaf(S2, q2y, fmaf(Sn, qny, vb[1]));
-    vb[2] = fmaf(S2, q2z, fmaf(S1, q1z, fmaf(Sn, qnz, vb[2])));
+    un = fmaf(D->imq, Sn, un); u1 = fmaf(D->imq, S1, u1); u2 = fmaf(D->imq, S2, u2);
     for (int j = 0; j < 3; ++j) wb[j] = 0.25f * ((wl[0][j] + wl[1][j]) + (wl[2][j] + wl[3][j]));
   }
   for (int it = 0; it < D->iters; ++it) {
     float wl[4][3], dn[4], d1[4], d2[4];
-    /* linear part of the three row velocities, shared by the four contacts */
-    float unv = fmaf(nb[2], vb[2], fmaf(nb[1], vb[1], nb[0] * vb[0]));
-    float u1v = fmaf(t1z, vb[2], t1x * vb[0]);
-    float u2v = fmaf(t2z, vb[2], fmaf(t2y, vb[1], t2x * vb[0]));
     for (int k = 0; k < 4; ++k) {
       float ox = wb[0], oy = wb[1], oz = wb[2];
       /* normal row */
-      float u = fmaf(an[k][2], oz, fmaf(an[k][1], oy, fmaf(an[k][0], ox, unv)));
-      float dl = (b[k] - u) * mn[k];
-      float nw = fmaxf(ln[k] + dl, 0.0f);
-      dl = nw - ln[k];
+      float u = fmaf(an[k][2], oz, fmaf(an[k][1], oy, fmaf(an[k][0], ox, un)));
+      float nw = fmaxf(fmaf(b[k] - u, mn[k], ln[k]), 0.0f);
+      float dl = nw - ln[k];
       ln[k] = nw;
       dn[k] = dl;
       ox = fmaf(dl, Jan[k][0], ox); oy = fmaf(dl, Jan[k][1], oy); oz = fmaf(dl, Jan[k][2], oz);
       float lim = mu * ln[k];
       /* longitudinal row (couples the wheel spin) */
-      u = fmaf(-D->rw, spin[k], fmaf(a1[k][2], oz, fmaf(a1[k][1], oy, fmaf(a1[k][0], ox, u1v))));
-      dl = -(u * m1[k]);
-      nw = fminf(fmaxf(l1[k] + dl, -lim), lim);
+      u = fmaf(-D->rw, spin[k], fmaf(a1[k][2], oz, fmaf(a1[k][1], oy, fmaf(a1[k][0], ox, u1))));
+      nw = fminf(fmaxf(fmaf(-u, m1[k], l1[k]), -lim), lim);
       dl = nw - l1[k];
       l1[k] = nw;
       d1[k] = dl;
       ox = fmaf(dl, Ja1[k][0], ox); oy = fmaf(dl, Ja1[k][1], oy); oz = fmaf(dl, Ja1[k][2], oz);
       spin[k] = fmaf(-D->rw_over_Is, dl, spin[k]);
       /* lateral row */
-      u = fmaf(a2[k][2], oz, fmaf(a2[k][1], oy, fmaf(a2[k][0], ox, u2v)));
-      dl = -(u * m2[k]);
-      nw = fminf(fmaxf(l2[k] + dl, -lim), lim);
+      u = fmaf(a2[k][2], oz, fmaf(a2[k][1], oy, fmaf(a2[k][0], ox, u2)));
+      nw = fminf(fmaxf(fmaf(-u, m2[k], l2[k]), -lim), lim);
       dl = nw - l2[k];
       l2[k] = nw;
       d2[k] = dl;
@@ -612,11 +610,13 @@ static void substep(const derived* D, float mu, const float n_in[3], const float
     float Sn = (dn[0] + dn[1]) + (dn[2] + dn[3]);
     float S1 = (d1[0] + d1[1]) + (d1[2] + d1[3]);
     float S2 = (d2[0] + d2[1]) + (d2[2] + d2[3]);
-    vb[0] = fmaf(S2, q2x, fmaf(S1, q1x, fmaf(Sn, qnx, vb[0])));
-    vb[1] = fmaf(S2, q2y, fmaf(Sn, qny, vb[1]));
-    vb[2] = fmaf(S2, q2z, fmaf(S1, q1z, fmaf(Sn, qnz, vb[2])));
+    un = fmaf(D->imq, Sn, un); u1 = fmaf(D->imq, S1, u1); u2 = fmaf(D->imq, S2, u2);
     for (int j = 0; j < 3; ++j) wb[j] = 0.25f * ((wl[0][j] + wl[1][j]) + (wl[2][j] + wl[3][j]));
   }
+  /* rebuild v_b from its projections on the (orthonormal) contact frame; t1 has no y component */
+  vb[0] = fmaf(t2x, u2, fmaf(t1x, u1, nb[0] * un));
+  vb[1] = fmaf(t2y, u2, nb[1] * un);
+  vb[2] = fmaf(t2z, u2, fmaf(t1z, u1, nb[2] * un));
   /* back to the world frame, velocity caps (origin_v18.py:65-70), integrate */
   rot(R, vb, v);
   float w2 = fmaf(wb[2], wb[2], fmaf(wb[1], wb[1], wb[0] * wb[0]));
@@ -707,6 +707,7 @@ int orc_create(const ois_config* cfg, orc_env** out) {
   if (cfg->num_envs <= 0) return fail(OIS_EINVAL, "num_envs must be > 0");
   if (cfg->action_dim != 4 && cfg->action_dim != 2 && cfg->action_dim != 1) return fail(OIS_EINVAL, "action_dim must be 4, 2 or 1");
   if (cfg->solver_iterations < 1 || cfg->solver_iterations > 16) return fail(OIS_EINVAL, "solver_iterations out of range");
+  if (!(cfg->baumgarte > 0.0f && cfg->baumgarte < 1.0f)) return fail(OIS_EINVAL, "baumgarte must be in (0, 1)");
   orc_env* e = (orc_env*)zalloc(sizeof *e);
   if (!e) return fail(OIS_ENOMEM, "host alloc");
   e->cfg = *cfg;

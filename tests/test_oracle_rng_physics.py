@@ -66,12 +66,14 @@ def test_rest_equilibrium_is_exact():
 
 
 def test_constant_torque_steady_state():
-    """equal torque tau on 4 wheels: steady wheel speed = tau / c (viscous joint damping),
-    rolling without slip, no yaw."""
+    """equal torque tau on 4 wheels: steady wheel speed where the joint resistance
+    c1 w + c2 (w - w_lim) balances tau (docs/SPEC.md 3.3), rolling without slip, no yaw."""
     cfg = build_config(variant="KAMMA_eval", num_envs=2)
     a = np.full((2, 4), 1.0 / 3.0, np.float32)  # tau = 1 N m
     env = run(cfg, 80, a)
-    w = 1.0 / cfg.wheel_damping
+    c1, c2, wl = cfg.wheel_damping, cfg.wheel_limit_damping, cfg.wheel_limit_velocity
+    w = (1.0 + c2 * wl) / (c1 + c2)
+    assert w > wl
     np.testing.assert_allclose(env.buffer(_abi.BUF_WHEEL_VEL), w, rtol=1e-3)
     np.testing.assert_allclose(env.buffer(_abi.BUF_POSE)[:, 3], w * cfg.wheel_radius, rtol=1e-3)  # v_forward
     np.testing.assert_allclose(env.buffer(_abi.BUF_ANGVEL)[:, 2], 0.0, atol=1e-4)
