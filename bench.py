@@ -12,15 +12,26 @@ arena ids keep every stream identical to a 1-GPU run), ONE all-gather of the epi
 statistics per logging interval (800 steps, train_kamma_4d_nofifo_random_RLIL.py:176) — the
 path's only exchange.
 
+`python bench.py --gpus N` with N > 1 and no torch.distributed environment launches its own N
+ranks (a child `python -m torch.distributed.run`, started before anything in this process touches
+the GPU; the parent never initialises it and never execs); under the driver's own
+torch.distributed.run launch it is simply one of the ranks.
+
 Prints ONE JSON line on rank 0 (contract in the task statement) with two extra objects:
-  roofline      HBM roofline of the step kernel: algorithmic bytes (352 B/env-step, SURVEY.md
-                §8d) x arenas / mean kernel time measured with events on the launch stream.
+  roofline      of the step kernel, against the ceiling that binds it (fp32 VALU issue; the HBM
+                figure on the algorithmic 352 B/env-step of SURVEY.md section 8d sits beside it).
+                The kernel time is measured live: start / stop events on the kernel's own dispatch
+                packets over the timed region (ois_profile_*), i.e. what rocprofv3 --kernel-trace
+                reports for the same launches.
   cpu_baseline  the CPU oracle (oracle/, test infrastructure) timed on this host's cores on a
                 bounded sample of the same workload (rank 0, N=1 only).
 """
 import argparse
+import hashlib
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -29,13 +40,23 @@ sys.path.insert(0, ROOT)
 
 ALGO_BYTES_PER_ENV_STEP = 352.0
 HBM_PEAK_GBS = 8000.0             # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
-# secondary ceiling (SURVEY.md §8(d) asks to say which one binds): fp32 vector peak, and the
-# arithmetic one env-step performs, counted from the ISA of the packed step kernel's substep loop
-# (691 VALU instructions = 217 v_pk_fma + 143 v_pk_add/mul + 331 scalar ops = 1 563 FLOP per
-# arena-substep; x 20 substeps; pre/post-physics not counted)
+# The ceiling that binds (SURVEY.md §8(d) asks to say which): fp32 vector peak, and the arithmetic
+# one env-step performs, counted from the ISA of the packed step kernel's substep loop
+# (tools/isa_census.py: 614 executed VALU instructions, 344 of them packed = 1 440 FLOP per
+# arena-substep with fma = 2; x 20 substeps; pre/post-physics not counted)
 FP32_VECTOR_PEAK_TFLOPS = 157.3   # MI355X_MICROARCH.md
-FLOP_PER_ENV_STEP = 20 * 1563.0
+FLOP_PER_ENV_STEP = 20 * 1440.0
 ARENAS_PER_GPU = 65536
+KERNEL_SOURCES = ("ois_kernels.hip", "ois_device.h", "ois_physics.h", "ois_physics_pk.h", "Makefile")
+
+
+def kernel_source_hash():
+    """sha256 over the step kernel's sources: ties profiles/*_pmc_traffic.json to the kernel at HEAD"""
+    h = hashlib.sha256()
+    for name in KERNEL_SOURCES:
+        with open(os.path.join(ROOT, "options_in_simulation_amd", "csrc", name), "rb") as f:
+            h.update(f.read())
+    return h.hexdigest()
 
 
 def build_actor(torch, device):
@@ -78,19 +99,28 @@ def measured_copy_gbs(torch, device, mb=1024, reps=10):
     return 2.0 * n * 4 * reps / (e0.elapsed_time(e1) * 1e-3) / 1e9
 
 
-def pmc_traffic(n_arenas):
-    """HBM bytes per step_kernel launch from the committed PMC run (bench.py cannot collect
-    counters on itself). Only returned when the profile was taken at this arena count."""
+def pmc_traffic(n_arenas, profile="r2_pmc_traffic.json"):
+    """HBM bytes per step_kernel launch from the committed PMC run (bench.py cannot collect counters
+    on itself). Quoted only when the profile was taken at this arena count AND on the kernel sources
+    of this checkout (sha256 recorded by tools/profile_round.sh); returns (bytes | None, provenance)."""
+    path = os.path.join(ROOT, "profiles", profile)
     try:
-        d = json.load(open(os.path.join(ROOT, "profiles", "r1_pmc_traffic.json")))
-        return d["hbm_bytes_per_launch"] if int(d["arenas"]) == int(n_arenas) else None
-    except (OSError, KeyError, ValueError):
-        return None
+        d = json.load(open(path))
+    except (OSError, ValueError):
+        return None, {"file": "profiles/" + profile, "status": "missing"}
+    prov = {"file": "profiles/" + profile, "profile_head": d.get("git_head"), "kernel_src_sha256": d.get("kernel_src_sha256")}
+    if int(d.get("arenas", -1)) != int(n_arenas):
+        prov["status"] = f"not quoted: profile taken at {d.get('arenas')} arenas"
+        return None, prov
+    if d.get("kernel_src_sha256") != kernel_source_hash():
+        prov["status"] = "not quoted: the kernel sources changed since the profile was taken"
+        return None, prov
+    prov["status"] = "quoted: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes, FETCH_SIZE x2 per the gfx950 correction"
+    return d["hbm_bytes_per_launch"], prov
 
 
 def cpu_baseline(n_arenas, seconds_target=12.0):
     """time the oracle on the host cores: same task, same actor-free step (random actions)."""
-    import numpy as np
     from options_in_simulation_amd import _abi, build_config
     from oracle.binding import OracleEnv
     cores = usable_cores()
@@ -125,7 +155,31 @@ def cpu_baseline(n_arenas, seconds_target=12.0):
                               "sample": f"{n1} arenas x {steps1} policy steps, {dt1:.1f} s"}}
 
 
-def main():
+def free_port():
+    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def spawn_command(gpus, argv, port):
+    """the rank launch of a bare `python bench.py --gpus N`: the command line the driver itself uses"""
+    return [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={gpus}",
+            "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__), *argv]
+
+
+def maybe_self_launch(args, argv):
+    """--gpus N > 1 outside a torch.distributed launch: start the N ranks as a child process and
+    pass its exit code on. Nothing before this point imports torch or touches the GPU, and the
+    parent only waits: it never initialises the GPU and never execs."""
+    if args.gpus <= 1 or "RANK" in os.environ or "LOCAL_RANK" in os.environ:
+        return
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env.setdefault("OMP_NUM_THREADS", "4")
+    sys.exit(subprocess.call(spawn_command(args.gpus, argv, free_port()), env=env))
+
+
+def parse_args(argv):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=300)
@@ -134,6 +188,7 @@ def main():
     ap.add_argument("--log-interval", type=int, default=800)
     ap.add_argument("--no-actor", action="store_true", help="env-only loop (fixed random actions)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-extras", action="store_true", help="skip the env-only / fused side measurements after the timed region")
     ap.add_argument("--fused", type=int, default=0, metavar="K",
                     help="env-only, K policy steps per launch with the in-kernel random-torque policy (ois_rollout; "
                          "BASELINE.json configs[1]'s policy at this arena count): one timed 'step' = one launch of K steps")
@@ -142,20 +197,78 @@ def main():
                     help="BASELINE.json configs[3]: per-arena friction U(0.5, 1.0) and plane slope from the generator's set")
     ap.add_argument("--terrain", action="store_true",
                     help="configs[3] on the reference's full terrain family: 6 x 2 random tiles, wheel contact on the height field")
-    args = ap.parse_args()
+    return ap.parse_args(argv)
+
+
+def side_measurements(torch, env, _abi, fixed_actions, N, launches=200, fused_k=20, fused_launches=20):
+    """after the timed region, same env (its state simply moves on): the env-only single-launch loop
+    and the fused 20-step rollout — the two lines that show the kernel rather than the actor"""
+    res = {}
+    for name, fn, per in (("single_launch", lambda: env.step(fixed_actions), 1),
+                          (f"fused_{fused_k}", lambda: env.rollout(fused_k, _abi.POLICY_RANDOM), fused_k)):
+        n = launches if per == 1 else fused_launches
+        for _ in range(3):
+            fn()
+        torch.cuda.synchronize()
+        env.profile_begin()
+        t0 = time.perf_counter()
+        for _ in range(n):
+            fn()
+        torch.cuda.synchronize()
+        wall = time.perf_counter() - t0
+        ms, cnt = env.profile_end()
+        sec = ms / cnt * 1e-3
+        res[name] = {"env_steps_per_s_wall": N * per * n / wall, "kernel_us_per_policy_step": sec / per * 1e6,
+                     "valu_frac": FLOP_PER_ENV_STEP * N * per / sec / 1e12 / FP32_VECTOR_PEAK_TFLOPS,
+                     "hbm_frac_algorithmic": ALGO_BYTES_PER_ENV_STEP * N * per / sec / 1e9 / HBM_PEAK_GBS, "launches": n}
+    return res
+
+
+def dry_run(args, world, rank):
+    """OIS_BENCH_DRYRUN=1: the launch / rendezvous / collective plumbing of a run without a GPU
+    (tests/test_bench_launch.py): every rank joins a gloo group, the rank table goes through the
+    same all-gather as in a real run, rank 0 prints one JSON line."""
+    import torch
+    import torch.distributed as dist
+    from options_in_simulation_amd.dist import shard_range
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+    lo, hi = shard_range(args.arenas * world, rank, world)
+    mine = torch.tensor([rank, -1, lo, hi - lo], dtype=torch.int64)
+    allr = torch.empty(world * 4, dtype=torch.int64)
+    if world > 1:
+        dist.all_gather_into_tensor(allr, mine)
+    else:
+        allr.copy_(mine)
+    if rank == 0:
+        print(json.dumps({"dryrun": True, "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+                          "config": {"ranks": dist.get_world_size() if world > 1 else 1,
+                                     "rank_table": [{"rank": r, "device": d, "arena_offset": o, "arenas": n}
+                                                    for r, d, o, n in allr.view(world, 4).tolist()]}}), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+def main(argv=None):
+    argv = list(sys.argv[1:] if argv is None else argv)
+    args = parse_args(argv)
+    maybe_self_launch(args, argv)
 
     import torch
     import torch.distributed as dist
     from options_in_simulation_amd import _abi, build_config
-    from options_in_simulation_amd.dist import gather_stats
+    from options_in_simulation_amd.dist import gather_stats, merge_stats
     from options_in_simulation_amd.vecenv import NativeEnv
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if args.gpus > 1 and world != args.gpus:
-        raise SystemExit(f"--gpus {args.gpus} needs a torch.distributed.run launch with {args.gpus} ranks "
-                         f"(WORLD_SIZE={world})")
+    if args.gpus != world:
+        raise SystemExit(f"--gpus {args.gpus} does not match the launch's WORLD_SIZE={world}")
+    if os.environ.get("OIS_BENCH_DRYRUN"):
+        return dry_run(args, world, rank)
     # one process per GPU. OIS_DIST_BACKEND=gloo + fewer GPUs than ranks is only for rehearsing the
     # multi-process path on a 1-GPU box (ranks then share device 0; RCCL refuses duplicate GPUs).
     backend = os.environ.get("OIS_DIST_BACKEND", "nccl")
@@ -188,29 +301,17 @@ def main():
     obs = env.buffer(_abi.BUF_OBS)
     fixed_actions = torch.rand((N, cfg.action_dim), device=device, generator=torch.Generator(device).manual_seed(1))
 
-    ev_pairs = []
-
     K_fused = max(0, args.fused)
     if K_fused:
         actor = None
 
-    def launch(a):
+    def one_step():
+        with torch.no_grad():
+            a = fixed_actions if actor is None else actor(obs)
         if K_fused:
             env.rollout(K_fused, _abi.POLICY_RANDOM)
         else:
             env.step(a)
-
-    def one_step(timed):
-        with torch.no_grad():
-            a = fixed_actions if actor is None else actor(obs)
-        if timed:
-            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            e0.record()
-            launch(a)
-            e1.record()
-            ev_pairs.append((e0, e1))
-        else:
-            launch(a)
 
     def barrier():
         if world > 1:
@@ -218,32 +319,48 @@ def main():
         torch.cuda.synchronize()
 
     for _ in range(args.warmup):
-        one_step(False)
+        one_step()
     if world > 1:  # warm the collective too
         gather_stats(env.stats(reset_after=True), device)
     barrier()
+    env.profile_begin()  # start / stop events on every step kernel's own dispatch packet
     t0 = time.perf_counter()
     gathered = None
     for s in range(args.steps):
-        one_step(True)
+        one_step()
         if (s + 1) % args.log_interval == 0 or s + 1 == args.steps:
             st = env.stats(reset_after=True)           # one tiny D2H per logging interval
             gathered = gather_stats(st, device) if world > 1 else [st]
     barrier()
     elapsed = time.perf_counter() - t0
+    kernel_ms_total, launches = env.profile_end()
     if world > 1:
         t = torch.tensor([elapsed], dtype=torch.float64, device=comm_device)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
+        # who took part: every rank's (rank, device, arena_offset, arenas) through the same collective
+        mine = torch.tensor([rank, dev_index, cfg.arena_offset, N], dtype=torch.int64, device=comm_device)
+        allr = torch.empty(world * 4, dtype=torch.int64, device=comm_device)
+        dist.all_gather_into_tensor(allr, mine)
+        rank_table = allr.view(world, 4).cpu().tolist()
+    else:
+        rank_table = [[0, dev_index, int(cfg.arena_offset), N]]
 
-    kernel_ms = sum(a.elapsed_time(b) for a, b in ev_pairs) / max(1, len(ev_pairs))
+    kernel_ms = kernel_ms_total / max(1, launches)
     per_launch = max(1, K_fused)
     total_env_steps = float(N) * world * args.steps * per_launch
     value = total_env_steps / elapsed
 
     if rank == 0:
-        achieved = ALGO_BYTES_PER_ENV_STEP * N * per_launch / (kernel_ms * 1e-3) / 1e9
+        flops = FLOP_PER_ENV_STEP * N * per_launch / (kernel_ms * 1e-3) / 1e12
+        hbm = ALGO_BYTES_PER_ENV_STEP * N * per_launch / (kernel_ms * 1e-3) / 1e9
         copy_gbs = measured_copy_gbs(torch, device)  # after the timed region
+        traffic, traffic_prov = (None, {"status": "not quoted for this workload"}) if (args.terrain or K_fused) else pmc_traffic(N)
+        gamma_note = ""
+        if args.variant in ("KAMMA", "KAMMA_medium", "KAMMA_curr1", "KAMMA_curr2") and actor is not None:
+            g = 1.0 - (args.warmup + args.steps + 1) / float(cfg.max_sim_steps)
+            gamma_note = (f"; gamma1 >= {g:.4f} over the timed window, so the switch executes the expert's torques on nearly "
+                          "every step and the actor's output is computed but rarely applied (same cost either way)")
         out = {
             "metric": "env-steps/sec at 65 536 parallel arenas; achieved HBM GB/s vs roofline",
             "value": value, "unit": "env-steps/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -253,34 +370,41 @@ def main():
                                    + (f"in-kernel random-torque policy, {K_fused} policy steps per launch (env only)" if K_fused else
                                       "fixed random actions (env only)" if actor is None else
                                       "scripted actor MLP 6-512-512-128-4 (fp32 PyTorch-ROCm) inference in-loop")
-                                   + (" [BASELINE.json configs[3]]" if (args.domain_rand or args.terrain) else " [BASELINE.json configs[2]]"),
+                                   + (" [BASELINE.json configs[3]]" if (args.domain_rand or args.terrain) else " [BASELINE.json configs[2]]")
+                                   + gamma_note,
                        "arenas_per_gpu": N, "substeps_per_step": cfg.decimation + cfg.extra_substeps,
                        "solver_iterations": cfg.solver_iterations, "sharding": f"arenas x{world}, no data-path collective",
-                       "stats_allgather_every": args.log_interval},
-            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": None if (args.terrain or K_fused) else pmc_traffic(N),
-                         "kernel": "step_kernel", "kernel_ms": kernel_ms,
-                         "algorithmic_bytes_per_launch": ALGO_BYTES_PER_ENV_STEP * N * per_launch,
-                         "measured_copy": {"GB/s": copy_gbs, "frac": achieved / copy_gbs,
-                                           "what": "1 GiB device-to-device torch copy on this GPU, read + write bytes / time"},
-                         "traffic_source": "profiles/r1_pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, "
-                                           "separate passes, FETCH_SIZE x2 per the gfx950 correction)",
-                         "valu": {"achieved": FLOP_PER_ENV_STEP * N * per_launch / (kernel_ms * 1e-3) / 1e12, "peak": FP32_VECTOR_PEAK_TFLOPS,
-                                  "unit": "TFLOP/s", "frac": FLOP_PER_ENV_STEP * N * per_launch / (kernel_ms * 1e-3) / 1e12 / FP32_VECTOR_PEAK_TFLOPS,
-                                  "flop_per_env_step": FLOP_PER_ENV_STEP,
-                                  "how": "ISA instruction mix of the substep loop x 20 substeps (20 substeps x 1 563 FLOP); "
-                                         "one wave per SIMD issues one VALU instruction per ~4-5 cycles, i.e. at most "
-                                         "~50 % of the vector peak with packed fp32"},
-                         "note": "HBM is not the limiter: the kernel is fp32-VALU issue bound (20 substeps x 4-iteration "
-                                 "contact solve = 13.8k VALU instructions per env-step, 360 of every 691 packed; one wave "
-                                 "per SIMD at 65 536 arenas: 1024 waves on 1024 SIMDs); see roofline.valu and "
-                                 "DESIGN.md section 4"},
+                       "stats_allgather_every": args.log_interval,
+                       "ranks": dist.get_world_size() if world > 1 else 1,
+                       "backend": (dist.get_backend() + (" (RCCL)" if backend == "nccl" else "")) if world > 1 else "none",
+                       "rank_table": [{"rank": r, "device": d, "arena_offset": o, "arenas": n} for r, d, o, n in rank_table]},
+            "roofline": {"bound": "valu", "achieved": flops, "peak": FP32_VECTOR_PEAK_TFLOPS, "unit": "TFLOP/s",
+                         "frac": flops / FP32_VECTOR_PEAK_TFLOPS, "traffic": traffic,
+                         "kernel": "step_kernel", "kernel_ms": kernel_ms, "kernel_launches": launches,
+                         "kernel_ms_how": "mean over the timed region of hipEventElapsedTime(start, stop) with both events "
+                                          "attached to the kernel's dispatch packet (hipExtLaunchKernel): kernel begin -> end as "
+                                          "rocprofv3 --kernel-trace measures it, no launch gap",
+                         "flop_per_env_step": FLOP_PER_ENV_STEP,
+                         "flop_how": "ISA instruction mix of the substep loop x 20 substeps (tools/isa_census.py: 1 440 FLOP per "
+                                     "arena-substep, fma = 2); one wave per SIMD issues one VALU instruction per ~4 cycles, "
+                                     "i.e. at most ~50 % of the vector peak with the kernel's half-packed mix",
+                         "hbm": {"achieved": hbm, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": hbm / HBM_PEAK_GBS,
+                                 "algorithmic_bytes_per_launch": ALGO_BYTES_PER_ENV_STEP * N * per_launch,
+                                 "measured_copy": {"GB/s": copy_gbs, "frac": hbm / copy_gbs,
+                                                   "what": "1 GiB device-to-device torch copy on this GPU, read + write bytes / time"}},
+                         "traffic_provenance": traffic_prov,
+                         "note": "fp32-VALU issue bound, not HBM bound: 20 substeps x 4-iteration contact solve = ~12.6k VALU "
+                                 "instructions per env-step, more than half of them packed; one wave per SIMD at 65 536 arenas "
+                                 "(1024 waves on 1024 SIMDs). BASELINE.md's >= 50 % HBM target would need <= 140 lane-instructions "
+                                 "per arena-substep; DESIGN.md section 4"},
             "env_only_env_steps_per_s": N * per_launch / (kernel_ms * 1e-3),
         }
         if gathered:
-            eps = sum(g.episodes for g in gathered)
-            out["episode_stats"] = {"episodes": eps,
-                                    "return_mean": (sum(g.return_sum for g in gathered) / eps) if eps else None}
+            m = merge_stats(gathered)
+            out["episode_stats"] = {"episodes": m["episodes"], "return_mean": m["return_mean"], "return_std": m["return_std"],
+                                    "episodes_per_rank": [g.episodes for g in gathered]}
+        if not args.no_extras and not K_fused and not args.terrain:
+            out["env_only"] = side_measurements(torch, env, _abi, fixed_actions, N)
         if world == 1 and not args.no_cpu_baseline:
             try:
                 out["cpu_baseline"] = cpu_baseline(N)

@@ -59,7 +59,8 @@ extern "C" {
  * (state blobs of version 1 do not load)
  * 3: ois_terrain_attach takes the min-field scratch (one gather per height sample)
  * 4: ois_config: wheel_limit_velocity / wheel_limit_damping (two of the reserved words); state blobs of
- *    version 3 do not load (the solver and the joint model changed, see docs/SPEC.md 3.3, 3.5) */
+ *    version 3 do not load (the solver and the joint model changed, see docs/SPEC.md 3.3, 3.5);
+ *    OIS_CMD_LEVEL, OIS_BUF_CMD_FRACTION, ois_profile_* */
 #define OIS_ABI_VERSION 4
 
 /* error codes */
@@ -87,6 +88,10 @@ extern "C" {
 #define OIS_CMD_BOX 1  /* KAMMA_curr1.py:577-598 */
 #define OIS_CMD_GRID 2 /* KAMMA_curr2.py:602-640 */
 #define OIS_CMD_EVAL 3 /* KAMMA_eval.py:545-550 */
+#define OIS_CMD_LEVEL 4 /* terrain.curriculum: the per-terrain-level generators of sample_velocity_command
+                           (KAMMA.py:533-567), re-drawn for EVERY arena after EVERY step (KAMMA.py:719-725) and
+                           not at a reset (KAMMA.py:490). Also switched on by ois_terrain_attach with
+                           curriculum != 0. Costs one small extra launch per policy step. */
 
 /* rollout policies */
 #define OIS_POLICY_ZERO 0     /* actions == 0                                  */
@@ -162,7 +167,8 @@ typedef struct ois_config {
   float wheel_limit_velocity; /* joint velocity limit [rad/s]: <limit velocity="10"/> urdf:117,125,133,141 */
   float wheel_limit_damping;  /* resistance above the limit [N m s/rad], CALIBRATED with wheel_damping
                                  (docs/SPEC.md section 3.3, tests/golden/ref_stats.json); 0 = no limit */
-  int32_t reserved_[6];
+  float curriculum_threshold_high; /* 10.0: self.threshold_high, the divisor of `fraction` (KAMMA.py:269, 498) */
+  int32_t reserved_[5];
 } ois_config;
 
 /* Buffer ids for ois_buffer(). Shapes are row-major; N = num_envs. */
@@ -190,6 +196,8 @@ enum ois_buffer_id {
   OIS_BUF_LAMBDA_T = 20,   /* float [N,4]  cached lateral friction impulses */
   OIS_BUF_ENV_ORIGINS = 21, /* float [N,4] env_origins xyz of the arena's terrain tile (KAMMA.py:397, 529); 0 = no terrain */
   OIS_BUF_TERRAIN_IDX = 22, /* int32 [N,4] terrain_levels, terrain_types (KAMMA.py:342-347), -, - */
+  OIS_BUF_CMD_FRACTION = 23, /* float [N]  self.fraction: r1 episode sum / threshold_high as of the last step in which
+                                 ANY arena of this environment was reset (KAMMA.py:498); OIS_CMD_LEVEL only */
   OIS_BUF_COUNT_
 };
 

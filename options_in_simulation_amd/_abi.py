@@ -8,13 +8,13 @@ OK, EINVAL, ENOMEM, EHIP, ESTATE = 0, -1, -2, -3, -4
 MIX_SWITCH, MIX_BLEND = 0, 1
 GAMMA_SCHEDULE, GAMMA_CONST = 0, 1
 GUIDE_EXECUTED, GUIDE_POLICY = 0, 1
-CMD_RAND, CMD_BOX, CMD_GRID, CMD_EVAL = 0, 1, 2, 3
+CMD_RAND, CMD_BOX, CMD_GRID, CMD_EVAL, CMD_LEVEL = 0, 1, 2, 3, 4
 POLICY_ZERO, POLICY_RANDOM, POLICY_EXTERNAL = 0, 1, 2
 
 (BUF_OBS, BUF_REW, BUF_DONE, BUF_TIMEOUT, BUF_WHEEL_TORQS, BUF_POSE, BUF_QUAT, BUF_LINVEL,
  BUF_ANGVEL, BUF_WHEEL_VEL, BUF_COMMANDS, BUF_COUNTERS, BUF_SUMS_A, BUF_SUMS_B, BUF_PARAMS,
  BUF_EPISODE_INFO, BUF_ENV0_DIAG, BUF_SUMS_C, BUF_LAMBDA_N, BUF_LAMBDA_L, BUF_LAMBDA_T,
- BUF_ENV_ORIGINS, BUF_TERRAIN_IDX, BUF_COUNT) = range(24)
+ BUF_ENV_ORIGINS, BUF_TERRAIN_IDX, BUF_CMD_FRACTION, BUF_COUNT) = range(25)
 HEIGHT_POINTS = 140
 
 EPISODE_INFO_LEN = 32
@@ -122,7 +122,8 @@ class OisConfig(C.Structure):
         ("solver_iterations", C.c_int32),
         ("wheel_limit_velocity", C.c_float),
         ("wheel_limit_damping", C.c_float),
-        ("reserved_", C.c_int32 * 6),
+        ("curriculum_threshold_high", C.c_float),
+        ("reserved_", C.c_int32 * 5),
     ]
 
 

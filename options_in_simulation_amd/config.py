@@ -215,6 +215,9 @@ def build_config(task_cfg: Optional[Dict[str, Any]] = None, variant: str = "KAMM
         c.cmd_sampler = _abi.CMD_EVAL
     for k, v in var.items():
         setattr(c, k, v)
+    if terrain.get("curriculum"):  # sample_velocity_command tests self.curriculum first (KAMMA.py:533)
+        c.cmd_sampler = _abi.CMD_LEVEL
+    c.curriculum_threshold_high = 10.0                            # KAMMA.py:269
 
     ctrl, learn = env["control"], env["learn"]
     c.sim_dt = float(sim["dt"])                                   # KAMMA.py:259

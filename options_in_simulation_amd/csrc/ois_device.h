@@ -45,6 +45,9 @@ struct DevConsts {
       max_episode_length;
   uint32_t seed_lo, seed_hi;
   int64_t arena_offset;
+  // per-level command generators (OIS_CMD_LEVEL): Python doubles of the reference kept as doubles
+  double cmd_dt, cmd_episode_s;
+  float cmd_thr_high;
 };
 
 // height-field terrain (include/ois.h ois_terrain_attach); on == 0: the per-arena plane of `params`
@@ -78,6 +81,9 @@ struct DevBuffers {
   float4* env_origins;
   int4* terrain_idx;
   DevTerrain ter;
+  // OIS_CMD_LEVEL: self.fraction [N] and the sim_steps value of the last step in which any arena reset
+  float* cmd_fraction;
+  int32_t* reset_stamp;
 };
 
 // ---------------------------------------------------------------- RNG -----------------
@@ -96,7 +102,7 @@ OIS_DEV void philox4x32_10(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, u
   o[0] = c0; o[1] = c1; o[2] = c2; o[3] = c3;
 }
 OIS_DEV float u01(uint32_t x) { return (float)(x >> 8) * 5.9604644775390625e-08f; }
-enum { PURPOSE_MASK = 0, PURPOSE_RESET_A = 1, PURPOSE_RESET_B = 2, PURPOSE_ACTION = 3, PURPOSE_PARAMS = 4, PURPOSE_RESET_C = 5 };
+enum { PURPOSE_MASK = 0, PURPOSE_RESET_A = 1, PURPOSE_RESET_B = 2, PURPOSE_ACTION = 3, PURPOSE_PARAMS = 4, PURPOSE_RESET_C = 5, PURPOSE_CMD = 6 };
 OIS_DEV void draw4(const DevConsts& K, int64_t gid, uint32_t step, uint32_t purpose, float u[4]) {
   uint32_t o[4];
   philox4x32_10((uint32_t)((uint64_t)gid & 0xffffffffu), (uint32_t)((uint64_t)gid >> 32), step, purpose,
@@ -151,6 +157,56 @@ OIS_DEV float normal_det(float u1, float u2) {  // u1, u2 in [0, 1) -> N(0, 1)
   float s, c;
   sincos_det(6.28318530717958647692f * t, s, c);
   return r * c;
+}
+
+// Deterministic sin for |x| < ~1e4 (cephes sinf reduction by pi/4, the kernels of sincos_det) and the
+// per-terrain-level command generators of sample_velocity_command (KAMMA.py:533-567): mirrors of
+// the oracle's orc_sin / orc_level_command, bit for bit (doubles where the reference has Python doubles).
+OIS_DEV float sin_det(float x) {
+  float sign = 1.0f;
+  if (x < 0.0f) { x = -x; sign = -1.0f; }
+  int j = (int)(1.27323954473516f * x);
+  float y = (float)j;
+  if (j & 1) { j += 1; y += 1.0f; }
+  j &= 7;
+  if (j > 3) { sign = -sign; j -= 4; }
+  const float r = __builtin_fmaf(-y, 3.77489497744594108e-8f, __builtin_fmaf(-y, 2.4187564849853515625e-4f, __builtin_fmaf(-y, 0.78515625f, x)));
+  const float z = r * r;
+  float v;
+  if (j == 1 || j == 2) {
+    float pc = __builtin_fmaf(z, 2.443315711809948e-5f, -1.388731625493765e-3f);
+    pc = __builtin_fmaf(z, pc, 4.166664568298827e-2f);
+    v = __builtin_fmaf(z * z, pc, __builtin_fmaf(-0.5f, z, 1.0f));
+  } else {
+    float ps = __builtin_fmaf(z, -1.9515295891e-4f, 8.3321608736e-3f);
+    ps = __builtin_fmaf(z, ps, -1.6666654611e-1f);
+    v = __builtin_fmaf(r * z, ps, r);
+  }
+  return sign * v;
+}
+OIS_DEV void level_command(int level, float fraction, int step_counter, float z, double dt, double episode_length_s, float& cmd_x,
+                           float& cmd_yaw) {
+  if (level == 0) {
+    const float sigma = 0.01f + 0.09f * fraction;  // :538
+    const float x = 0.5f + sigma * z;               // :539
+    cmd_x = 0.0f; cmd_yaw = x > 0.0f ? x : 0.0f;    // :541 return 0.0, max(x_vel, 0.0)
+  } else if (level == 1) {
+    const float freq = 0.01f + 0.09f * fraction;   // :546
+    const double t = (double)step_counter * dt;     // :550
+    const float sn = sin_det(freq * (float)t);      // :551
+    float x;
+    if (fraction > 0.5f) { const float amp = 0.1f + 0.4f * fraction; x = 0.5f + amp * sn; }  // :548-549
+    else x = (float)(0.5 + 0.1 * (double)sn);
+    cmd_x = x > 0.0f ? x : 0.0f; cmd_yaw = 0.0f;
+  } else if (level == 2) {
+    const double t = (double)step_counter * dt;     // :558
+    const float nz = 0.0f + (0.5f * fraction) * z;  // :560-561 torch.normal(mean=0.0, std=Noise)
+    const float x = (float)((double)nz + 0.5 * t / episode_length_s);
+    cmd_x = x > 0.0f ? x : 0.0f; cmd_yaw = 0.0f;
+  } else {
+    const float x = 0.5f + 0.1f * z;                // :566
+    cmd_x = x > 0.0f ? x : 0.0f; cmd_yaw = 0.0f;
+  }
 }
 
 // ---------------------------------------------------------------- quaternions ---------
@@ -313,6 +369,7 @@ OIS_DEV void reset_arena(const DevConsts& K, int64_t gid, int wheel0, float gamm
   const float keep = sqrtf(cx * cx + cy * cy) > 0.25f ? 1.0f : 0.0f;  // :458
   S.cmd[1] = cy * keep;
   S.cmd[3] = ch * keep;
+  const float cmd2_kept = S.cmd[2] * keep;  // :458 on the value commands[:, 2] had (only the level mode keeps it)
   float x_vel = rand_span(K.cmd_x_lo, K.cmd_x_span, u[6]);  // :571 (u[7]: discarded omega draw :572)
   if (K.cmd_sampler == OIS_CMD_BOX) {  // KAMMA_curr1.py:577-598
     const float progress = fminf(1.0f, (float)S.sim_steps / K.max_sim_steps);
@@ -336,6 +393,10 @@ OIS_DEV void reset_arena(const DevConsts& K, int64_t gid, int wheel0, float gamm
   }
   S.cmd[0] = x_vel > 0.0f ? x_vel : 0.0f;  // :575, :495
   S.cmd[2] = 0.0f;                         // :574, :496
+  if (K.cmd_sampler == OIS_CMD_LEVEL) {    // `if not self.curriculum:` skips the re-draw (:490)
+    S.cmd[0] = cx * keep;
+    S.cmd[2] = cmd2_kept;
+  }
   float R[9];
   rotmat(S.q, R);
   S.p[0] = __builtin_fmaf(R[2], K.com_height, px);

@@ -112,7 +112,10 @@ OIS_DEV void step_body(const DevConsts& K, const DevBuffers& B, const float* __r
 
   ArenaT<LPA> S;
   load_arena<LPA>(K, B, la, h, S);
-  float rsum = 0.0f;
+  // bit 8 of `policy`: this launch continues a rollout that is split into launches (OIS_CMD_LEVEL)
+  const bool rsum_continue = (policy & 0x100) != 0;
+  policy &= 0xff;
+  float rsum = (rsum_continue && reward_sum != nullptr) ? reward_sum[la] : 0.0f;
   bool cmd_dirty = false;
   // terrain tile of this arena (origin xyz; level / type for the curriculum)
   float tor[3] = {0.0f, 0.0f, 0.0f};
@@ -369,7 +372,11 @@ OIS_DEV void step_body(const DevConsts& K, const DevBuffers& B, const float* __r
     S.vfwd = forward_projection(S.q, S.v);
     // per-group record of the reset event (extras["episode"], episode statistics)
     const unsigned long long m = __ballot(do_reset);
-    if (m != 0ull) group_record<LPA>(B, arena / kGroup, lane, group_any<LPA>(m, lane), rc, S.sim_steps, true);
+    if (m != 0ull) {
+      group_record<LPA>(B, arena / kGroup, lane, group_any<LPA>(m, lane), rc, S.sim_steps, true);
+      // any reset_idx call re-snapshots `fraction` of every arena (KAMMA.py:498): tell level_command_kernel
+      if (K.cmd_sampler == OIS_CMD_LEVEL && lane == 0) *B.reset_stamp = S.sim_steps;
+    }
   }
   if (valid) {
     store_arena<LPA>(K, B, arena, h, S, cmd_dirty);
@@ -501,6 +508,31 @@ __global__ __launch_bounds__(kBlock) void reset_kernel(DevConsts K, DevBuffers B
     B.rew[arena] = 0.0f; B.done[arena] = 0; B.timeout[arena] = 0;
   }
   if (arena < OIS_ENV0_DIAG_LEN) { B.env0_diag[arena] = 0.0f; B.episode_info[arena] = 0.0f; }
+  if (valid) B.cmd_fraction[arena] = 0.0f;  // KAMMA.py:498 at post_reset: the sums are zero
+  if (arena == 0) *B.reset_stamp = -1;
+}
+
+// Tail of post_physics_step with terrain.curriculum (KAMMA.py:719-725): the command of EVERY arena is
+// re-drawn from its terrain level's generator after every step; `fraction` (KAMMA.py:498) is
+// re-snapshot for all arenas when any arena reset in the step just done. Its own launch because that
+// "any arena" is only known once every wave of the step kernel has finished.
+__global__ __launch_bounds__(256) void level_command_kernel(DevConsts K, DevBuffers B, int N) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= N) return;
+  const int sim = B.counters[i].y;  // == episode_step_counter: policy steps since post_reset
+  float fr = B.cmd_fraction[i];
+  if (*B.reset_stamp == sim) {
+    fr = B.sums_a[i].x / K.cmd_thr_high;
+    B.cmd_fraction[i] = fr;
+  }
+  float u[4];
+  draw4(K, K.arena_offset + i, (uint32_t)sim, PURPOSE_CMD, u);
+  const int level = B.ter.on ? B.terrain_idx[i].x : 0;  // zeros without a terrain (KAMMA.py:223)
+  float cx, cw;
+  level_command(level, fr, sim, normal_det(u[0], u[1]), K.cmd_dt, K.cmd_episode_s, cx, cw);
+  float4 c = B.commands[i];
+  c.x = cx; c.z = cw;
+  B.commands[i] = c;
 }
 
 __global__ void init_params_kernel(DevBuffers B, int N, float mu) {
@@ -681,7 +713,7 @@ size_t align256(size_t x) { return (x + 255) & ~(size_t)255; }
 struct Layout {
   size_t off[OIS_BUF_COUNT_];
   size_t bytes[OIS_BUF_COUNT_];
-  size_t partials, stamps, stat_acc, stat_out, red_part, red_cmax, red_lvl, red_part8, total;
+  size_t partials, stamps, stat_acc, stat_out, red_part, red_cmax, red_lvl, red_part8, reset_stamp, total;
   int nwaves, nchunks;
 };
 
@@ -698,6 +730,7 @@ Layout make_layout(int N) {
   put(OIS_BUF_LAMBDA_N, f4); put(OIS_BUF_LAMBDA_L, f4); put(OIS_BUF_LAMBDA_T, f4);
   put(OIS_BUF_WHEEL_TORQS, f4);
   put(OIS_BUF_ENV_ORIGINS, f4); put(OIS_BUF_TERRAIN_IDX, f4);
+  put(OIS_BUF_CMD_FRACTION, (size_t)N * sizeof(float));
   put(OIS_BUF_OBS, (size_t)N * 6 * sizeof(float));
   put(OIS_BUF_REW, (size_t)N * sizeof(float));
   put(OIS_BUF_DONE, (size_t)N);
@@ -714,6 +747,7 @@ Layout make_layout(int N) {
   L.red_cmax = o; o = align256(o + (size_t)L.nchunks * sizeof(int));
   L.red_lvl = o; o = align256(o + (size_t)L.nchunks * sizeof(long long));
   L.red_part8 = o; o = align256(o + (size_t)L.nchunks * 8 * sizeof(float));
+  L.reset_stamp = o; o = align256(o + sizeof(int32_t));
   L.total = o;
   return L;
 }
@@ -731,7 +765,8 @@ int validate(const ois_config* c) {
       !(c->body_inertia[1] > 0.0f) || !(c->body_inertia[2] > 0.0f) || !(c->wheel_radius > 0.0f))
     return fail(OIS_EINVAL, "mass / inertia / radius must be positive");
   if (c->mix_mode != OIS_MIX_SWITCH && c->mix_mode != OIS_MIX_BLEND) return fail(OIS_EINVAL, "bad mix_mode");
-  if (c->cmd_sampler < 0 || c->cmd_sampler > OIS_CMD_EVAL) return fail(OIS_EINVAL, "bad cmd_sampler");
+  if (c->cmd_sampler < 0 || c->cmd_sampler > OIS_CMD_LEVEL) return fail(OIS_EINVAL, "bad cmd_sampler");
+  if (c->cmd_sampler == OIS_CMD_LEVEL && !(c->curriculum_threshold_high > 0.0f)) return fail(OIS_EINVAL, "curriculum_threshold_high must be positive");
   if (!(c->max_sim_steps > 0.0f)) return fail(OIS_EINVAL, "max_sim_steps must be positive");
   if (!(c->baumgarte > 0.0f && c->baumgarte < 1.0f)) return fail(OIS_EINVAL, "baumgarte must be in (0, 1)");
   if (!(c->wheel_damping >= 0.0f) || !(c->wheel_limit_damping >= 0.0f) || !(c->wheel_limit_velocity >= 0.0f))
@@ -788,6 +823,9 @@ void derive(const ois_config* c, DevConsts* K) {
   K->seed_lo = (uint32_t)(c->seed & 0xffffffffu);
   K->seed_hi = (uint32_t)(c->seed >> 32);
   K->arena_offset = c->arena_offset;
+  K->cmd_dt = (double)c->decimation * (double)c->sim_dt;  // self.dt, a Python double (KAMMA.py:260)
+  K->cmd_episode_s = (double)c->episode_length_s;
+  K->cmd_thr_high = c->curriculum_threshold_high;
 }
 
 }  // namespace
@@ -880,6 +918,7 @@ int ois_config_default(ois_config* c) {
   c->wheel_damping = 0.0f; c->wheel_limit_velocity = 10.0f /* urdf:117 */; c->wheel_limit_damping = 0.6f;
   c->friction = 0.85f; c->baumgarte = 0.2f; c->max_depenetration_velocity = 100.0f;
   c->max_angular_velocity = 64.0f; c->solver_iterations = 4;
+  c->curriculum_threshold_high = 10.0f;  // KAMMA.py:269
   return OIS_OK;
 }
 
@@ -952,6 +991,7 @@ int ois_create(const ois_config* cfg, int device, void* workspace_device, size_t
   B.partials = (float*)(w + L.partials); B.stamps = (int32_t*)(w + L.stamps); B.stat_acc = (float*)(w + L.stat_acc);
   B.rp_states = B.rp_actions = B.rp_rewards = B.rp_next = nullptr; B.rp_done = nullptr; B.rp_size = 0;
   B.env_origins = (float4*)(w + L.off[OIS_BUF_ENV_ORIGINS]); B.terrain_idx = (int4*)(w + L.off[OIS_BUF_TERRAIN_IDX]);
+  B.cmd_fraction = (float*)(w + L.off[OIS_BUF_CMD_FRACTION]); B.reset_stamp = (int32_t*)(w + L.reset_stamp);
   std::memset(&B.ter, 0, sizeof B.ter);
   e->rp_mem = nullptr; e->rp_head = 0; e->rp_filled = false;
   e->prof_on = false; e->prof_used = 0; e->prof_ms = 0.0; e->prof_launches = 0;
@@ -1033,7 +1073,7 @@ static int prof_next_pair(ois_env* e, hipEvent_t* a, hipEvent_t* b) {
   return OIS_OK;
 }
 
-static int launch_steps(ois_env* e, int k, int policy, const float* actions, float* reward_sum, void* stream) {
+static int launch_kernel(ois_env* e, int k, int policy, const float* actions, float* reward_sum, void* stream) {
   HIP_TRY(hipSetDevice(e->device));
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
   if (e->prof_on) {
@@ -1072,6 +1112,21 @@ static int launch_steps(ois_env* e, int k, int policy, const float* actions, flo
   if (e->B.rp_size > 0) {  // the kernel wrote rows rp_head .. rp_head + k - 1 (mod size)
     if (e->rp_head + k >= e->B.rp_size) e->rp_filled = true;
     e->rp_head = (e->rp_head + k) % e->B.rp_size;
+  }
+  return OIS_OK;
+}
+
+static int launch_steps(ois_env* e, int k, int policy, const float* actions, float* reward_sum, void* stream) {
+  if (e->K.cmd_sampler != OIS_CMD_LEVEL) return launch_kernel(e, k, policy, actions, reward_sum, stream);
+  // per-level command curriculum: the commands of all arenas are re-drawn between two policy steps
+  // from a quantity that depends on every arena of the step before (level_command_kernel), so a
+  // rollout is k launches of one step, each followed by the command launch
+  for (int s = 0; s < k; ++s) {
+    const float* a = (policy == OIS_POLICY_EXTERNAL) ? actions + (size_t)s * e->N * e->K.action_dim : actions;
+    int rc = launch_kernel(e, 1, policy | (s > 0 ? 0x100 : 0), a, reward_sum, stream);
+    if (rc != OIS_OK) return rc;
+    hipLaunchKernelGGL(level_command_kernel, dim3((e->N + 255) / 256), dim3(256), 0, (hipStream_t)stream, e->K, e->B, e->N);
+    HIP_TRY(hipGetLastError());
   }
   return OIS_OK;
 }
@@ -1124,6 +1179,7 @@ int ois_terrain_attach(ois_env* e, const ois_terrain* t, const int16_t* heights_
   const size_t f4 = (size_t)e->N * 4 * sizeof(float);
   if (!t) {  // detach: back to the per-arena plane, origins and indices cleared
     std::memset(&e->B.ter, 0, sizeof e->B.ter);
+    e->K.cmd_sampler = e->cfg.cmd_sampler;
     HIP_TRY(hipMemsetAsync(e->B.env_origins, 0, f4, s));
     HIP_TRY(hipMemsetAsync(e->B.terrain_idx, 0, f4, s));
     return OIS_OK;
@@ -1162,6 +1218,9 @@ int ois_terrain_attach(ois_env* e, const ois_terrain* t, const int16_t* heights_
   T.curriculum = t->curriculum; T.on = 1;
   T.hs = t->horizontal_scale; T.inv_hs = 1.0f / t->horizontal_scale; T.vs = t->vertical_scale; T.border = t->border_size;
   T.thr_lo = t->threshold_low; T.thr_hi = t->threshold_high;
+  // terrain.curriculum also switches the commands to the per-level generators (KAMMA.py:533, 719)
+  e->K.cmd_sampler = t->curriculum ? OIS_CMD_LEVEL : e->cfg.cmd_sampler;
+  if (t->curriculum && !(e->K.cmd_thr_high > 0.0f)) e->K.cmd_thr_high = 10.0f;
   return OIS_OK;
 }
 

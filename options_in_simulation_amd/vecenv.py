@@ -39,6 +39,7 @@ _DTYPES = {
     _abi.BUF_ENV0_DIAG: (torch.float32, None), _abi.BUF_LAMBDA_N: (torch.float32, 4),
     _abi.BUF_LAMBDA_L: (torch.float32, 4), _abi.BUF_LAMBDA_T: (torch.float32, 4),
     _abi.BUF_ENV_ORIGINS: (torch.float32, 4), _abi.BUF_TERRAIN_IDX: (torch.int32, 4),
+    _abi.BUF_CMD_FRACTION: (torch.float32, None),
 }
 
 
@@ -484,6 +485,12 @@ class TorqueDistributionTask:
     @property
     def terrain_types(self) -> torch.Tensor:
         return self.native.buffer(_abi.BUF_TERRAIN_IDX)[:, 1]
+
+    @property
+    def fraction(self) -> torch.Tensor:
+        """self.fraction (KAMMA.py:498): r1 episode sum / threshold_high as of the last step in which any
+        arena was reset; drives the per-level command generators when terrain.curriculum is on"""
+        return self.native.buffer(_abi.BUF_CMD_FRACTION)
 
     def get_heights(self, env_ids=None) -> torch.Tensor:
         """KAMMA.py:872-893: measured_heights [N, 140] (rows ``env_ids`` if given)."""

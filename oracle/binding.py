@@ -81,6 +81,12 @@ def lib() -> C.CDLL:
         L.orc_sincos.argtypes = [C.c_float, fp, fp]
         L.orc_sincos.restype = None
         L.orc_substep.argtypes = [cfgp, C.c_float] + [fp] * 10
+        L.orc_sin.argtypes = [C.c_float]
+        L.orc_sin.restype = C.c_float
+        L.orc_normal.argtypes = [C.c_float, C.c_float]
+        L.orc_normal.restype = C.c_float
+        L.orc_level_command.argtypes = [C.c_int, C.c_float, C.c_int32, C.c_float, C.c_double, C.c_double, fp, fp]
+        L.orc_level_command.restype = None
         L.orc_substep.restype = None
         _lib = L
     return _lib
@@ -111,6 +117,7 @@ _BUF_META = {
     _abi.BUF_ENV0_DIAG: (np.float32, None),
     _abi.BUF_LAMBDA_N: (np.float32, 4), _abi.BUF_LAMBDA_L: (np.float32, 4), _abi.BUF_LAMBDA_T: (np.float32, 4),
     _abi.BUF_ENV_ORIGINS: (np.float32, 4), _abi.BUF_TERRAIN_IDX: (np.int32, 4),
+    _abi.BUF_CMD_FRACTION: (np.float32, None),
 }
 
 

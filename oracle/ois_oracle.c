@@ -49,7 +49,7 @@ void orc_philox4x32_10(const uint32_t ctr[4], const uint32_t key[2], uint32_t ou
 /* 24 random bits -> [0,1), exact in float32 */
 float orc_u01(uint32_t x) { return (float)(x >> 8) * 5.9604644775390625e-08f; }
 
-enum { PURPOSE_MASK = 0, PURPOSE_RESET_A = 1, PURPOSE_RESET_B = 2, PURPOSE_ACTION = 3, PURPOSE_PARAMS = 4, PURPOSE_RESET_C = 5 };
+enum { PURPOSE_MASK = 0, PURPOSE_RESET_A = 1, PURPOSE_RESET_B = 2, PURPOSE_ACTION = 3, PURPOSE_PARAMS = 4, PURPOSE_RESET_C = 5, PURPOSE_CMD = 6 };
 
 static void draw4(uint64_t seed, int64_t arena, uint32_t step, uint32_t purpose, float u[4]) {
   uint32_t ctr[4] = {(uint32_t)((uint64_t)arena & 0xffffffffu), (uint32_t)((uint64_t)arena >> 32), step, purpose};
@@ -80,6 +80,31 @@ void orc_sincos(float x, float* s, float* c) {
     case 2: *s = -sn; *c = -cs; break;
     default: *s = -cs; *c = sn; break;
   }
+}
+
+/* Deterministic sin for any |x| < ~1e4 (cephes sinf: reduction by pi/4 with a three-part pi/4,
+ * the minimax kernels of orc_sincos; mul/add/fma and one float -> int truncation only). Used by the
+ * level-1 command generator (KAMMA.py:550-551: math.sin(freq * t), t up to max_sim_steps * dt). */
+float orc_sin(float x) {
+  float sign = 1.0f;
+  if (x < 0.0f) { x = -x; sign = -1.0f; }
+  int j = (int)(1.27323954473516f * x); /* integer part of x / (pi/4) */
+  float y = (float)j;
+  if (j & 1) { j += 1; y += 1.0f; }     /* map zeros to the origin */
+  j &= 7;
+  if (j > 3) { sign = -sign; j -= 4; }
+  float r = fmaf(-y, 3.77489497744594108e-8f, fmaf(-y, 2.4187564849853515625e-4f, fmaf(-y, 0.78515625f, x)));
+  float z = r * r, v;
+  if (j == 1 || j == 2) {
+    float pc = fmaf(z, 2.443315711809948e-5f, -1.388731625493765e-3f);
+    pc = fmaf(z, pc, 4.166664568298827e-2f);
+    v = fmaf(z * z, pc, fmaf(-0.5f, z, 1.0f));
+  } else {
+    float ps = fmaf(z, -1.9515295891e-4f, 8.3321608736e-3f);
+    ps = fmaf(z, ps, -1.6666654611e-1f);
+    v = fmaf(r * z, ps, r);
+  }
+  return sign * v;
 }
 
 /* Deterministic natural log for x in (0, 1] (cephes logf: frexp by bit manipulation + degree-8
@@ -329,6 +354,42 @@ void orc_reset_draws(const ois_config* cfg, const float u[8], float pos3[3], flo
   commands4[0] = x_vel > 0.0f ? x_vel : 0.0f;                      /* :575 max(x_vel, 0.0), :495 */
   commands4[2] = 0.0f;                                             /* :574, :496 */
 }
+
+/* sample_velocity_command, curriculum branch (KAMMA.py:533-567), for one arena: terrain level,
+ * the `fraction` snapshot (KAMMA.py:498), episode_step_counter (KAMMA.py:376, 684: policy steps since
+ * post_reset) and one standard normal z standing for torch.normal's draw (mean + std * z). Returns
+ * the pair that post_physics_step writes to commands[i, 0] and commands[i, 2] (KAMMA.py:722-725);
+ * note the level-0 return order (0.0, x) (KAMMA.py:541). t, and the level-2 ramp, are Python
+ * doubles in the reference and doubles here; tensor arithmetic is float32.
+ * Where the reference would raise (torch.normal with std < 0: sigma < 0 at level 0 once the r1 sum
+ * is below -1.11, Noise < 0 at level 2) the build evaluates mean + std * z all the same. */
+void orc_level_command(int level, float fraction, int32_t step_counter, float z, double dt, double episode_length_s,
+                       float* cmd_x, float* cmd_yaw) {
+  if (level == 0) {
+    float sigma = 0.01f + 0.09f * fraction;             /* :538 */
+    float x = 0.5f + sigma * z;                          /* :539 */
+    *cmd_x = 0.0f; *cmd_yaw = x > 0.0f ? x : 0.0f;       /* :541 return 0.0, max(x_vel, 0.0) */
+  } else if (level == 1) {
+    float freq = 0.01f + 0.09f * fraction;              /* :546 */
+    double t = (double)step_counter * dt;                /* :550 */
+    float arg = freq * (float)t;                         /* tensor * python float -> float32 */
+    float sn = orc_sin(arg);                             /* :551 math.sin */
+    float x;
+    if (fraction > 0.5f) { float amp = 0.1f + 0.4f * fraction; x = 0.5f + amp * sn; }  /* :548-549 */
+    else x = (float)(0.5 + 0.1 * (double)sn);            /* amp stays the Python float 0.1 */
+    *cmd_x = x > 0.0f ? x : 0.0f; *cmd_yaw = 0.0f;
+  } else if (level == 2) {
+    double t = (double)step_counter * dt;                /* :558 */
+    float noise = 0.5f * fraction;                       /* :560 */
+    float nz = 0.0f + noise * z;                         /* torch.normal(mean=0.0, std=Noise) */
+    float x = (float)((double)nz + 0.5 * t / episode_length_s); /* :561, Python doubles */
+    *cmd_x = x > 0.0f ? x : 0.0f; *cmd_yaw = 0.0f;
+  } else {
+    float x = 0.5f + 0.1f * z;                           /* :566 */
+    *cmd_x = x > 0.0f ? x : 0.0f; *cmd_yaw = 0.0f;
+  }
+}
+float orc_normal(float u1, float u2) { return normal_det(u1, u2); }
 
 /* ------------------------------------------------------------------ physics ---------- */
 typedef struct {
@@ -678,6 +739,7 @@ struct orc_env {
   /* buffers, same ids/shapes as the product */
   float *obs, *rew, *wheel_torqs, *pose, *quat, *linvel, *angvel, *wheel_vel, *commands, *sums_a, *sums_b, *sums_c, *params;
   float *lam_n, *lam_l, *lam_t; /* contact impulse cache (warm start), [N,4] each */
+  float* cmd_fraction;          /* [N] self.fraction (KAMMA.py:498), OIS_CMD_LEVEL only */
   uint8_t *done, *timeout;
   int32_t* counters;
   float episode_info[OIS_EPISODE_INFO_LEN];
@@ -722,6 +784,7 @@ int orc_create(const ois_config* cfg, orc_env** out) {
   e->angvel = zalloc(f4); e->wheel_vel = zalloc(f4); e->commands = zalloc(f4);
   e->sums_a = zalloc(f4); e->sums_b = zalloc(f4); e->sums_c = zalloc(f4); e->params = zalloc(f4);
   e->lam_n = zalloc(f4); e->lam_l = zalloc(f4); e->lam_t = zalloc(f4);
+  e->cmd_fraction = zalloc((size_t)N * sizeof(float));
   e->done = zalloc((size_t)N); e->timeout = zalloc((size_t)N);
   e->counters = zalloc((size_t)N * 4 * sizeof(int32_t));
   e->env_origins = zalloc(f4);
@@ -745,6 +808,7 @@ void orc_destroy(orc_env* e) {
   free(e->stat_acc);
   free(e->rp_states); free(e->rp_actions); free(e->rp_rewards); free(e->rp_next); free(e->rp_done);
   free(e->theights); free(e->terrain_origins); free(e->env_origins); free(e->terrain_idx);
+  free(e->cmd_fraction);
   free(e);
 }
 
@@ -782,11 +846,17 @@ int orc_buffer(orc_env* e, int id, void** ptr, size_t* bytes) {
     case OIS_BUF_LAMBDA_T: *ptr = e->lam_t; *bytes = f4; break;
     case OIS_BUF_ENV_ORIGINS: *ptr = e->env_origins; *bytes = f4; break;
     case OIS_BUF_TERRAIN_IDX: *ptr = e->terrain_idx; *bytes = N * 4 * sizeof(int32_t); break;
+    case OIS_BUF_CMD_FRACTION: *ptr = e->cmd_fraction; *bytes = N * sizeof(float); break;
     case OIS_BUF_EPISODE_INFO: *ptr = e->episode_info; *bytes = sizeof e->episode_info; break;
     case OIS_BUF_ENV0_DIAG: *ptr = e->env0_diag; *bytes = sizeof e->env0_diag; break;
     default: return fail(OIS_EINVAL, "unknown buffer id");
   }
   return OIS_OK;
+}
+
+/* commands follow the per-level generators: config switch, or an attached terrain with curriculum */
+static int level_mode(const orc_env* e) {
+  return e->cfg.cmd_sampler == OIS_CMD_LEVEL || (e->terrain_on && e->tcfg.curriculum);
 }
 
 /* per-arena values contributed to the group partial record when the arena resets */
@@ -847,7 +917,14 @@ static void reset_arena(orc_env* e, int i, uint32_t step_ctr, float gamma2, rese
   draw4(e->seed, gid, step_ctr, PURPOSE_RESET_B, &u[4]);
   float pos[3], q[4], cmd[4];
   orc_reset_draws(c, u, pos, q, cmd);
-  if (c->cmd_sampler == OIS_CMD_BOX) {
+  if (level_mode(e)) {
+    /* `if not self.curriculum:` skips the re-draw (KAMMA.py:490): commands[:, 0] keeps the draw of :448,
+     * commands[:, 2] its previous value, both times the small-command mask of :458 */
+    float x0 = c->cmd_x_span * u[3] + c->cmd_x_lo, y0 = c->cmd_y_span * u[4] + c->cmd_y_lo;
+    float keep = sqrtf(x0 * x0 + y0 * y0) > 0.25f ? 1.0f : 0.0f;
+    cmd[0] = x0 * keep;
+    cmd[2] = e->commands[4 * i + 2] * keep;
+  } else if (c->cmd_sampler == OIS_CMD_BOX) {
     /* KAMMA_curr1.py:577-598 */
     float progress = fminf(1.0f, (float)cnt[1] / c->max_sim_steps);
     float factor = 0.1f + (1.0f - 0.1f) * progress;
@@ -967,6 +1044,7 @@ int orc_reset(orc_env* e, uint64_t seed) {
   memset(e->angvel, 0, f4); memset(e->wheel_vel, 0, f4); memset(e->commands, 0, f4);
   memset(e->sums_a, 0, f4); memset(e->sums_b, 0, f4); memset(e->sums_c, 0, f4);
   memset(e->lam_n, 0, f4); memset(e->lam_l, 0, f4); memset(e->lam_t, 0, f4);
+  memset(e->cmd_fraction, 0, (size_t)N * sizeof(float)); /* :498 at post_reset: the sums are zero */
   memset(e->done, 0, (size_t)N); memset(e->timeout, 0, (size_t)N);
   memset(e->counters, 0, (size_t)N * 4 * sizeof(int32_t));
   memset(e->partials, 0, (size_t)e->G * PART_STRIDE * sizeof(float));
@@ -1159,6 +1237,24 @@ static int step_all(orc_env* e, int policy, const float* actions, float* reward_
       if (reward_sum) reward_sum[i] += r;
     }
     group_reduce(e, g, rs, rc, stamp, lg1, lg2, 1);
+  }
+  if (level_mode(e)) {
+    /* KAMMA.py:498: any reset_idx call re-snapshots `fraction` for ALL arenas (after the sums of the
+     * resetting ones were zeroed); then the tail of post_physics_step re-draws the command of every
+     * arena (KAMMA.py:719-725). episode_step_counter == sim_steps: both count policy steps since post_reset. */
+    int any = 0;
+    for (int i = 0; i < N; ++i) any |= rs[i];
+    if (any) for (int i = 0; i < N; ++i) e->cmd_fraction[i] = e->sums_a[4 * i] / e->cfg.curriculum_threshold_high;
+#ifdef _OPENMP
+#pragma omp parallel for schedule(static) num_threads(e->threads)
+#endif
+    for (int i = 0; i < N; ++i) {
+      float u[4];
+      draw4(e->seed, e->cfg.arena_offset + i, (uint32_t)stamp, PURPOSE_CMD, u);
+      int level = e->terrain_on ? e->terrain_idx[4 * i] : 0; /* zeros without a terrain (KAMMA.py:223) */
+      orc_level_command(level, e->cmd_fraction[i], stamp, normal_det(u[0], u[1]), (double)e->cfg.decimation * (double)e->cfg.sim_dt,
+                        (double)e->cfg.episode_length_s, &e->commands[4 * i], &e->commands[4 * i + 2]);
+    }
   }
   e->steps_done += (double)N;
   if (e->rp_size > 0) {

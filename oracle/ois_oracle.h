@@ -124,6 +124,12 @@ void orc_substep(const ois_config* cfg, float mu, const float n_world[3], const 
                  float p[3], float q[4], float v[3], float w[3], float spin[4], float lam_n[4],
                  float lam_l[4], float lam_t[4]);
 
+/* the per-terrain-level command generators (KAMMA.py:533-567) and the deterministic helpers they use */
+float orc_sin(float x);
+float orc_normal(float u1, float u2);
+void orc_level_command(int level, float fraction, int32_t step_counter, float z, double dt, double episode_length_s,
+                       float* cmd_x, float* cmd_yaw);
+
 #ifdef __cplusplus
 }
 #endif

@@ -308,6 +308,58 @@ def refmath_heights(seed=4, n=96):
 
 
 # ----------------------------------------------------------------------------------------
+def refmath_curriculum(seed=6, n=384):
+    """sample_velocity_command with self.curriculum (KAMMA.py:533-567) as post_physics_step calls it for
+    every arena (KAMMA.py:719-725), plus the `fraction` line of reset_idx (KAMMA.py:498). The per-arena
+    Python loop, the 0-dim tensor indexing (self.fraction[env_id]), math.sin on a tensor and the Python
+    doubles (t, scale * t / max_episode_length_s) are kept as they are; torch.normal's draw is passed
+    in as a standard normal z (normal(mean, std) = mean + std * z in float32), so any RNG can replay it
+    and a negative std (where the reference's torch.normal raises) still has a value."""
+    import math
+    g = torch.Generator().manual_seed(seed)
+    terrain_levels = torch.randint(0, 5, (n,), generator=g)
+    r1_sums = -torch.rand(n, generator=g, dtype=F) * 14.0                      # episode sums of w1 * r1 <= 0
+    r1_sums[::7] = torch.rand(len(r1_sums[::7]), generator=g, dtype=F) * 9.0   # positive values reach fraction > 0.5 (:548)
+    threshold_high = 10.0                                                      # :269
+    fraction = r1_sums / threshold_high                                        # :498
+    z = torch.randn(n, generator=g, dtype=F)
+    counters = torch.randint(1, 500000, (n,), generator=g)                     # episode_step_counter (:376, :684)
+    dt = 10 * 0.01                                                             # :258-260 (Python double)
+    max_episode_length_s = 10.0                                                # :261
+    cmd0, cmd2 = torch.zeros(n, dtype=F), torch.zeros(n, dtype=F)
+    for env_id in range(n):
+        episode_step_counter = int(counters[env_id])
+        normal = lambda mean, std: (torch.tensor(mean, dtype=F) + torch.as_tensor(std, dtype=F) * z[env_id]).item()
+        if terrain_levels[env_id] == 0:
+            sigma = 0.01 + 0.09 * fraction[env_id]                             # :538
+            x_vel = normal(0.5, sigma)                                         # :539
+            cmds = (0.0, max(x_vel, 0.0))                                      # :541
+        elif terrain_levels[env_id] == 1:
+            freq = 0.01 + 0.09 * fraction[env_id]                              # :546
+            amp = 0.1                                                          # :547
+            if fraction[env_id] > 0.5:
+                amp = 0.1 + 0.4 * fraction[env_id]                             # :549
+            t = float(episode_step_counter) * dt                               # :550
+            x_vel = 0.5 + amp * math.sin(freq * t)                             # :551
+            cmds = (max(x_vel, 0.0), 0.0)                                      # :552
+        elif terrain_levels[env_id] == 2:
+            t = float(episode_step_counter) * dt                               # :558
+            scale = 0.5                                                        # :559
+            Noise = 0.5 * fraction[env_id]                                     # :560
+            x_vel = normal(0.0, Noise) + scale * t / max_episode_length_s      # :561
+            cmds = (max(x_vel, 0.0), 0.0)                                      # :562
+        else:
+            x_vel = normal(0.5, 0.1)                                           # :566
+            cmds = (max(x_vel, 0.0), 0.0)                                      # :567
+        cmd0[env_id] = cmds[0]                                                 # :724 (assignment rounds to float32)
+        cmd2[env_id] = cmds[1]                                                 # :725
+    return {"terrain_levels": terrain_levels.numpy().astype(np.int32), "r1_sums": r1_sums.numpy(),
+            "threshold_high": np.float32(threshold_high), "fraction": fraction.numpy(), "z": z.numpy(),
+            "episode_step_counter": counters.numpy().astype(np.int32), "dt": np.float64(dt),
+            "max_episode_length_s": np.float64(max_episode_length_s), "commands_0": cmd0.numpy(), "commands_2": cmd2.numpy()}
+
+
+# ----------------------------------------------------------------------------------------
 def trajectories():
     from oracle.binding import OracleEnv
     from tests.golden_replay import TRAJ_SPECS, run_spec
@@ -317,6 +369,7 @@ def trajectories():
 def main():
     np.savez_compressed(os.path.join(HERE, "refmath_gae.npz"), **refmath_gae())
     np.savez_compressed(os.path.join(HERE, "refmath_heights.npz"), **refmath_heights())
+    np.savez_compressed(os.path.join(HERE, "refmath_curriculum.npz"), **refmath_curriculum())
     if "--gae-only" in sys.argv or "--unit-only" in sys.argv:
         return
     np.savez_compressed(os.path.join(HERE, "refmath_step.npz"), **refmath_step())

@@ -1,0 +1,58 @@
+"""bench.py's own rank launch: `python bench.py --gpus N` must work without a
+torch.distributed environment — it starts its N ranks itself, before touching the GPU — and the
+JSON line must show that N ranks took part. No GPU here: OIS_BENCH_DRYRUN keeps the launch,
+rendezvous and all-gather and skips the environment."""
+import json
+import os
+import subprocess
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+
+def _clean_env(**extra):
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    env.update(extra)
+    return env
+
+
+def test_spawn_command_is_the_drivers_launch_line():
+    import bench
+    cmd = bench.spawn_command(4, ["--gpus", "4", "--steps", "7"], 29511)
+    assert cmd[1:4] == ["-m", "torch.distributed.run", "--nnodes=1"]
+    assert "--nproc-per-node=4" in cmd and cmd[cmd.index("--master-addr") + 1] == "127.0.0.1"
+    assert cmd[cmd.index("--master-port") + 1] == "29511"
+    assert cmd[-5] == os.path.join(ROOT, "bench.py") and cmd[-4:] == ["--gpus", "4", "--steps", "7"]
+
+
+def test_no_self_launch_for_one_gpu_or_inside_a_launch(monkeypatch):
+    import bench
+    called = []
+    monkeypatch.setattr(bench.subprocess, "call", lambda *a, **k: called.append(a) or 0)
+    monkeypatch.delenv("RANK", raising=False)
+    monkeypatch.delenv("LOCAL_RANK", raising=False)
+    bench.maybe_self_launch(bench.parse_args(["--gpus", "1"]), ["--gpus", "1"])
+    monkeypatch.setenv("RANK", "0")
+    bench.maybe_self_launch(bench.parse_args(["--gpus", "2"]), ["--gpus", "2"])  # already a rank of somebody's launch
+    assert not called
+
+
+def test_bare_bench_gpus_2_starts_two_ranks_and_prints_one_line():
+    res = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1",
+                          "--arenas", "1000"], env=_clean_env(OIS_BENCH_DRYRUN="1"), capture_output=True, text=True, timeout=300)
+    assert res.returncode == 0, res.stderr[-2000:]
+    lines = [l for l in res.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["config"]["ranks"] == 2 and d["steps"] == 3
+    table = d["config"]["rank_table"]
+    assert [r["rank"] for r in table] == [0, 1]
+    assert [(r["arena_offset"], r["arenas"]) for r in table] == [(0, 1000), (1000, 1000)]
+
+
+def test_world_size_mismatch_is_an_error_not_a_silent_run():
+    res = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2"],
+                         env=_clean_env(RANK="0", LOCAL_RANK="0", WORLD_SIZE="1", OIS_BENCH_DRYRUN="1"),
+                         capture_output=True, text=True, timeout=300)
+    assert res.returncode != 0 and "WORLD_SIZE" in (res.stderr + res.stdout)

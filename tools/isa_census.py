@@ -47,7 +47,13 @@ def census(asm, want):
                        "fma/mul/add" if re.match(r"v_(fma|mul|add|sub|fmac|mac)", ins) else "mov/cndmask" if re.match(r"v_(mov|cndmask|accvgpr)", ins)
                        else "other valu" if ins.startswith("v_") else "salu" if ins.startswith("s_") else "mem")
                 tot[cls] = tot.get(cls, 0) + 1
+        flop = 0
+        for b in inner:
+            for ins in b[2]:
+                flop += (4 if ins.startswith("v_pk_fma") else 2 if ins.startswith("v_pk_") and not ins.startswith("v_pk_mov") else
+                         2 if re.match(r"v_(fma|fmac|fmaak|fmamk|mad|mac)_f32", ins) else 1 if re.match(r"v_(add|sub|subrev|mul)_f32", ins) else 0)
         valu = sum(v for k, v in tot.items() if k not in ("salu", "mem"))
+        print(f"   substep loop FLOP per lane (fma = 2, packed = x2; all blocks incl. the rare velocity-cap branch): {flop}")
         print(f"   substep loop ({len(inner)} blocks): VALU {valu}  " + "  ".join(f"{k} {v}" for k, v in sorted(tot.items())))
         big = max(blocks, key=lambda b: len(b[2]))
         print(f"   largest block {big[0]}: {len(big[2])} instr; whole kernel {sum(len(b[2]) for b in blocks)} instr")

@@ -4,7 +4,7 @@
 # traffic counters (separate --pmc passes, as the microarch guide prescribes).
 #   tools/profile_round.sh r1        -> gpurun_out/r1_*   (copy what is judged into profiles/)
 set -e -o pipefail
-R=${1:-r1}
+R=${1:-r2}
 OUT=$PWD/gpurun_out
 mkdir -p $OUT
 export TMPDIR=/tmp
@@ -13,16 +13,19 @@ echo "bench done" && tail -c 300 $OUT/${R}_bench.json
 python bench.py --no-actor --no-cpu-baseline --steps 400 --warmup 40 > $OUT/${R}_bench_envonly.json 2>> $OUT/${R}_bench.err
 P=/tmp/ois_prof_$$
 rm -rf $P && mkdir -p $P
-(cd /tmp && rocprofv3 --kernel-trace --stats --output-format csv -d $P/kt -- python3 $OLDPWD/bench.py --steps 100 --warmup 10 --no-cpu-baseline > $OUT/${R}_bench_under_rocprof.json 2> $P/kt.err) || { tail -5 $P/kt.err; exit 1; }
+(cd /tmp && rocprofv3 --kernel-trace --stats --output-format csv -d $P/kt -- python3 $OLDPWD/bench.py --steps 100 --warmup 10 --no-cpu-baseline --no-extras > $OUT/${R}_bench_under_rocprof.json 2> $P/kt.err) || { tail -5 $P/kt.err; exit 1; }
 cp $(find $P/kt -name '*kernel_stats.csv' | head -1) $OUT/${R}_bench_kernel_stats.csv
 echo "kernel trace done"
 for C in FETCH_SIZE WRITE_SIZE; do
-  (cd /tmp && rocprofv3 --pmc $C --kernel-trace --output-format csv -d $P/$C -- python3 $OLDPWD/bench.py --steps 60 --warmup 10 --no-actor --no-cpu-baseline > /dev/null 2> $P/$C.err) || { tail -5 $P/$C.err; exit 1; }
+  (cd /tmp && rocprofv3 --pmc $C --kernel-trace --output-format csv -d $P/$C -- python3 $OLDPWD/bench.py --steps 60 --warmup 10 --no-actor --no-cpu-baseline --no-extras > /dev/null 2> $P/$C.err) || { tail -5 $P/$C.err; exit 1; }
   cp $(find $P/$C -name '*counter_collection.csv' | head -1) $P/$C.csv
 done
-python3 - "$P" "$OUT" "$R" <<'PY'
-import csv, json, sys
-P, OUT, R = sys.argv[1:4]
+python3 - "$P" "$OUT" "$R" "$PWD" <<'PY'
+import csv, json, subprocess, sys
+P, OUT, R, REPO = sys.argv[1:5]
+sys.path.insert(0, REPO)
+import bench
+head = open(REPO + "/.git_head").read().strip() if __import__("os").path.exists(REPO + "/.git_head") else None
 res = {}
 for c in ("FETCH_SIZE", "WRITE_SIZE"):
     vals = []
@@ -40,6 +43,8 @@ fm, wm = sum(f) / len(f), sum(w) / len(w)
 out = {"FETCH_SIZE_KB_per_launch_mean": fm, "FETCH_SIZE_launches": len(f), "WRITE_SIZE_KB_per_launch_mean": wm,
        "WRITE_SIZE_launches": len(w), "fetch_correction": 2.0,
        "hbm_bytes_per_launch": (2.0 * fm + wm) * 1024.0, "arenas": 65536,
+       "bytes_per_arena_step": (2.0 * fm + wm) * 1024.0 / 65536, "ratio_to_algorithmic_352": (2.0 * fm + wm) * 1024.0 / 65536 / 352.0,
+       "kernel_src_sha256": bench.kernel_source_hash(), "git_head": head,
        "kernel": "step_kernel<1,true,4> (one arena per lane, packed fp32 over wheel pairs, 1 policy step per launch)",
        "command": "rocprofv3 --pmc FETCH_SIZE|WRITE_SIZE --kernel-trace --output-format csv -- python3 bench.py --steps 60 "
                   "--warmup 10 --no-actor --no-cpu-baseline (two separate passes; FETCH_SIZE x2 = the guide's gfx950 correction)"}
@@ -47,3 +52,6 @@ json.dump(out, open(f"{OUT}/{R}_pmc_traffic.json", "w"), indent=1)
 print(json.dumps(out))
 PY
 grep step_kernel $OUT/${R}_bench_kernel_stats.csv | cut -c1-200
+# the multi-process path on this 1-GPU box: two gloo ranks sharing the card, launched by bench.py itself
+OIS_DIST_BACKEND=gloo python bench.py --gpus 2 --steps 60 --warmup 10 > $OUT/${R}_bench_gloo2.json 2>> $OUT/${R}_bench.err
+tail -c 400 $OUT/${R}_bench_gloo2.json
