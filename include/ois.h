@@ -168,7 +168,11 @@ typedef struct ois_config {
   float wheel_limit_damping;  /* resistance above the limit [N m s/rad], CALIBRATED with wheel_damping
                                  (docs/SPEC.md section 3.3, tests/golden/ref_stats.json); 0 = no limit */
   float curriculum_threshold_high; /* 10.0: self.threshold_high, the divisor of `fraction` (KAMMA.py:269, 498) */
-  int32_t reserved_[5];
+  int32_t env0_reward_guard;  /* 1: KAMMA_g1d_g21.py:838-842 — get_observations overwrites rew_buf[0] with 1e-12 when
+                                 |rew_buf[0]| < 1e-12 (a division guard for the env-0 percentages), BEFORE the reward is
+                                 returned: the returned reward, the diagnostics and the transition row of LOCAL arena 0
+                                 carry it, the episode sums (added in calculate_metrics) do not */
+  int32_t reserved_[4];
 } ois_config;
 
 /* Buffer ids for ois_buffer(). Shapes are row-major; N = num_envs. */

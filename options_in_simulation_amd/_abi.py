@@ -123,7 +123,8 @@ class OisConfig(C.Structure):
         ("wheel_limit_velocity", C.c_float),
         ("wheel_limit_damping", C.c_float),
         ("curriculum_threshold_high", C.c_float),
-        ("reserved_", C.c_int32 * 5),
+        ("env0_reward_guard", C.c_int32),
+        ("reserved_", C.c_int32 * 4),
     ]
 
 

@@ -100,9 +100,9 @@ VARIANTS: Dict[str, Dict[str, Any]] = {
     "KAMMA_g11_g21": dict(action_dim=4, action_low=0.0, mix_mode=A.MIX_SWITCH, max_sim_steps=100000.0,
                           gamma1_mode=A.GAMMA_CONST, gamma1_const=1.0,
                           gamma2_mode=A.GAMMA_CONST, gamma2_const=1.0),
-    # KAMMA_g1d_g21.py:628: gamma2 line commented
+    # KAMMA_g1d_g21.py:628: gamma2 line commented; :838-842: rew_buf[0] = 1e-12 when it is (nearly) zero
     "KAMMA_g1d_g21": dict(action_dim=4, action_low=0.0, mix_mode=A.MIX_SWITCH, max_sim_steps=500000.0,
-                          gamma2_mode=A.GAMMA_CONST, gamma2_const=1.0),
+                          gamma2_mode=A.GAMMA_CONST, gamma2_const=1.0, env0_reward_guard=1),
     # KAMMA_curr1.py:56-57, 179, 577-598
     "KAMMA_curr1": dict(action_dim=4, action_low=0.0, mix_mode=A.MIX_SWITCH, max_sim_steps=500000.0,
                         cmd_sampler=A.CMD_BOX),

@@ -42,7 +42,7 @@ struct DevConsts {
       spawn_xy_range;
   float init_pos[3], init_quat[4], init_lin_vel[3], init_ang_vel[3], init_dof_vel[4];
   int action_dim, mix_mode, gamma1_mode, gamma2_mode, guiding_mode, cmd_sampler, eval_sums,
-      max_episode_length;
+      max_episode_length, env0_reward_guard;
   uint32_t seed_lo, seed_hi;
   int64_t arena_offset;
   // per-level command generators (OIS_CMD_LEVEL): Python doubles of the reference kept as doubles

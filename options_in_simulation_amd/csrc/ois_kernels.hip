@@ -304,7 +304,6 @@ OIS_DEV void step_body(const DevConsts& K, const DevBuffers& B, const float* __r
     S.sa[0] += c1; S.sa[1] += c2; S.sa[2] += c3; S.sa[3] += rdense;               // :803-806
     S.sb[0] += sparse; S.sb[1] += guiding; S.sb[2] += observed; S.sb[3] += rew;   // :807-810
     if (K.eval_sums) S.sc[1] += fabsf(vd) / 10.0f;                 // KAMMA_eval.py:840
-    rsum += rew;
     // reset_idx (:417-498)
     ResetContrib rc;
     contrib_identity(rc);
@@ -325,6 +324,10 @@ OIS_DEV void step_body(const DevConsts& K, const DevBuffers& B, const float* __r
     const float co = K.clip_obs;
     const float ob[6] = {clipf(S.cmd[0], -co, co), clipf(S.cmd[2], -co, co), clipf(vd, -co, co),
                          clipf(od, -co, co),       clipf(lin_acc, -co, co),  clipf(ang_acc, -co, co)};
+    // KAMMA_g1d_g21.py:838-842: get_observations replaces a (nearly) zero rew_buf[0] by 1e-12 before it is
+    // returned; the episode sums above already hold the unmodified value (local arena 0, like the diagnostics)
+    if (K.env0_reward_guard && arena == 0 && fabs((double)rew) < 1e-12) rew = 1e-12f;
+    rsum += rew;
     // FIFO transition memory row (train_kaddpg_4d_nofifo_random_RLIL.py:147-156; executed action:
     // base_KA_DDPG.py:212)
     if (B.rp_size > 0 && valid) {
@@ -820,6 +823,7 @@ void derive(const ois_config* c, DevConsts* K) {
   K->action_dim = c->action_dim; K->mix_mode = c->mix_mode; K->gamma1_mode = c->gamma1_mode; K->gamma2_mode = c->gamma2_mode;
   K->guiding_mode = c->guiding_mode; K->cmd_sampler = c->cmd_sampler; K->eval_sums = c->eval_sums;
   K->max_episode_length = c->max_episode_length;
+  K->env0_reward_guard = c->env0_reward_guard;
   K->seed_lo = (uint32_t)(c->seed & 0xffffffffu);
   K->seed_hi = (uint32_t)(c->seed >> 32);
   K->arena_offset = c->arena_offset;

@@ -1185,6 +1185,9 @@ static float step_arena(orc_env* e, int i, const float* act /*[A]*/, uint8_t* rs
   float o[6] = {CMD[0], CMD[2], v_delta, omega_delta, mo.lin_acc, mo.ang_acc};
   float ob[6];
   for (int k = 0; k < 6; ++k) ob[k] = clipf(o[k], -c->clip_obs, c->clip_obs); /* rl_task.py:99 clamp in the VecEnv */
+  /* KAMMA_g1d_g21.py:838-842: get_observations replaces a (nearly) zero rew_buf[0] by 1e-12 before it is
+   * returned (division guard of the env-0 percentages); the episode sums were added in calculate_metrics */
+  if (c->env0_reward_guard && i == 0 && fabs((double)mo.rew) < 1e-12) mo.rew = 1e-12f;
   if (e->rp_size > 0) {
     /* FIFOMemory row (train_kaddpg_4d_nofifo_random_RLIL.py:147-156): states = the previous
      * observation, actions = executed torques / action_scale (base_KA_DDPG.py:212) */

@@ -132,6 +132,64 @@ def test_full_size_properties(N):
     assert float(a.episode_info()[_abi.EI_COUNT]) == N
 
 
+def _blocks(N, width=64):
+    """contiguous arena blocks spread over [0, N): the oracle steps them as small envs at arena_offset"""
+    starts = sorted({0, (N // 3) // 16 * 16 + 5, (2 * N // 3) // 16 * 16 + 11, N - width})
+    return [(s0, min(width, N - s0)) for s0 in starts]
+
+
+@pytest.mark.parametrize("domain_rand", [False, True], ids=["config3_actions", "config4_domain_rand"])
+def test_external_actions_at_full_size_against_the_oracle(domain_rand):
+    """BASELINE.json configs[2] / configs[3] through their actual entry point at the stated size:
+    65 536 arenas, EXTERNAL actions (ois_step, what the actor loop calls), gamma decaying so that the
+    policy's torques are executed on part of the steps; with domain_rand also ois_randomize_params at
+    this size. Four 64-arena blocks across the range are stepped by the oracle (arena_offset = block
+    start, same per-step actions): every state buffer bit-identical, across the synchronous timeout."""
+    from options_in_simulation_amd.vecenv import NativeEnv
+    from oracle.binding import OracleEnv
+    N = 65536
+    kw = dict(variant="KAMMA_medium", seed=17, max_sim_steps=150.0)
+    dev = NativeEnv(build_config(num_envs=N, **kw), "cuda:0")
+    blocks = _blocks(N)
+    orcs = [OracleEnv(build_config(num_envs=n, arena_offset=s0, **kw)) for s0, n in blocks]
+    slopes = [-0.3, -0.2, 0.0, 0.2, 0.3]  # origin_terrain_generator.py:92
+    if domain_rand:
+        dev.randomize_params(0.5, 1.0, slopes)
+        for o in orcs:
+            o.randomize_params(0.5, 1.0, slopes)
+    dev.reset(17)
+    for o in orcs:
+        o.reset(17)
+    bufs = [_abi.BUF_POSE, _abi.BUF_QUAT, _abi.BUF_LINVEL, _abi.BUF_ANGVEL, _abi.BUF_WHEEL_VEL, _abi.BUF_COMMANDS,
+            _abi.BUF_COUNTERS, _abi.BUF_SUMS_A, _abi.BUF_SUMS_B, _abi.BUF_LAMBDA_N, _abi.BUF_LAMBDA_L, _abi.BUF_LAMBDA_T,
+            _abi.BUF_OBS, _abi.BUF_REW, _abi.BUF_DONE, _abi.BUF_TIMEOUT, _abi.BUF_WHEEL_TORQS, _abi.BUF_PARAMS]
+
+    def check(where):
+        torch.cuda.synchronize()
+        for (s0, n), o in zip(blocks, orcs):
+            for bid in bufs:
+                got = dev.buffer(bid)[s0:s0 + n].cpu().numpy()
+                got = got.astype(np.uint8) if got.dtype == np.bool_ else got
+                assert np.array_equal(got, o.buffer(bid)), f"{where}: arenas {s0}..{s0 + n}: buffer {bid} not bit-identical"
+    check("post_reset")
+    g = torch.Generator(device="cuda").manual_seed(5)
+    policy_steps = 0
+    for t in range(104):
+        a = torch.rand((N, 4), device="cuda", generator=g)
+        dev.step(a)
+        for (s0, n), o in zip(blocks, orcs):
+            o.step(a[s0:s0 + n].cpu().numpy())
+        if t in (0, 60, 98, 99, 103):
+            check(f"step {t}")
+    wt = dev.buffer(_abi.BUF_WHEEL_TORQS)
+    assert torch.isfinite(dev.buffer(_abi.BUF_OBS)).all() and wt.abs().max() <= 4.0
+    st = dev.stats()
+    assert st.episodes >= N and st.steps == float(N) * 104
+    if domain_rand:
+        p = dev.buffer(_abi.BUF_PARAMS)
+        assert 0.5 <= float(p[:, 0].min()) and float(p[:, 0].max()) <= 1.0 and len(torch.unique(p[:, 3])) == 3  # |slope| in {0, 0.2, 0.3}
+
+
 def test_step_is_capturable_in_a_hip_graph():
     """policy + ois_step recorded once with torch.cuda.graph and replayed: the library only
     enqueues on the caller's stream (no allocation, no synchronisation in ois_step), so the

@@ -297,3 +297,31 @@ def test_lean_exact_reciprocal_is_the_ieee_quotient(tmp_path):
                     os.path.join(root, "tools", "exact_rcp_check.hip")], check=True, capture_output=True)
     res = subprocess.run([exe], capture_output=True, text=True, timeout=300)
     assert res.returncode == 0 and " 0 mismatches" in res.stdout, res.stdout + res.stderr
+
+
+@pytest.mark.gpu
+def test_calibration_statistic_on_the_hip_path():
+    """the calibration statistic of tests/test_oracle_rng_physics.py (expert-only run against the
+    reference's training log and controller figure, tests/golden/ref_stats.json) computed on the HIP
+    path at 4 096 arenas: calibration, not parity — the parity of this run is the rest of this file."""
+    import json
+    from tests.calibration import expert_run_stats
+    ref = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "ref_stats.json")))
+    log, built = ref["train_log"]["first_100000_steps"], ref["build"]
+    N = 4096
+    from options_in_simulation_amd.vecenv import NativeEnv
+    dev = NativeEnv(build_config(variant="KAMMA_g11_g21", num_envs=N, seed=11), "cuda:0")
+    dev.reset(11)
+
+    class Adapter:
+        def step(self, a): dev.step(torch.from_numpy(a).cuda())
+        def buffer(self, bid): return dev.buffer(bid)
+    r = expert_run_stats(Adapter(), N, to_numpy=lambda t: t.cpu().numpy())
+    line = lambda d, x: d["slope"] * x + d["intercept"]
+    assert r["v_delta"] == pytest.approx(built["v_delta"], rel=0.05) and r["v_delta"] == pytest.approx(log["v_delta"], rel=0.05)
+    assert r["slope"] == pytest.approx(built["slope"], rel=0.05)
+    t = log["v_delta_vs_desired_v"]
+    assert abs(line(r, 1.3) - line(t, 1.3)) < 0.02 and abs(line(r, 1.7) - line(t, 1.7)) < 0.02
+    te, fig = r["te_by_command"], ref["figure_controller"]["te"]
+    assert te[2] < te[0] and te[2] < te[4]
+    assert abs(te[0] - fig["1.0-1.3"]) < 0.06 and abs(te[2] - fig["1.53"]) < 0.03 and abs(te[4] - fig["2.0"]) < 0.06

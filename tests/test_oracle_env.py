@@ -231,3 +231,33 @@ def test_non_finite_physics_outcome_is_discarded_and_reset():
     for _ in range(5):
         env.step(z)
     assert all(np.isfinite(env.buffer(b)).all() for b in ids) and not env.done.any()
+
+
+def test_g1d_g21_env0_reward_guard():
+    """KAMMA_g1d_g21.py:838-842: with gamma2 == 1 the reward is the guiding reward alone, which is
+    exactly 0 whenever the expert's torque is executed un-clipped; get_observations then overwrites
+    rew_buf[0] — arena 0 only — with 1e-12 before the reward is returned. The episode sums were added
+    before (calculate_metrics) and keep the zero."""
+    N = 6
+    cfg = build_config(variant="KAMMA_g1d_g21", num_envs=N, seed=2)
+    assert cfg.env0_reward_guard == 1 and build_config(variant="KAMMA_g11_g21", num_envs=1).env0_reward_guard == 0
+    env = OracleEnv(cfg)
+    env.reset(2)
+    z = np.zeros((N, 4), np.float32)
+    hit = 0
+    for t in range(60):
+        env.step(z)
+        wt = env.buffer(_abi.BUF_WHEEL_TORQS)
+        unclipped = np.abs(wt).max(axis=1) < 4.0
+        assert (env.rew[1:][unclipped[1:]] == 0.0).all()        # guiding = -||wt - criteria|| = 0
+        if unclipped[0]:
+            assert env.rew[0] == np.float32(1e-12)
+            assert env.buffer(_abi.BUF_ENV0_DIAG)[27] == np.float32(1e-12)
+            hit += 1
+    assert hit > 20
+    plain = OracleEnv(build_config(variant="KAMMA_g1d_g21", num_envs=N, seed=2, env0_reward_guard=0))
+    plain.reset(2)
+    for t in range(60):
+        plain.step(z)
+    for bid in (_abi.BUF_SUMS_A, _abi.BUF_SUMS_B, _abi.BUF_POSE, _abi.BUF_OBS):  # nothing but the returned reward moves
+        assert np.array_equal(env.buffer(bid), plain.buffer(bid))

@@ -3,6 +3,7 @@ build-defined rigid-body model (docs/SPEC.md §3). The physics has no reference 
 (PhysX is not in the reference: parity unpinned), so these are property tests: equilibria,
 conservation-style invariants and closed-form steady states."""
 import ctypes as C
+import os
 
 import numpy as np
 import pytest
@@ -206,26 +207,39 @@ def test_skid_steer_turns_in_place(oracle_lib):
     assert abs(w3[2]) < 1e-5 and v3[0] > 0.3 and abs(v3[1]) < 1e-5
 
 
-def test_calibration_band_against_the_reference_artefacts():
-    """STATISTICAL SANITY PIN, not parity: with the expert
-    controller in charge, the shipped training log's first 100 k steps average v_des 1.508,
-    v 1.343, v_delta 0.164, |omega| < 2e-5 (my_runs/.../reward_components_env0_timeseries.csv),
-    and the reference's figure puts the classical controller's tracking error between 0.15 and
-    0.45 m/s over 1-2 m/s (docs/img/TE_KAMMA.png). The one calibrated constant of the physics
-    (wheel joint damping 0.125 N m s/rad) must keep the build inside those bands."""
-    N = 96
-    env = OracleEnv(build_config(variant="KAMMA_g11_g21", num_envs=N, seed=1), threads=4)
-    env.reset(1)
-    z = np.zeros((N, 4), np.float32)
-    vdes, v, vd, wz = [], [], [], []
-    for _ in range(400):
-        env.step(z)
-        vdes.append(env.obs[:, 0].copy()); vd.append(env.obs[:, 2].copy())
-        v.append(env.buffer(_abi.BUF_POSE)[:, 3].copy()); wz.append(env.buffer(_abi.BUF_ANGVEL)[:, 2].copy())
-    vdes, v, vd, wz = map(np.array, (vdes, v, vd, wz))
-    assert 1.45 < vdes.mean() < 1.55           # linear_x ~ U(1, 2)
-    assert 1.20 < v.mean() < 1.45              # reference 1.343
-    assert 0.10 < vd.mean() < 0.30             # reference 0.164
-    assert np.abs(wz).mean() < 2e-5            # reference |omega| < 2e-5
-    te = np.abs(vd[-99:]).mean(axis=0)         # episode-mean |v_delta| per arena
-    assert 0.15 < te.mean() < 0.45
+def test_calibration_against_the_reference_artefacts():
+    """CALIBRATION PIN, not parity. tests/golden/ref_stats.json holds
+    what the reference's own PhysX runs left behind (tools/calibrate_physics.py --distil: the env-0
+    window means of the shipped training log, whose first 100 k steps the expert controller
+    dominates, and the README figure's controller curve) and the result of fitting the two joint
+    resistance constants to them (--fit). The shipped constants must reproduce the fitted statistic
+    to 5 %, and that statistic must sit where the reference's does."""
+    import json
+    from tests.calibration import expert_run_stats
+    ref = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "ref_stats.json")))
+    log, fit, built = ref["train_log"]["first_100000_steps"], ref["fit"], ref["build"]
+    cfg = build_config(variant="KAMMA_g11_g21", num_envs=512, seed=3)
+    assert cfg.wheel_damping == pytest.approx(fit["wheel_damping"]) and cfg.wheel_limit_damping == pytest.approx(fit["wheel_limit_damping"])
+    assert cfg.wheel_limit_velocity == 10.0  # <limit velocity="10"/>, origin_sym.urdf:117
+    env = OracleEnv(cfg, threads=4)
+    env.reset(3)
+    r = expert_run_stats(env, 512)
+    line = lambda d, x: d["slope"] * x + d["intercept"]
+    # (a) the shipped constants give the statistic the fit recorded (other seed, half the arenas): 5 %
+    assert r["v_delta"] == pytest.approx(built["v_delta"], rel=0.05)
+    assert r["slope"] == pytest.approx(built["slope"], rel=0.05)
+    for x in (1.2, 1.8):
+        assert line(r, x) == pytest.approx(line(built, x), rel=0.05, abs=0.004)
+    np.testing.assert_allclose(r["te_by_command"], built["te_by_command"], rtol=0.08)
+    # (b) against the reference's log: mean tracking error to 5 %, its dependence on the commanded
+    # speed (the line through the window means) to 0.02 m/s over the log's range
+    t = log["v_delta_vs_desired_v"]
+    assert r["v_delta"] == pytest.approx(log["v_delta"], rel=0.05)              # 0.1645
+    assert r["desired_v"] == pytest.approx(log["desired_v"], rel=0.02)          # 1.508: linear_x ~ U(1, 2)
+    assert r["current_v"] == pytest.approx(log["current_v"], rel=0.02)          # 1.343
+    assert abs(line(r, 1.3) - line(t, 1.3)) < 0.02 and abs(line(r, 1.7) - line(t, 1.7)) < 0.02
+    assert r["slope"] == pytest.approx(t["slope"], rel=0.12)                    # 0.283 vs 0.309: stated in DESIGN.md
+    # (c) against the README figure's controller curve (read off, +-0.03): U-shaped, 0.42 / 0.15 / 0.33
+    te, fig = r["te_by_command"], ref["figure_controller"]["te"]
+    assert te[2] < te[0] and te[2] < te[4]
+    assert abs(te[0] - fig["1.0-1.3"]) < 0.06 and abs(te[2] - fig["1.53"]) < 0.03 and abs(te[4] - fig["2.0"]) < 0.06
