@@ -31,7 +31,8 @@ def main(argv=None):
     value = torch.nn.Sequential(torch.nn.Linear(6, 128), torch.nn.ELU(), torch.nn.Linear(128, 1)).to(dev)
 
     states, _ = env.reset()
-    memory = DeviceFIFOMemory(env, memory_size=args.rollouts)
+    # actions='policy': PPO stores the action it sampled, beside its log_prob (ppo.py:270-272), not the executed torque
+    memory = DeviceFIFOMemory(env, memory_size=args.rollouts, actions="policy")
     for name in ("log_prob", "values", "returns", "advantages"):   # ppo.py:193-196
         memory.create_tensor(name, 1)
     names = ["states", "actions", "log_prob", "values", "returns", "advantages"]

@@ -256,7 +256,9 @@ void ois_destroy(ois_env* env);
 /* post_reset: zero all task buffers, reset_idx(all arenas) with `seed`. */
 int ois_reset(ois_env* env, uint64_t seed, void* stream);
 
-/* One policy step for all arenas. actions_device: float [N, action_dim] row-major. */
+/* One policy step for all arenas. actions_device: float [N, action_dim] row-major, aligned to
+ * action_dim * 4 bytes (the kernel reads an arena's actions with one vector load; OIS_EINVAL otherwise).
+ * Every entry point makes the env's device current for the call and restores the caller's. */
 int ois_step(ois_env* env, const float* actions_device, void* stream);
 
 /* k policy steps in ONE launch; state stays in registers between steps.
@@ -392,7 +394,13 @@ int ois_terrain_attach(ois_env* env, const ois_terrain* terrain, const int16_t* 
 int ois_height_scan(ois_env* env, float* heights_out_device, void* stream);
 
 /* Snapshot / restore the complete environment state (all persistent buffers) to/from a
- * host blob of ois_state_bytes(). Beyond reference parity (SURVEY.md §5 checkpoint). */
+ * host blob of ois_state_bytes(). Beyond reference parity (SURVEY.md §5 checkpoint).
+ * The blob carries a hash of the ois_config it was saved under, the descriptor of the attached
+ * terrain and the cursor of the attached transition memory; ois_load_state refuses (OIS_EINVAL, with
+ * the reason in ois_last_error) a blob from another config, terrain attachment or memory size —
+ * attach the same terrain / a memory of the same size first. The height field and the transition
+ * tensors themselves are caller-owned and not part of the blob; the cursor (memory_index, filled)
+ * is restored. */
 size_t ois_state_bytes(const ois_env* env);
 int ois_save_state(ois_env* env, void* host_blob, size_t bytes, void* stream);
 int ois_load_state(ois_env* env, const void* host_blob, size_t bytes, void* stream);

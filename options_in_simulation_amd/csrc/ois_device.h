@@ -70,7 +70,7 @@ struct DevBuffers {
   uint8_t* timeout;  // [N]
   float* partials;   // [ngroups][32] per-group reset-event records
   int32_t* stamps;   // [ngroups]
-  float* stat_acc;   // [ngroups][8]
+  double* stat_acc;  // [ngroups][8] finished-episode accumulators, double
   float* episode_info;  // [32]
   float* env0_diag;     // [32]
   // optional FIFO transition memory (include/ois.h ois_replay_*), rp_size = 0 when detached
@@ -445,10 +445,10 @@ OIS_DEV void group_record(const DevBuffers& B, int group, int lane, bool group_h
     for (int k = 0; k < 4; ++k) P[24 + k] = rm[k];
     B.stamps[group] = stamp;
     if (count_stats) {
-      float* A = B.stat_acc + (size_t)group * 8;
+      double* A = B.stat_acc + (size_t)group * 8;
       // A[0..3] = count, ret^2, len, ret ; A[6], A[7] = max(-ret), max(ret)
-      A[0] += rs[0]; A[1] += rs[1]; A[2] += rs[2]; A[3] += rs[11];
-      A[6] = fmaxf(A[6], rm[2]); A[7] = fmaxf(A[7], rm[3]);
+      A[0] += (double)rs[0]; A[1] += (double)rs[1]; A[2] += (double)rs[2]; A[3] += (double)rs[11];
+      A[6] = fmax(A[6], (double)rm[2]); A[7] = fmax(A[7], (double)rm[3]);
     }
   }
 }

@@ -490,8 +490,8 @@ __global__ __launch_bounds__(kBlock) void reset_kernel(DevConsts K, DevBuffers B
   reset_arena<1>(K, K.arena_offset + la, 0, g1, g2, S, rc);
   if (!valid) contrib_identity(rc);
   if ((lane & (kGroup - 1)) == 0 && valid) {  // clear the finished-episode accumulators of this group
-    float* Acc = B.stat_acc + (size_t)(arena / kGroup) * 8;
-    for (int k = 0; k < 4; ++k) { Acc[k] = 0.0f; Acc[4 + k] = -__builtin_inff(); }
+    double* Acc = B.stat_acc + (size_t)(arena / kGroup) * 8;
+    for (int k = 0; k < 4; ++k) { Acc[k] = 0.0; Acc[4 + k] = -__builtin_inf(); }
   }
   const unsigned long long m = __ballot(valid);
   group_record<1>(B, arena / kGroup, lane, group_any<1>(m, lane), rc, 0, false);
@@ -647,27 +647,28 @@ __global__ __launch_bounds__(64) void episode_final_kernel(DevConsts K, DevBuffe
   }
 }
 
-// finished-episode statistics: the same two-level order over the per-group accumulators
-__global__ __launch_bounds__(64) void stats_partial_kernel(DevBuffers B, int ngroups, float* __restrict__ part8, int reset_after) {
+// finished-episode statistics: the same two-level order over the per-group accumulators, in double
+// (sum of squared returns of millions of episodes: the variance is a difference of two large numbers)
+__global__ __launch_bounds__(64) void stats_partial_kernel(DevBuffers B, int ngroups, double* __restrict__ part8, int reset_after) {
   const int c = blockIdx.x, t = threadIdx.x;
   if (t >= 8) return;
   const int g0 = c * kChunkGroups, g1 = min(g0 + kChunkGroups, ngroups);
-  float a = t < 4 ? 0.0f : -__builtin_inff();
+  double a = t < 4 ? 0.0 : -__builtin_inf();
   for (int g = g0; g < g1; ++g) {
-    float* p = B.stat_acc + (size_t)g * 8 + t;
-    const float x = *p;
-    a = t < 4 ? a + x : fmaxf(a, x);
-    if (reset_after) *p = t < 4 ? 0.0f : -__builtin_inff();
+    double* p = B.stat_acc + (size_t)g * 8 + t;
+    const double x = *p;
+    a = t < 4 ? a + x : fmax(a, x);
+    if (reset_after) *p = t < 4 ? 0.0 : -__builtin_inf();
   }
   part8[(size_t)c * 8 + t] = a;
 }
-__global__ __launch_bounds__(64) void stats_final_kernel(int nchunks, const float* __restrict__ part8, float* __restrict__ out8) {
+__global__ __launch_bounds__(64) void stats_final_kernel(int nchunks, const double* __restrict__ part8, double* __restrict__ out8) {
   const int t = threadIdx.x;
   if (t >= 8) return;
-  float a = t < 4 ? 0.0f : -__builtin_inff();
+  double a = t < 4 ? 0.0 : -__builtin_inf();
   for (int c = 0; c < nchunks; ++c) {
-    const float x = part8[(size_t)c * 8 + t];
-    a = t < 4 ? a + x : fmaxf(a, x);
+    const double x = part8[(size_t)c * 8 + t];
+    a = t < 4 ? a + x : fmax(a, x);
   }
   out8[t] = a;
 }
@@ -713,6 +714,23 @@ int fail(int code, const char* fmt, const char* detail = "") {
 
 size_t align256(size_t x) { return (x + 255) & ~(size_t)255; }
 
+// Makes `device` current for the scope of one entry point and puts the caller's device back on the
+// way out: a process that drives several GPUs (torch on cuda:0, an env on cuda:1) keeps its own
+// current device across library calls.
+struct DeviceGuard {
+  int prev = -1;
+  hipError_t err = hipSuccess;
+  explicit DeviceGuard(int device) {
+    err = hipGetDevice(&prev);
+    if (err == hipSuccess && prev != device) err = hipSetDevice(device);
+    else if (err == hipSuccess) prev = -1;  // already current: nothing to restore
+  }
+  ~DeviceGuard() { if (prev >= 0) (void)hipSetDevice(prev); }
+};
+#define OIS_ON_DEVICE(dev_)            \
+  DeviceGuard device_guard_(dev_);     \
+  HIP_TRY(device_guard_.err)
+
 struct Layout {
   size_t off[OIS_BUF_COUNT_];
   size_t bytes[OIS_BUF_COUNT_];
@@ -743,13 +761,13 @@ Layout make_layout(int N) {
   L.nwaves = (N + kGroup - 1) / kGroup;  // reduction groups of 16 arenas
   L.partials = o; o = align256(o + (size_t)L.nwaves * 32 * sizeof(float));
   L.stamps = o; o = align256(o + (size_t)L.nwaves * sizeof(int32_t));
-  L.stat_acc = o; o = align256(o + (size_t)L.nwaves * 8 * sizeof(float));
-  L.stat_out = o; o = align256(o + 32 * sizeof(float));  // 8 stats out / 16-entry slope table scratch
+  L.stat_acc = o; o = align256(o + (size_t)L.nwaves * 8 * sizeof(double));
+  L.stat_out = o; o = align256(o + 32 * sizeof(double));  // 8 stats out (double) / 16-entry slope table scratch (float)
   L.nchunks = (L.nwaves + kChunkGroups - 1) / kChunkGroups;  // level-1 partials of the logging reductions
   L.red_part = o; o = align256(o + (size_t)L.nchunks * 32 * sizeof(float));
   L.red_cmax = o; o = align256(o + (size_t)L.nchunks * sizeof(int));
   L.red_lvl = o; o = align256(o + (size_t)L.nchunks * sizeof(long long));
-  L.red_part8 = o; o = align256(o + (size_t)L.nchunks * 8 * sizeof(float));
+  L.red_part8 = o; o = align256(o + (size_t)L.nchunks * 8 * sizeof(double));
   L.reset_stamp = o; o = align256(o + sizeof(int32_t));
   L.total = o;
   return L;
@@ -852,6 +870,7 @@ struct ois_env {
   size_t rp_off[OIS_RP_COUNT_], rp_bytes[OIS_RP_COUNT_];
   int rp_head;
   bool rp_filled;
+  ois_terrain tdesc;  // descriptor of the attached terrain (B.ter.on says whether one is)
   // ois_profile_*: start / stop events attached to the step kernel's own dispatch packets
   bool prof_on;
   std::vector<hipEvent_t> prof_ev;  // pairs; [2 i] start, [2 i + 1] stop
@@ -943,7 +962,7 @@ int ois_create(const ois_config* cfg, int device, void* workspace_device, size_t
   int ndev = 0;
   HIP_TRY(hipGetDeviceCount(&ndev));
   if (device < 0 || device >= ndev) return fail(OIS_EINVAL, "device ordinal out of range");
-  HIP_TRY(hipSetDevice(device));
+  OIS_ON_DEVICE(device);
   ois_env* e = new (std::nothrow) ois_env;
   if (!e) return fail(OIS_ENOMEM, "host allocation failed");
   e->cfg = *cfg;
@@ -992,7 +1011,7 @@ int ois_create(const ois_config* cfg, int device, void* workspace_device, size_t
   B.obs = (float*)(w + L.off[OIS_BUF_OBS]); B.rew = (float*)(w + L.off[OIS_BUF_REW]);
   B.done = (uint8_t*)(w + L.off[OIS_BUF_DONE]); B.timeout = (uint8_t*)(w + L.off[OIS_BUF_TIMEOUT]);
   B.episode_info = (float*)(w + L.off[OIS_BUF_EPISODE_INFO]); B.env0_diag = (float*)(w + L.off[OIS_BUF_ENV0_DIAG]);
-  B.partials = (float*)(w + L.partials); B.stamps = (int32_t*)(w + L.stamps); B.stat_acc = (float*)(w + L.stat_acc);
+  B.partials = (float*)(w + L.partials); B.stamps = (int32_t*)(w + L.stamps); B.stat_acc = (double*)(w + L.stat_acc);
   B.rp_states = B.rp_actions = B.rp_rewards = B.rp_next = nullptr; B.rp_done = nullptr; B.rp_size = 0;
   B.env_origins = (float4*)(w + L.off[OIS_BUF_ENV_ORIGINS]); B.terrain_idx = (int4*)(w + L.off[OIS_BUF_TERRAIN_IDX]);
   B.cmd_fraction = (float*)(w + L.off[OIS_BUF_CMD_FRACTION]); B.reset_stamp = (int32_t*)(w + L.reset_stamp);
@@ -1030,7 +1049,7 @@ int ois_profile_begin(ois_env* e) {
 int ois_profile_end(ois_env* e, double* kernel_ms_total, long long* launches) {
   if (!e || !kernel_ms_total || !launches) return fail(OIS_EINVAL, "null argument");
   if (!e->prof_on) return fail(OIS_ESTATE, "ois_profile_end without ois_profile_begin");
-  HIP_TRY(hipSetDevice(e->device));
+  OIS_ON_DEVICE(e->device);
   const size_t live = e->prof_used < e->prof_ev.size() / 2 ? e->prof_used : e->prof_ev.size() / 2;
   double ms_total = e->prof_ms;
   for (size_t i = 0; i < live; ++i) {
@@ -1046,7 +1065,7 @@ int ois_profile_end(ois_env* e, double* kernel_ms_total, long long* launches) {
 
 int ois_reset(ois_env* e, uint64_t seed, void* stream) {
   if (!e) return fail(OIS_EINVAL, "null env");
-  HIP_TRY(hipSetDevice(e->device));
+  OIS_ON_DEVICE(e->device);
   e->seed = seed;
   e->K.seed_lo = (uint32_t)(seed & 0xffffffffu);
   e->K.seed_hi = (uint32_t)(seed >> 32);
@@ -1078,7 +1097,7 @@ static int prof_next_pair(ois_env* e, hipEvent_t* a, hipEvent_t* b) {
 }
 
 static int launch_kernel(ois_env* e, int k, int policy, const float* actions, float* reward_sum, void* stream) {
-  HIP_TRY(hipSetDevice(e->device));
+  OIS_ON_DEVICE(e->device);
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
   if (e->prof_on) {
     int rc = prof_next_pair(e, &ev0, &ev1);
@@ -1139,6 +1158,8 @@ int ois_step(ois_env* e, const float* actions_device, void* stream) {
   if (!e) return fail(OIS_EINVAL, "null env");
   if (!actions_device) return fail(OIS_EINVAL, "null actions");
   if (!e->reset_done) return fail(OIS_ESTATE, "ois_step called before ois_reset");
+  if (((uintptr_t)actions_device & (uintptr_t)(4 * e->K.action_dim - 1)) != 0)
+    return fail(OIS_EINVAL, "actions must be aligned to action_dim * 4 bytes (one vector load per arena)");
   return launch_steps(e, 1, OIS_POLICY_EXTERNAL, actions_device, nullptr, stream);
 }
 
@@ -1147,6 +1168,8 @@ int ois_rollout(ois_env* e, int k, int policy, const float* actions_device, floa
   if (k < 1 || k > (1 << 20)) return fail(OIS_EINVAL, "k out of range");
   if (policy < OIS_POLICY_ZERO || policy > OIS_POLICY_EXTERNAL) return fail(OIS_EINVAL, "unknown policy");
   if (policy == OIS_POLICY_EXTERNAL && !actions_device) return fail(OIS_EINVAL, "EXTERNAL policy needs actions");
+  if (policy == OIS_POLICY_EXTERNAL && ((uintptr_t)actions_device & (uintptr_t)(4 * e->K.action_dim - 1)) != 0)
+    return fail(OIS_EINVAL, "actions must be aligned to action_dim * 4 bytes (one vector load per arena)");
   if (!e->reset_done) return fail(OIS_ESTATE, "ois_rollout called before ois_reset");
   return launch_steps(e, k, policy, actions_device, reward_sum_device, stream);
 }
@@ -1162,7 +1185,7 @@ int ois_buffer(ois_env* e, int id, void** ptr_device, size_t* bytes) {
 int ois_randomize_params(ois_env* e, float mu_lo, float mu_hi, const float* slopes_host, int n_slopes, void* stream) {
   if (!e) return fail(OIS_EINVAL, "null env");
   if (n_slopes < 0 || n_slopes > 16 || (n_slopes > 0 && !slopes_host)) return fail(OIS_EINVAL, "bad slopes (0..16 values)");
-  HIP_TRY(hipSetDevice(e->device));
+  OIS_ON_DEVICE(e->device);
   float* tbl = (float*)(e->ws + e->L.stat_out);  // scratch shared with ois_stats_fetch
   if (n_slopes > 0) HIP_TRY(hipMemcpyAsync(tbl, slopes_host, (size_t)n_slopes * sizeof(float), hipMemcpyHostToDevice, (hipStream_t)stream));
   DevConsts K = e->K;  // keyed by the CONFIG seed: arena parameters do not change with ois_reset(seed)
@@ -1178,7 +1201,7 @@ int ois_randomize_params(ois_env* e, float mu_lo, float mu_hi, const float* slop
 int ois_terrain_attach(ois_env* e, const ois_terrain* t, const int16_t* heights_device, int16_t* minfield_device,
                        const float* terrain_origins_device, const int32_t* levels_types_host, void* stream) {
   if (!e) return fail(OIS_EINVAL, "null env");
-  HIP_TRY(hipSetDevice(e->device));
+  OIS_ON_DEVICE(e->device);
   hipStream_t s = (hipStream_t)stream;
   const size_t f4 = (size_t)e->N * 4 * sizeof(float);
   if (!t) {  // detach: back to the per-arena plane, origins and indices cleared
@@ -1222,6 +1245,7 @@ int ois_terrain_attach(ois_env* e, const ois_terrain* t, const int16_t* heights_
   T.curriculum = t->curriculum; T.on = 1;
   T.hs = t->horizontal_scale; T.inv_hs = 1.0f / t->horizontal_scale; T.vs = t->vertical_scale; T.border = t->border_size;
   T.thr_lo = t->threshold_low; T.thr_hi = t->threshold_high;
+  e->tdesc = *t;
   // terrain.curriculum also switches the commands to the per-level generators (KAMMA.py:533, 719)
   e->K.cmd_sampler = t->curriculum ? OIS_CMD_LEVEL : e->cfg.cmd_sampler;
   if (t->curriculum && !(e->K.cmd_thr_high > 0.0f)) e->K.cmd_thr_high = 10.0f;
@@ -1232,7 +1256,7 @@ int ois_height_scan(ois_env* e, float* heights_out_device, void* stream) {
   if (!e || !heights_out_device) return fail(OIS_EINVAL, "null argument");
   if (!e->B.ter.on) return fail(OIS_ESTATE, "ois_height_scan needs an attached terrain");
   if (!e->reset_done) return fail(OIS_ESTATE, "ois_height_scan called before ois_reset");
-  HIP_TRY(hipSetDevice(e->device));
+  OIS_ON_DEVICE(e->device);
   const size_t pts = (size_t)e->N * OIS_HEIGHT_POINTS;
   hipLaunchKernelGGL(height_scan_kernel, dim3((unsigned)((pts + 255) / 256)), dim3(256), 0, (hipStream_t)stream, e->K, e->B,
                      e->N, heights_out_device);
@@ -1243,7 +1267,7 @@ int ois_height_scan(ois_env* e, float* heights_out_device, void* stream) {
 int ois_episode_info(ois_env* e, void* stream) {
   if (!e) return fail(OIS_EINVAL, "null env");
   if (!e->reset_done) return fail(OIS_ESTATE, "ois_episode_info called before ois_reset");
-  HIP_TRY(hipSetDevice(e->device));
+  OIS_ON_DEVICE(e->device);
   float* part = (float*)(e->ws + e->L.red_part);
   int* cmax = (int*)(e->ws + e->L.red_cmax);
   long long* lvl = (long long*)(e->ws + e->L.red_lvl);
@@ -1258,17 +1282,17 @@ int ois_episode_info(ois_env* e, void* stream) {
 int ois_stats_fetch(ois_env* e, ois_stats* out, int reset_after, void* stream) {
   if (!e || !out) return fail(OIS_EINVAL, "null argument");
   if (!e->reset_done) return fail(OIS_ESTATE, "ois_stats_fetch called before ois_reset");
-  HIP_TRY(hipSetDevice(e->device));
-  float* d = (float*)(e->ws + e->L.stat_out);
-  float* part8 = (float*)(e->ws + e->L.red_part8);
+  OIS_ON_DEVICE(e->device);
+  double* d = (double*)(e->ws + e->L.stat_out);
+  double* part8 = (double*)(e->ws + e->L.red_part8);
   hipLaunchKernelGGL(stats_partial_kernel, dim3(e->L.nchunks), dim3(64), 0, (hipStream_t)stream, e->B, e->L.nwaves, part8, reset_after);
   hipLaunchKernelGGL(stats_final_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, e->L.nchunks, part8, d);
   HIP_TRY(hipGetLastError());
-  float h[8];
+  double h[8];
   HIP_TRY(hipMemcpyAsync(h, d, sizeof h, hipMemcpyDeviceToHost, (hipStream_t)stream));
   HIP_TRY(hipStreamSynchronize((hipStream_t)stream));
   out->episodes = h[0]; out->return_sqsum = h[1]; out->length_sum = h[2]; out->return_sum = h[3];
-  out->return_min = -(double)h[6]; out->return_max = h[7];
+  out->return_min = -h[6]; out->return_max = h[7];
   out->steps = e->steps_done; out->reserved = 0.0;
   if (reset_after) e->steps_done = 0.0;
   return OIS_OK;
@@ -1276,7 +1300,7 @@ int ois_stats_fetch(ois_env* e, ois_stats* out, int reset_after, void* stream) {
 
 int ois_env0_diag(ois_env* e, float* host_out, void* stream) {
   if (!e || !host_out) return fail(OIS_EINVAL, "null argument");
-  HIP_TRY(hipSetDevice(e->device));
+  OIS_ON_DEVICE(e->device);
   HIP_TRY(hipMemcpyAsync(host_out, e->B.env0_diag, OIS_ENV0_DIAG_LEN * sizeof(float), hipMemcpyDeviceToHost, (hipStream_t)stream));
   HIP_TRY(hipStreamSynchronize((hipStream_t)stream));
   return OIS_OK;
@@ -1333,14 +1357,31 @@ struct StateHeader {
   uint64_t seed;
   double steps_done;
   uint64_t payload;
+  uint64_t config_hash;   // every field of ois_config: variant switches, arena_offset, task and physics constants
+  uint64_t terrain_hash;  // descriptor of the attached terrain, 0 = none
+  int32_t rp_size, rp_head, rp_filled;  // transition memory cursor (the memory itself is the caller's)
+  int32_t cmd_sampler;    // effective sampler (a terrain with curriculum switches it)
 };
+
+static uint64_t fnv1a(const void* p, size_t n, uint64_t h = 1469598103934665603ull) {
+  const unsigned char* b = (const unsigned char*)p;
+  for (size_t i = 0; i < n; ++i) { h ^= b[i]; h *= 1099511628211ull; }
+  return h;
+}
+static uint64_t terrain_hash(const ois_env* e) {
+  if (!e->B.ter.on) return 0;
+  const ois_terrain& t = e->tdesc;
+  const int32_t iv[7] = {t.rows, t.cols, t.num_levels, t.num_types, t.curriculum, t.max_level, 1};
+  const float fv[5] = {t.horizontal_scale, t.vertical_scale, t.border_size, t.threshold_low, t.threshold_high};
+  return fnv1a(fv, sizeof fv, fnv1a(iv, sizeof iv)) | 1ull;
+}
 
 int ois_replay_sample(ois_env* e, const int64_t* indexes_device, int count, float* states_out, float* actions_out,
                       float* rewards_out, float* next_states_out, uint8_t* terminated_out, void* stream) {
   if (!e || !indexes_device) return fail(OIS_EINVAL, "null argument");
   if (e->B.rp_size <= 0) return fail(OIS_ESTATE, "no replay memory attached");
   if (count < 1) return fail(OIS_EINVAL, "count must be >= 1");
-  HIP_TRY(hipSetDevice(e->device));
+  OIS_ON_DEVICE(e->device);
   const size_t rows = (size_t)e->B.rp_size * (size_t)e->N;
   hipLaunchKernelGGL(replay_sample_kernel, dim3((count + 255) / 256), dim3(256), 0, (hipStream_t)stream, e->B, rows, indexes_device,
                      count, states_out, actions_out, rewards_out, next_states_out, terminated_out);
@@ -1353,8 +1394,13 @@ size_t ois_state_bytes(const ois_env* e) { return e ? sizeof(StateHeader) + e->L
 int ois_save_state(ois_env* e, void* host_blob, size_t bytes, void* stream) {
   if (!e || !host_blob) return fail(OIS_EINVAL, "null argument");
   if (bytes < ois_state_bytes(e)) return fail(OIS_ENOMEM, "blob smaller than ois_state_bytes()");
-  HIP_TRY(hipSetDevice(e->device));
-  StateHeader h = {0x3053494fu /* "OIS0" */, OIS_ABI_VERSION, e->N, e->reset_done ? 1 : 0, e->seed, e->steps_done, e->L.total};
+  OIS_ON_DEVICE(e->device);
+  StateHeader h;
+  std::memset(&h, 0, sizeof h);
+  h.magic = 0x3053494fu /* "OIS0" */; h.abi = OIS_ABI_VERSION; h.num_envs = e->N; h.reset_done = e->reset_done ? 1 : 0;
+  h.seed = e->seed; h.steps_done = e->steps_done; h.payload = e->L.total;
+  h.config_hash = fnv1a(&e->cfg, sizeof e->cfg); h.terrain_hash = terrain_hash(e);
+  h.rp_size = e->B.rp_size; h.rp_head = e->rp_head; h.rp_filled = e->rp_filled ? 1 : 0; h.cmd_sampler = e->K.cmd_sampler;
   std::memcpy(host_blob, &h, sizeof h);
   HIP_TRY(hipMemcpyAsync((char*)host_blob + sizeof h, e->ws, e->L.total, hipMemcpyDeviceToHost, (hipStream_t)stream));
   HIP_TRY(hipStreamSynchronize((hipStream_t)stream));
@@ -1368,7 +1414,15 @@ int ois_load_state(ois_env* e, const void* host_blob, size_t bytes, void* stream
   std::memcpy(&h, host_blob, sizeof h);
   if (h.magic != 0x3053494fu || h.abi != OIS_ABI_VERSION) return fail(OIS_EINVAL, "not an ois state blob of this ABI");
   if (h.num_envs != e->N || h.payload != e->L.total || bytes < sizeof h + h.payload) return fail(OIS_EINVAL, "state blob does not match this environment");
-  HIP_TRY(hipSetDevice(e->device));
+  if (h.config_hash != fnv1a(&e->cfg, sizeof e->cfg))
+    return fail(OIS_EINVAL, "state blob was saved under a different ois_config (variant, arena_offset, task or physics constants)");
+  if (h.terrain_hash != terrain_hash(e))
+    return fail(OIS_EINVAL, h.terrain_hash ? "state blob was saved with a terrain attached: attach the same terrain (ois_terrain_attach) before ois_load_state"
+                                           : "state blob was saved on the plane: detach the terrain before ois_load_state");
+  if (h.rp_size != e->B.rp_size)
+    return fail(OIS_EINVAL, h.rp_size ? "state blob was saved with a transition memory attached: attach one of the same size (its tensors are the caller's to restore) before ois_load_state"
+                                      : "state blob was saved without a transition memory: detach it before ois_load_state");
+  OIS_ON_DEVICE(e->device);
   HIP_TRY(hipMemcpyAsync(e->ws, (const char*)host_blob + sizeof h, e->L.total, hipMemcpyHostToDevice, (hipStream_t)stream));
   HIP_TRY(hipStreamSynchronize((hipStream_t)stream));
   e->reset_done = h.reset_done != 0;
@@ -1376,6 +1430,7 @@ int ois_load_state(ois_env* e, const void* host_blob, size_t bytes, void* stream
   e->K.seed_lo = (uint32_t)(h.seed & 0xffffffffu);
   e->K.seed_hi = (uint32_t)(h.seed >> 32);
   e->steps_done = h.steps_done;
+  e->rp_head = h.rp_head; e->rp_filled = h.rp_filled != 0;
   return OIS_OK;
 }
 

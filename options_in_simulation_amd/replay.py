@@ -8,6 +8,18 @@ filled part. The difference: nobody calls ``add_samples`` for the transition its
 torques / action_scale as the trainer substitutes at src/my_trainers/base_KA_DDPG.py:212,
 rewards, next_states, terminated), so a training loop needs no per-step host work for it.
 
+Which actions a row holds (``actions=`` of the constructor):
+
+* ``"executed"`` — the kernel-written ``wheel_torqs / action_scale`` [4]: what
+  ``base_KA_DDPG.py:212`` records, i.e. the trainer of the KAMMA and ``kaddpg_4d`` scripts. Whatever
+  ``add_samples(actions=...)`` is handed is ignored, as that trainer overwrites it too.
+* ``"policy"`` — the agent's own action, width ``action_dim``: what ``base_KA`` (train_kaddpg_1d / 2d
+  via ``sequential_KA``) and PPO's ``record_transition`` (ppo.py:270-272, the sampled action whose
+  ``log_prob`` sits beside it) store. When gamma1 > 0 or the clip is active the executed torque is
+  not the policy's action, and a PPO ratio or a 1-D / 2-D critic trained on it would be wrong, so
+  here ``add_samples(actions=...)`` copies the passed actions into the row; the executed ones stay
+  available as ``executed_actions``. Default for ``action_dim != 4`` (the executed width is always 4).
+
 The on-policy agents keep more per step (``log_prob``, ``values``, later ``returns`` and
 ``advantages``: src/my_agents/ppo.py:189-196): ``create_tensor`` adds such tensors beside the
 kernel-written ones and ``add_samples(**tensors)`` puts the agent's values into the row the
@@ -59,7 +71,8 @@ def indices_without_replacement(size: int, batch_size: int, device, generator=No
 
 
 class DeviceFIFOMemory:
-    def __init__(self, env: "VecEnv | NativeEnv", memory_size: int, replacement: bool = False):
+    def __init__(self, env: "VecEnv | NativeEnv", memory_size: int, replacement: bool = False,
+                 actions: Optional[str] = None):
         native = env.task.native if isinstance(env, VecEnv) else env
         self.native = native
         self.memory_size = int(memory_size)
@@ -68,6 +81,19 @@ class DeviceFIFOMemory:
         self.replacement = replacement
         self.tensors: Dict[str, torch.Tensor] = native.attach_replay(self.memory_size)
         self.sampling_indexes = None
+        if actions is None:
+            actions = "executed" if native.A == 4 else "policy"
+        if actions not in ("executed", "policy"):
+            raise ValueError("actions must be 'executed' or 'policy'")
+        if actions == "executed" and native.A != 4:
+            raise ValueError(f"executed actions are the 4 wheel torques; this task's action_dim is {native.A}: use actions='policy'")
+        self.actions_mode = actions
+        self._kernel_tensors = KERNEL_TENSORS
+        if actions == "policy":
+            # the kernel keeps writing the executed torques; the row's `actions` becomes the agent's own
+            self.tensors["executed_actions"] = self.tensors["actions"]
+            self.tensors["actions"] = torch.zeros((self.memory_size, self.num_envs, native.A), dtype=torch.float32, device=self.device)
+            self._kernel_tensors = tuple(n for n in KERNEL_TENSORS if n != "actions")
 
     # ---- skrl Memory surface used by the agents ---------------------------------------------
     @property
@@ -90,8 +116,9 @@ class DeviceFIFOMemory:
         kernel-written ones (``log_prob``, ``values``, ``returns``, ``advantages`` …). The five
         transition tensors exist already; asking for one of them only checks its width."""
         if name in self.tensors:
-            if name in KERNEL_TENSORS and self.tensors[name].shape[-1] != int(size):
-                raise ValueError(f"{name} is written by the step kernel with width {self.tensors[name].shape[-1]}, not {size}")
+            if (name in KERNEL_TENSORS or name == "executed_actions") and self.tensors[name].shape[-1] != int(size):
+                raise ValueError(f"{name} exists with width {self.tensors[name].shape[-1]}, not {size}"
+                                 + (" (the executed wheel torques; actions='policy' stores the agent's own)" if name == "actions" else ""))
             return False
         self.tensors[name] = torch.zeros((self.memory_size, self.num_envs, int(size)), dtype=dtype or torch.float32,
                                          device=self.device)
@@ -99,12 +126,13 @@ class DeviceFIFOMemory:
 
     def add_samples(self, **tensors: torch.Tensor) -> None:
         """Complete the row the step kernel has just written (call after ``env.step``) with the
-        agent's own per-step tensors. Transition tensors passed along (states, actions, …), as
-        ``record_transition`` does (ppo.py:270-272), are ignored: the kernel wrote them."""
+        agent's own per-step tensors. Transition tensors the kernel wrote (states, rewards, …, and the
+        actions in ``"executed"`` mode), passed along as ``record_transition`` does (ppo.py:270-272),
+        are ignored; in ``"policy"`` mode the passed ``actions`` are stored."""
         idx, _ = self.native.replay_cursor()
         row = (idx - 1) % self.memory_size
         for name, value in tensors.items():
-            if name in KERNEL_TENSORS or name == "truncated":
+            if name in self._kernel_tensors or name in ("truncated", "executed_actions"):
                 continue
             if name not in self.tensors:
                 raise KeyError(f"unknown memory tensor {name!r}: create_tensor() it first")
@@ -119,7 +147,7 @@ class DeviceFIFOMemory:
 
     def _gather(self, names: Sequence[str], indexes: torch.Tensor) -> List[torch.Tensor]:
         """the kernel-written tensors in one launch (ois_replay_sample), the agent's own by indexing"""
-        fused = [n for n in names if n in KERNEL_TENSORS]
+        fused = [n for n in names if n in self._kernel_tensors]
         got = self.native.replay_sample(indexes, fused) if fused else {}
         for n in names:
             if n not in got:

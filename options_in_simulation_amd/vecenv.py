@@ -80,6 +80,7 @@ class NativeEnv:
             t = raw.view(dt)
             self._views[bid] = t.view(-1, cols) if cols else t
         self.policy_steps = 0
+        self.epoch = 0  # bumped by everything that changes device state: the key of the host-side log caches
 
     # ---- lifetime ----
     def close(self):
@@ -104,6 +105,7 @@ class NativeEnv:
         seed = int(self.cfg.seed if seed is None else seed) & 0xFFFFFFFFFFFFFFFF
         _native.check(self.L.ois_reset(self.h, seed, _stream_ptr(self.device)))
         self.policy_steps = 0
+        self.epoch += 1
 
     def _check_actions(self, actions: torch.Tensor, k: Optional[int] = None) -> torch.Tensor:
         shape = (self.N, self.A) if k is None else (k, self.N, self.A)
@@ -123,6 +125,7 @@ class NativeEnv:
         a = self._check_actions(actions)
         _native.check(self.L.ois_step(self.h, C.c_void_p(a.data_ptr()), _stream_ptr(self.device)))
         self.policy_steps += 1
+        self.epoch += 1
         self._last_actions = a  # keep alive until the stream has consumed it
 
     def rollout(self, k: int, policy: int, actions: Optional[torch.Tensor] = None,
@@ -142,6 +145,7 @@ class NativeEnv:
             r_ptr = C.c_void_p(reward_sum.data_ptr())
         _native.check(self.L.ois_rollout(self.h, int(k), int(policy), a_ptr, r_ptr, _stream_ptr(self.device)))
         self.policy_steps += int(k)
+        self.epoch += 1
 
     def profile_begin(self):
         """start kernel-only timing of the step launches (include/ois.h ois_profile_begin)"""
@@ -169,7 +173,7 @@ class NativeEnv:
         return st
 
     def env0_diag(self) -> np.ndarray:
-        if getattr(self, "_logs_step", -1) == self.policy_steps:
+        if getattr(self, "_logs_epoch", -1) == self.epoch:
             return self._logs[1]
         out = np.zeros(_abi.ENV0_DIAG_LEN, np.float32)
         _native.check(self.L.ois_env0_diag(self.h, out.ctypes.data_as(C.POINTER(C.c_float)), _stream_ptr(self.device)))
@@ -180,7 +184,7 @@ class NativeEnv:
         synchronisation: the finalisation kernels are enqueued, then the two adjacent 128-byte
         blocks come over in a single copy. A trainer that reads both every step
         (base_KA_DDPG.py:184-262) otherwise drains the pipeline twice."""
-        if getattr(self, "_logs_step", -1) != self.policy_steps:
+        if getattr(self, "_logs_epoch", -1) != self.epoch:
             info, diag = self.episode_info(), self._views[_abi.BUF_ENV0_DIAG]
             base = self.workspace.data_ptr()
             lo = min(info.data_ptr(), diag.data_ptr()) - base
@@ -188,7 +192,7 @@ class NativeEnv:
             blob = self.workspace[lo:hi].cpu().numpy().view(np.float32)
             i0, d0 = (info.data_ptr() - base - lo) // 4, (diag.data_ptr() - base - lo) // 4
             self._logs = (blob[i0:i0 + _abi.EPISODE_INFO_LEN].copy(), blob[d0:d0 + _abi.ENV0_DIAG_LEN].copy())
-            self._logs_step = self.policy_steps
+            self._logs_epoch = self.epoch
         return self._logs
 
     def attach_terrain(self, terrain, levels_types: np.ndarray, curriculum: Optional[bool] = None,
@@ -216,11 +220,13 @@ class NativeEnv:
                                                 C.c_void_p(minfield.data_ptr()), C.c_void_p(origins.data_ptr()),
                                                 lt.ctypes.data_as(C.POINTER(C.c_int32)), _stream_ptr(self.device)))
         self._terrain = (field, minfield, origins, t)  # the library reads them on every step: keep them alive
+        self.epoch += 1
 
     def detach_terrain(self):
         torch.cuda.synchronize(self.device)
         _native.check(self.L.ois_terrain_attach(self.h, None, None, None, None, None, _stream_ptr(self.device)))
         self._terrain = None
+        self.epoch += 1
 
     def height_scan(self, out: Optional[torch.Tensor] = None) -> torch.Tensor:
         """get_heights (KAMMA.py:872-893): measured_heights [N, 140] of the current state."""
@@ -284,6 +290,7 @@ class NativeEnv:
     def load_state(self, blob: bytes):
         buf = (C.c_uint8 * len(blob)).from_buffer_copy(blob)
         _native.check(self.L.ois_load_state(self.h, C.cast(buf, C.c_void_p), len(blob), _stream_ptr(self.device)))
+        self.epoch += 1
 
 
 class _LazyEpisodeInfo(dict):
@@ -296,10 +303,15 @@ class _LazyEpisodeInfo(dict):
     def __init__(self, native: NativeEnv, eval_keys: bool, on_host: bool = True):
         super().__init__()
         self._native, self._eval, self._done, self._on_host = native, eval_keys, False, on_host
+        self._epoch = native.epoch  # the step this dict belongs to
 
     def _materialize(self):
         if self._done:
             return
+        if self._native.epoch != self._epoch:
+            raise RuntimeError("infos['episode'] of an earlier step was first read after the environment moved on "
+                               "(the values live in one device buffer that every step overwrites): read it, or "
+                               "dict(infos['episode']), before the next step() / reset() / load_state()")
         self._done = True
         if self._on_host:
             vec = torch.from_numpy(self._native.host_logs()[0])  # shares its one copy with observed_components
@@ -427,7 +439,7 @@ class TorqueDistributionTask:
     # ---- env-0 diagnostics (KAMMA.py:840-867), read lazily: one 128-byte D2H copy per step ----
     @property
     def observed_components(self) -> Dict[str, float]:
-        if self._diag_step != self.native.policy_steps:
+        if self._diag_step != self.native.epoch:
             # a loop that also reads infos["episode"] every step gets both blocks in one copy
             combined = getattr(self.native, "_infos_read", False) and self.infos_on_host
             d = (self.native.host_logs()[1] if combined else self.native.env0_diag()).astype(np.float64)
@@ -450,7 +462,7 @@ class TorqueDistributionTask:
                 "env0_perc_guiding": perc(d[26], g2),
             }
             self._diag_cache = {k: (v if isinstance(v, int) else float(v)) for k, v in self._diag_cache.items()}
-            self._diag_step = self.native.policy_steps
+            self._diag_step = self.native.epoch
         return self._diag_cache
 
     # ---- terrain (KAMMA.py:296-349, 872-893; commented out in the reference's task) ----

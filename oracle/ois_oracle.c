@@ -746,7 +746,7 @@ struct orc_env {
   float env0_diag[OIS_ENV0_DIAG_LEN];
   float* partials;  /* [G][PART_STRIDE] */
   int32_t* stamps;  /* [G] */
-  float* stat_acc;  /* [G][ST_STRIDE] */
+  double* stat_acc; /* [G][ST_STRIDE] finished-episode accumulators, double */
   /* height-field terrain (mirror of ois_terrain_attach): own copies of the field and the table */
   int terrain_on;
   ois_terrain tcfg;
@@ -791,7 +791,7 @@ int orc_create(const ois_config* cfg, orc_env** out) {
   e->terrain_idx = zalloc((size_t)N * 4 * sizeof(int32_t));
   e->partials = zalloc((size_t)G * PART_STRIDE * sizeof(float));
   e->stamps = zalloc((size_t)G * sizeof(int32_t));
-  e->stat_acc = zalloc((size_t)G * ST_STRIDE * sizeof(float));
+  e->stat_acc = zalloc((size_t)G * ST_STRIDE * sizeof(double));
   for (int i = 0; i < N; ++i) {
     e->params[4 * i + 0] = cfg->friction;
     e->params[4 * i + 1] = 0.0f; e->params[4 * i + 2] = 0.0f; e->params[4 * i + 3] = 1.0f;
@@ -1013,20 +1013,20 @@ static void group_reduce(orc_env* e, int g, const uint8_t* rs, const reset_contr
   P[P_LEN] = tree16(x, n, 0.0f, 0);
   e->stamps[g] = stamp;
   if (count_stats) {
-    float* A = &e->stat_acc[(size_t)g * ST_STRIDE];
-    A[ST_COUNT] += P[OIS_EI_COUNT];
-    A[ST_RET] += P[OIS_EI_FINAL];
-    A[ST_RET2] += P[P_RET2];
-    A[ST_RMIN] = fminf(A[ST_RMIN], P[P_RMIN]);
-    A[ST_RMAX] = fmaxf(A[ST_RMAX], P[P_RMAX]);
-    A[ST_LEN] += P[P_LEN];
+    double* A = &e->stat_acc[(size_t)g * ST_STRIDE];
+    A[ST_COUNT] += (double)P[OIS_EI_COUNT];
+    A[ST_RET] += (double)P[OIS_EI_FINAL];
+    A[ST_RET2] += (double)P[P_RET2];
+    A[ST_RMIN] = fmin(A[ST_RMIN], (double)P[P_RMIN]);
+    A[ST_RMAX] = fmax(A[ST_RMAX], (double)P[P_RMAX]);
+    A[ST_LEN] += (double)P[P_LEN];
   }
 }
 
 static void stats_clear(orc_env* e) {
   for (int g = 0; g < e->G; ++g) {
-    float* A = &e->stat_acc[(size_t)g * ST_STRIDE];
-    memset(A, 0, ST_STRIDE * sizeof(float));
+    double* A = &e->stat_acc[(size_t)g * ST_STRIDE];
+    memset(A, 0, ST_STRIDE * sizeof(double));
     A[ST_RMIN] = INFINITY;
     A[ST_RMAX] = -INFINITY;
   }
@@ -1465,14 +1465,14 @@ int orc_episode_info(orc_env* e) {
 
 int orc_stats_fetch(orc_env* e, ois_stats* out, int reset_after) {
   if (!e || !out) return fail(OIS_EINVAL, "null argument");
-  float cnt = 0, ret = 0, ret2 = 0, len = 0, mn = INFINITY, mx = -INFINITY;
+  double cnt = 0, ret = 0, ret2 = 0, len = 0, mn = INFINITY, mx = -INFINITY;
   for (int g0 = 0; g0 < e->G; g0 += CHUNK_GROUPS) { /* same two-level order as the extras */
     int g1 = g0 + CHUNK_GROUPS < e->G ? g0 + CHUNK_GROUPS : e->G;
-    float c_cnt = 0, c_ret = 0, c_ret2 = 0, c_len = 0;
+    double c_cnt = 0, c_ret = 0, c_ret2 = 0, c_len = 0;
     for (int g = g0; g < g1; ++g) {
-      const float* A = &e->stat_acc[(size_t)g * ST_STRIDE];
+      const double* A = &e->stat_acc[(size_t)g * ST_STRIDE];
       c_cnt += A[ST_COUNT]; c_ret += A[ST_RET]; c_ret2 += A[ST_RET2]; c_len += A[ST_LEN];
-      mn = fminf(mn, A[ST_RMIN]); mx = fmaxf(mx, A[ST_RMAX]);
+      mn = fmin(mn, A[ST_RMIN]); mx = fmax(mx, A[ST_RMAX]);
     }
     cnt += c_cnt; ret += c_ret; ret2 += c_ret2; len += c_len;
   }

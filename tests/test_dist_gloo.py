@@ -89,3 +89,34 @@ def test_gather_without_process_group_is_identity():
     vec = np.zeros(_abi.EPISODE_INFO_LEN); vec[_abi.EI_COUNT], vec[_abi.EI_STEP], vec[8], vec[16] = 4, 99, -2.5, 0.75
     one = gather_episode_info(vec, 16)
     assert one["rew_Final reward"] == -2.5 and one["gamma_1 action assist"] == 0.75 and one["count"] == 4 and one["step"] == 99
+
+
+def test_merge_stats_std_at_half_a_million_episodes():
+    """the finished-episode sums are accumulated in double (oracle and library alike) so
+    that the variance — a difference of two large numbers — survives 524 288 episodes (BASELINE.json
+    configs[4]'s count after one timeout). The oracle env at 8 192 arenas x 64 timeouts has that many."""
+    import numpy as np
+    from options_in_simulation_amd import _abi, build_config
+    from options_in_simulation_amd.dist import merge_stats
+    from oracle.binding import OracleEnv
+    N, rounds = 2048, 4
+    env = OracleEnv(build_config(variant="KAMMA_medium", num_envs=N, seed=1, decimation=1, extra_substeps=0), threads=8)
+    env.reset(1)
+    returns = []
+    for r in range(rounds * 99):
+        before = env.buffer(_abi.BUF_SUMS_B)[:, 3].copy()
+        env.rollout(1, _abi.POLICY_RANDOM)
+        d = env.done.astype(bool)
+        if d.any():
+            # the finished episode's return = its Final-reward sum incl. this step's reward
+            returns.append((before + env.rew)[d].astype(np.float64))
+    st = env.stats()
+    x = np.concatenate(returns)
+    assert st.episodes == len(x) == N * rounds
+    # scale the same statistics to 524 288 episodes by merging 64 copies of the record (what 64 ranks would gather)
+    m = merge_stats([st] * 64)
+    assert m["episodes"] == 524288
+    ref_mean, ref_std = x.mean(), x.std()
+    assert m["return_mean"] == pytest.approx(ref_mean, rel=1e-6)
+    assert m["return_std"] == pytest.approx(ref_std, rel=1e-4)
+    assert st.return_min == pytest.approx(x.min(), rel=1e-6) and st.return_max == pytest.approx(x.max(), rel=1e-6)

@@ -207,7 +207,7 @@ def test_on_policy_rollout_memory_and_gae_stay_on_the_device():
     N, T = 128, 16
     env = VecEnv(num_envs=N, device="cuda:0", variant="KAMMA_eval", seed=5)
     states, _ = env.reset()
-    mem = DeviceFIFOMemory(env, memory_size=T)
+    mem = DeviceFIFOMemory(env, memory_size=T, actions="policy")
     assert mem.create_tensor("log_prob", 1) and mem.create_tensor("values", 1)
     assert mem.create_tensor("returns", 1) and mem.create_tensor("advantages", 1)
     assert not mem.create_tensor("states", 6)
@@ -223,6 +223,7 @@ def test_on_policy_rollout_memory_and_gae_stay_on_the_device():
                         truncated=trunc, log_prob=-values, values=values)
         vals.append(values)
         assert torch.equal(mem.get_tensor_by_name("values")[t], values)
+        assert torch.equal(mem.get_tensor_by_name("actions")[t], actions)      # the agent's own (policy mode)
         assert torch.equal(mem.get_tensor_by_name("rewards")[t], rew)          # written by the kernel
         assert torch.equal(mem.get_tensor_by_name("next_states")[t], next_states)
         states = next_states
@@ -243,8 +244,8 @@ def test_on_policy_rollout_memory_and_gae_stay_on_the_device():
     torch.testing.assert_close(mem.get_tensor_by_name("advantages"), ref, rtol=1e-4, atol=1e-5)
     batches = mem.sample_all(["states", "actions", "log_prob", "values", "returns", "advantages"], mini_batches=4)
     assert len(batches) == 4 and sum(b[0].shape[0] for b in batches) == T * N and batches[0][1].shape[1] == 4
-    assert sorted(mem.get_tensor_names()) == sorted(["states", "actions", "rewards", "next_states", "terminated",
-                                                     "log_prob", "values", "returns", "advantages"])
+    assert sorted(mem.get_tensor_names()) == sorted(["states", "actions", "executed_actions", "rewards", "next_states",
+                                                     "terminated", "log_prob", "values", "returns", "advantages"])
     mem.close(); env.close()
 
 
@@ -284,3 +285,60 @@ def test_fused_sample_equals_torch_indexing():
     mem.close()
     with pytest.raises(RuntimeError, match="no replay memory"):
         env.replay_sample(idx)
+
+
+@pytest.mark.gpu
+def test_policy_and_executed_action_modes():
+    """with gamma1 > 0 (the expert executes part of the steps) or an active clip the executed
+    torque is not the policy's action. base_KA_DDPG.py:212 records the executed one (mode "executed");
+    base_KA / PPO record the agent's own, whose log_prob sits beside it (mode "policy"): the stored
+    actions must then BE the actions that were passed, at the task's action width."""
+    from options_in_simulation_amd import VecEnv
+    from options_in_simulation_amd.replay import DeviceFIFOMemory
+    N, T = 96, 12
+    g = torch.Generator(device="cuda").manual_seed(3)
+    # KAMMA_medium with a fast schedule: gamma1 decays from 1, the switch executes the expert on many steps
+    env = VecEnv(num_envs=N, device="cuda:0", variant="KAMMA_medium", seed=4, max_sim_steps=40.0)
+    states, _ = env.reset()
+    pol = DeviceFIFOMemory(env, memory_size=T, actions="policy")
+    pol.create_tensor("log_prob", 1)
+    differ = 0
+    for t in range(T):
+        a = torch.rand((N, 4), device="cuda", generator=g)
+        lp = -(a ** 2).sum(1, keepdim=True)
+        nxt, rew, term, trunc, _ = env.step(a)
+        pol.add_samples(states=states, actions=a, rewards=rew, next_states=nxt, terminated=term, truncated=trunc, log_prob=lp)
+        states = nxt
+        row = pol.get_tensor_by_name("actions")[t]
+        assert torch.equal(row, a) and torch.equal(pol.get_tensor_by_name("log_prob")[t], lp)
+        executed = env.task.wheel_torqs / env.task.action_scale
+        # the kernel divides (IEEE), torch multiplies by the reciprocal of a Python scalar: 1 ulp apart
+        torch.testing.assert_close(pol.get_tensor_by_name("executed_actions")[t], executed, rtol=3e-7, atol=0)
+        differ += int((executed - a).abs().max() > 1e-3)
+    assert differ > 0, "the test needs steps on which the executed torque is not the policy action"
+    batch = pol.sample(["states", "actions", "log_prob"], batch_size=64)[0]
+    assert batch[1].shape == (64, 4) and torch.allclose(batch[2], -(batch[1] ** 2).sum(1, keepdim=True))
+    pol.close(); env.close()
+    # width follows the task: KA_DDPG_2D stores 2-wide policy actions by default, and refuses "executed"
+    env2 = VecEnv(num_envs=N, device="cuda:0", variant="KA_DDPG_2D", seed=4)
+    s2, _ = env2.reset()
+    m2 = DeviceFIFOMemory(env2, memory_size=4)
+    assert m2.actions_mode == "policy" and m2.get_tensor_by_name("actions").shape == (4, N, 2)
+    a2 = torch.rand((N, 2), device="cuda", generator=g) * 2 - 1
+    nxt, rew, term, trunc, _ = env2.step(a2)
+    m2.add_samples(states=s2, actions=a2, rewards=rew, next_states=nxt, terminated=term)
+    assert torch.equal(m2.get_tensor_by_name("actions")[0], a2) and m2.get_tensor_by_name("executed_actions").shape == (4, N, 4)
+    with pytest.raises(ValueError):
+        DeviceFIFOMemory(env2, memory_size=4, actions="executed")
+    m2.close(); env2.close()
+    # executed mode (the default at width 4): what base_KA_DDPG.py:212 substitutes; passed actions are ignored
+    env4 = VecEnv(num_envs=N, device="cuda:0", variant="KAMMA_medium", seed=4)
+    s4, _ = env4.reset()
+    m4 = DeviceFIFOMemory(env4, memory_size=4)
+    a4 = torch.rand((N, 4), device="cuda", generator=g)
+    nxt, rew, term, trunc, _ = env4.step(a4)
+    m4.add_samples(states=s4, actions=a4, rewards=rew, next_states=nxt, terminated=term)
+    assert m4.actions_mode == "executed" and "executed_actions" not in m4.tensors
+    torch.testing.assert_close(m4.get_tensor_by_name("actions")[0], env4.task.wheel_torqs / env4.task.action_scale, rtol=3e-7, atol=0)
+    assert not torch.equal(m4.get_tensor_by_name("actions")[0], a4)
+    m4.close(); env4.close()
