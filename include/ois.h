@@ -195,9 +195,12 @@ enum ois_buffer_id {
   OIS_BUF_EPISODE_INFO = 15, /* float [OIS_EPISODE_INFO_LEN] written by ois_episode_info */
   OIS_BUF_ENV0_DIAG = 16,  /* float [OIS_ENV0_DIAG_LEN] arena-0 diagnostics of the last step */
   OIS_BUF_SUMS_C = 17,     /* float [N,4]  eval sums smoothness, tracking error, desired v, prev-torque scratch */
-  OIS_BUF_LAMBDA_N = 18,   /* float [N,4]  cached normal contact impulses per wheel (solver warm start) */
-  OIS_BUF_LAMBDA_L = 19,   /* float [N,4]  cached longitudinal friction impulses */
-  OIS_BUF_LAMBDA_T = 20,   /* float [N,4]  cached lateral friction impulses */
+  OIS_BUF_LAMBDA_N = 18,   /* half [N,4]   contact impulses carried from one policy step to the next as the solver's warm
+                              start: normal, per wheel. IEEE binary16, rounded to nearest even at the end of every policy
+                              step (docs/SPEC.md 3.5): a warm start needs no more, and the three rows cost 48 B per
+                              arena-step instead of 96 */
+  OIS_BUF_LAMBDA_L = 19,   /* half [N,4]   longitudinal friction impulses */
+  OIS_BUF_LAMBDA_T = 20,   /* half [N,4]   lateral friction impulses */
   OIS_BUF_ENV_ORIGINS = 21, /* float [N,4] env_origins xyz of the arena's terrain tile (KAMMA.py:397, 529); 0 = no terrain */
   OIS_BUF_TERRAIN_IDX = 22, /* int32 [N,4] terrain_levels, terrain_types (KAMMA.py:342-347), -, - */
   OIS_BUF_CMD_FRACTION = 23, /* float [N]  self.fraction: r1 episode sum / threshold_high as of the last step in which

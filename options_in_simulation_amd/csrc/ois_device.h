@@ -61,8 +61,8 @@ struct DevTerrain {
 
 // device pointers of one environment ([N][4] unless noted)
 struct DevBuffers {
-  float4 *pose, *quat, *linvel, *angvel, *wheel_vel, *commands, *sums_a, *sums_b, *sums_c, *params,
-      *lam_n, *lam_l, *lam_t, *wheel_torqs;
+  float4 *pose, *quat, *linvel, *angvel, *wheel_vel, *commands, *sums_a, *sums_b, *sums_c, *params, *wheel_torqs;
+  uint2 *lam_n, *lam_l, *lam_t;  // [N] x 4 halves: warm-start impulses in binary16 (include/ois.h OIS_BUF_LAMBDA_*)
   int4* counters;
   float* obs;        // [N][6]
   float* rew;        // [N]
@@ -256,6 +256,19 @@ OIS_DEV void rot(const float R[9], const float a[3], float o[3]) {  // o = R a
 }
 
 OIS_DEV float clipf(float x, float lo, float hi) { return fminf(fmaxf(x, lo), hi); }
+
+// binary16 storage of the warm-start impulses: v_cvt_f16_f32 rounds to nearest even (default mode)
+typedef _Float16 half2_t __attribute__((ext_vector_type(2)));
+OIS_DEV float round_half(float x) { return (float)(_Float16)x; }
+OIS_DEV uint32_t pack_half2(float lo, float hi) {
+  half2_t v;
+  v.x = (_Float16)lo; v.y = (_Float16)hi;
+  return __builtin_bit_cast(uint32_t, v);
+}
+OIS_DEV void unpack_half2(uint32_t u, float& lo, float& hi) {
+  const half2_t v = __builtin_bit_cast(half2_t, u);
+  lo = (float)v.x; hi = (float)v.y;
+}
 
 // ---------------------------------------------------------------- lanes per arena -----
 // LPA = 1: one lane owns the whole arena (4 wheels).  LPA = 2: two adjacent lanes share an

@@ -45,6 +45,18 @@ OIS_DEV void store_wheels(float4* base, int arena, int h, const float* s) {
   else reinterpret_cast<float2*>(base)[arena * 2 + h] = make_float2(s[0], s[1]);
 }
 
+// the warm-start impulses: 4 halves per arena and row (this lane's 4 / LPA of them)
+template <int LPA>
+OIS_DEV void load_lambda(const uint2* base, int arena, int h, float* d) {
+  if (LPA == 1) { const uint2 t = base[arena]; unpack_half2(t.x, d[0], d[1]); unpack_half2(t.y, d[2], d[3]); }
+  else { unpack_half2(reinterpret_cast<const uint32_t*>(base)[arena * 2 + h], d[0], d[1]); }
+}
+template <int LPA>
+OIS_DEV void store_lambda(uint2* base, int arena, int h, const float* s) {
+  if (LPA == 1) base[arena] = make_uint2(pack_half2(s[0], s[1]), pack_half2(s[2], s[3]));
+  else reinterpret_cast<uint32_t*>(base)[arena * 2 + h] = pack_half2(s[0], s[1]);
+}
+
 template <int LPA>
 OIS_DEV void load_arena(const DevConsts& K, const DevBuffers& B, int i, int h, ArenaT<LPA>& S) {
   // issued in the order of first use (vector loads return in order, so a later row never holds up an
@@ -61,9 +73,9 @@ OIS_DEV void load_arena(const DevConsts& K, const DevBuffers& B, int i, int h, A
   S.v[0] = lv.x; S.v[1] = lv.y; S.v[2] = lv.z; S.prev_lin = lv.w;
   S.mu = pr.x; S.n[0] = pr.y; S.n[1] = pr.z; S.n[2] = pr.w;
   load_wheels<LPA>(B.wheel_vel, i, h, S.jv);
-  load_wheels<LPA>(B.lam_n, i, h, S.ln);
-  load_wheels<LPA>(B.lam_l, i, h, S.l1);
-  load_wheels<LPA>(B.lam_t, i, h, S.l2);
+  load_lambda<LPA>(B.lam_n, i, h, S.ln);
+  load_lambda<LPA>(B.lam_l, i, h, S.l1);
+  load_lambda<LPA>(B.lam_t, i, h, S.l2);
   if (K.eval_sums) {
     unpack(B.sums_c[i], S.sc);
     load_wheels<LPA>(B.wheel_torqs, i, h, S.wt);
@@ -89,9 +101,9 @@ OIS_DEV void store_arena(const DevConsts& K, const DevBuffers& B, int i, int h, 
     if (K.eval_sums) B.sums_c[i] = make_float4(S.sc[0], S.sc[1], S.sc[2], S.sc[3]);
   }
   store_wheels<LPA>(B.wheel_vel, i, h, S.jv);
-  store_wheels<LPA>(B.lam_n, i, h, S.ln);
-  store_wheels<LPA>(B.lam_l, i, h, S.l1);
-  store_wheels<LPA>(B.lam_t, i, h, S.l2);
+  store_lambda<LPA>(B.lam_n, i, h, S.ln);  // already binary16 values (rounded at the end of the policy step)
+  store_lambda<LPA>(B.lam_l, i, h, S.l1);
+  store_lambda<LPA>(B.lam_t, i, h, S.l2);
   store_wheels<LPA>(B.wheel_torqs, i, h, S.wt);
 }
 
@@ -242,6 +254,10 @@ OIS_DEV void step_body(const DevConsts& K, const DevBuffers& B, const float* __r
       }
       // safety net: a non-finite outcome (diverged reciprocal refresh of a violently tumbling
       // robot) is discarded: pre-step pose at rest, reset as fallen (oracle step_arena, SPEC §3.9)
+      // the impulses cross a policy-step boundary in binary16, inside a fused rollout too (SPEC 3.5);
+      // rounded before the check, so an impulse beyond the half range (inf) counts as non-finite
+#pragma unroll
+      for (int k = 0; k < W; ++k) { X.ln[k] = round_half(X.ln[k]); X.l1[k] = round_half(X.l1[k]); X.l2[k] = round_half(X.l2[k]); }
       float chk = 0.0f;
 #pragma unroll
       for (int k = 0; k < 3; ++k) chk += fabsf(X.p[k]) + fabsf(X.v[k]) + fabsf(X.wb[k]);
@@ -505,7 +521,7 @@ __global__ __launch_bounds__(kBlock) void reset_kernel(DevConsts K, DevBuffers B
     B.counters[arena] = make_int4(S.ep_buf, S.sim_steps, S.ep_count, 0);
     B.wheel_vel[arena] = make_float4(S.jv[0], S.jv[1], S.jv[2], S.jv[3]);
     const float4 z = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
-    B.lam_n[arena] = z; B.lam_l[arena] = z; B.lam_t[arena] = z;
+    B.lam_n[arena] = make_uint2(0u, 0u); B.lam_l[arena] = make_uint2(0u, 0u); B.lam_t[arena] = make_uint2(0u, 0u);
     B.sums_a[arena] = z; B.sums_b[arena] = z; B.sums_c[arena] = z; B.wheel_torqs[arena] = z;
     for (int k = 0; k < 6; ++k) B.obs[(size_t)arena * 6 + k] = 0.0f;
     B.rew[arena] = 0.0f; B.done[arena] = 0; B.timeout[arena] = 0;
@@ -748,7 +764,7 @@ Layout make_layout(int N) {
   put(OIS_BUF_POSE, f4); put(OIS_BUF_QUAT, f4); put(OIS_BUF_LINVEL, f4); put(OIS_BUF_ANGVEL, f4);
   put(OIS_BUF_WHEEL_VEL, f4); put(OIS_BUF_COMMANDS, f4); put(OIS_BUF_COUNTERS, f4);
   put(OIS_BUF_SUMS_A, f4); put(OIS_BUF_SUMS_B, f4); put(OIS_BUF_SUMS_C, f4); put(OIS_BUF_PARAMS, f4);
-  put(OIS_BUF_LAMBDA_N, f4); put(OIS_BUF_LAMBDA_L, f4); put(OIS_BUF_LAMBDA_T, f4);
+  put(OIS_BUF_LAMBDA_N, f4 / 2); put(OIS_BUF_LAMBDA_L, f4 / 2); put(OIS_BUF_LAMBDA_T, f4 / 2);  // 4 halves per arena
   put(OIS_BUF_WHEEL_TORQS, f4);
   put(OIS_BUF_ENV_ORIGINS, f4); put(OIS_BUF_TERRAIN_IDX, f4);
   put(OIS_BUF_CMD_FRACTION, (size_t)N * sizeof(float));
@@ -1006,8 +1022,8 @@ int ois_create(const ois_config* cfg, int device, void* workspace_device, size_t
   B.counters = (int4*)(w + L.off[OIS_BUF_COUNTERS]);
   B.sums_a = (float4*)(w + L.off[OIS_BUF_SUMS_A]); B.sums_b = (float4*)(w + L.off[OIS_BUF_SUMS_B]);
   B.sums_c = (float4*)(w + L.off[OIS_BUF_SUMS_C]); B.params = (float4*)(w + L.off[OIS_BUF_PARAMS]);
-  B.lam_n = (float4*)(w + L.off[OIS_BUF_LAMBDA_N]); B.lam_l = (float4*)(w + L.off[OIS_BUF_LAMBDA_L]);
-  B.lam_t = (float4*)(w + L.off[OIS_BUF_LAMBDA_T]); B.wheel_torqs = (float4*)(w + L.off[OIS_BUF_WHEEL_TORQS]);
+  B.lam_n = (uint2*)(w + L.off[OIS_BUF_LAMBDA_N]); B.lam_l = (uint2*)(w + L.off[OIS_BUF_LAMBDA_L]);
+  B.lam_t = (uint2*)(w + L.off[OIS_BUF_LAMBDA_T]); B.wheel_torqs = (float4*)(w + L.off[OIS_BUF_WHEEL_TORQS]);
   B.obs = (float*)(w + L.off[OIS_BUF_OBS]); B.rew = (float*)(w + L.off[OIS_BUF_REW]);
   B.done = (uint8_t*)(w + L.off[OIS_BUF_DONE]); B.timeout = (uint8_t*)(w + L.off[OIS_BUF_TIMEOUT]);
   B.episode_info = (float*)(w + L.off[OIS_BUF_EPISODE_INFO]); B.env0_diag = (float*)(w + L.off[OIS_BUF_ENV0_DIAG]);

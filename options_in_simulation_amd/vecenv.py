@@ -36,8 +36,8 @@ _DTYPES = {
     _abi.BUF_COMMANDS: (torch.float32, 4), _abi.BUF_COUNTERS: (torch.int32, 4),
     _abi.BUF_SUMS_A: (torch.float32, 4), _abi.BUF_SUMS_B: (torch.float32, 4), _abi.BUF_SUMS_C: (torch.float32, 4),
     _abi.BUF_PARAMS: (torch.float32, 4), _abi.BUF_EPISODE_INFO: (torch.float32, None),
-    _abi.BUF_ENV0_DIAG: (torch.float32, None), _abi.BUF_LAMBDA_N: (torch.float32, 4),
-    _abi.BUF_LAMBDA_L: (torch.float32, 4), _abi.BUF_LAMBDA_T: (torch.float32, 4),
+    _abi.BUF_ENV0_DIAG: (torch.float32, None), _abi.BUF_LAMBDA_N: (torch.float16, 4),
+    _abi.BUF_LAMBDA_L: (torch.float16, 4), _abi.BUF_LAMBDA_T: (torch.float16, 4),
     _abi.BUF_ENV_ORIGINS: (torch.float32, 4), _abi.BUF_TERRAIN_IDX: (torch.int32, 4),
     _abi.BUF_CMD_FRACTION: (torch.float32, None),
 }

@@ -81,6 +81,10 @@ def lib() -> C.CDLL:
         L.orc_sincos.argtypes = [C.c_float, fp, fp]
         L.orc_sincos.restype = None
         L.orc_substep.argtypes = [cfgp, C.c_float] + [fp] * 10
+        L.orc_f2h.argtypes = [C.c_float]
+        L.orc_f2h.restype = C.c_uint16
+        L.orc_h2f.argtypes = [C.c_uint16]
+        L.orc_h2f.restype = C.c_float
         L.orc_sin.argtypes = [C.c_float]
         L.orc_sin.restype = C.c_float
         L.orc_normal.argtypes = [C.c_float, C.c_float]
@@ -115,7 +119,7 @@ _BUF_META = {
     _abi.BUF_SUMS_A: (np.float32, 4), _abi.BUF_SUMS_B: (np.float32, 4), _abi.BUF_SUMS_C: (np.float32, 4),
     _abi.BUF_PARAMS: (np.float32, 4), _abi.BUF_EPISODE_INFO: (np.float32, None),
     _abi.BUF_ENV0_DIAG: (np.float32, None),
-    _abi.BUF_LAMBDA_N: (np.float32, 4), _abi.BUF_LAMBDA_L: (np.float32, 4), _abi.BUF_LAMBDA_T: (np.float32, 4),
+    _abi.BUF_LAMBDA_N: (np.float16, 4), _abi.BUF_LAMBDA_L: (np.float16, 4), _abi.BUF_LAMBDA_T: (np.float16, 4),
     _abi.BUF_ENV_ORIGINS: (np.float32, 4), _abi.BUF_TERRAIN_IDX: (np.int32, 4),
     _abi.BUF_CMD_FRACTION: (np.float32, None),
 }

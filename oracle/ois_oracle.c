@@ -59,6 +59,46 @@ static void draw4(uint64_t seed, int64_t arena, uint32_t step, uint32_t purpose,
   for (int i = 0; i < 4; ++i) u[i] = orc_u01(o[i]);
 }
 
+/* ------------------------------------------------------------------ binary16 --------- */
+/* IEEE binary16 <-> binary32, round to nearest even, subnormals kept (what v_cvt_f16_f32 /
+ * v_cvt_f32_f16 do in the kernel's default mode): the contact impulses carried from one policy
+ * step to the next are stored in half precision (OIS_BUF_LAMBDA_*). */
+uint16_t orc_f2h(float f) {
+  uint32_t x;
+  memcpy(&x, &f, 4);
+  uint16_t sign = (uint16_t)((x >> 16) & 0x8000u);
+  x &= 0x7fffffffu;
+  if (x > 0x7f800000u) return (uint16_t)(sign | 0x7e00u);  /* NaN */
+  if (x >= 0x47800000u) return (uint16_t)(sign | 0x7c00u); /* >= 2^16 (and inf) */
+  if (x < 0x38800000u) {                                    /* below 2^-14: subnormal half or zero */
+    if (x < 0x33000000u) return sign;                       /* below 2^-25: rounds to zero */
+    uint32_t e = x >> 23, m = (x & 0x7fffffu) | 0x800000u;
+    uint32_t shift = 126u - e;                              /* 14 .. 24 */
+    uint32_t h = m >> shift, rem = m & ((1u << shift) - 1u), half = 1u << (shift - 1u);
+    if (rem > half || (rem == half && (h & 1u))) h++;
+    return (uint16_t)(sign | h);
+  }
+  uint32_t h = (x - 0x38000000u) >> 13, rem = x & 0x1fffu;
+  if (rem > 0x1000u || (rem == 0x1000u && (h & 1u))) h++;  /* a carry into the exponent is the right answer, 65520 -> inf too */
+  return (uint16_t)(sign | h);
+}
+float orc_h2f(uint16_t h) {
+  uint32_t sign = (uint32_t)(h & 0x8000u) << 16, e = (h >> 10) & 0x1fu, m = h & 0x3ffu, x;
+  if (e == 0) {
+    if (m == 0) x = sign;
+    else { /* subnormal: normalise */
+      int s = 0;
+      while (!(m & 0x400u)) { m <<= 1; s++; }
+      x = sign | ((uint32_t)(113 - s) << 23) | ((m & 0x3ffu) << 13);
+    }
+  } else if (e == 31) x = sign | 0x7f800000u | (m << 13);
+  else x = sign | ((e + 112u) << 23) | (m << 13);
+  float f;
+  memcpy(&f, &x, 4);
+  return f;
+}
+static inline float round_half(float x) { return orc_h2f(orc_f2h(x)); }
+
 /* ------------------------------------------------------------------ trig ------------- */
 /* Deterministic sin/cos for x in [0, pi] built from mul/add/fma only (so the GPU can repeat
  * it bit for bit): Cody-Waite reduction by pi/2, cephes single-precision minimax kernels. */
@@ -738,7 +778,7 @@ struct orc_env {
   double steps_done;
   /* buffers, same ids/shapes as the product */
   float *obs, *rew, *wheel_torqs, *pose, *quat, *linvel, *angvel, *wheel_vel, *commands, *sums_a, *sums_b, *sums_c, *params;
-  float *lam_n, *lam_l, *lam_t; /* contact impulse cache (warm start), [N,4] each */
+  uint16_t *lam_n, *lam_l, *lam_t; /* contact impulse cache (warm start), binary16 [N,4] each */
   float* cmd_fraction;          /* [N] self.fraction (KAMMA.py:498), OIS_CMD_LEVEL only */
   uint8_t *done, *timeout;
   int32_t* counters;
@@ -783,7 +823,7 @@ int orc_create(const ois_config* cfg, orc_env** out) {
   e->wheel_torqs = zalloc(f4); e->pose = zalloc(f4); e->quat = zalloc(f4); e->linvel = zalloc(f4);
   e->angvel = zalloc(f4); e->wheel_vel = zalloc(f4); e->commands = zalloc(f4);
   e->sums_a = zalloc(f4); e->sums_b = zalloc(f4); e->sums_c = zalloc(f4); e->params = zalloc(f4);
-  e->lam_n = zalloc(f4); e->lam_l = zalloc(f4); e->lam_t = zalloc(f4);
+  e->lam_n = zalloc(f4 / 2); e->lam_l = zalloc(f4 / 2); e->lam_t = zalloc(f4 / 2);
   e->cmd_fraction = zalloc((size_t)N * sizeof(float));
   e->done = zalloc((size_t)N); e->timeout = zalloc((size_t)N);
   e->counters = zalloc((size_t)N * 4 * sizeof(int32_t));
@@ -841,9 +881,9 @@ int orc_buffer(orc_env* e, int id, void** ptr, size_t* bytes) {
     case OIS_BUF_SUMS_B: *ptr = e->sums_b; *bytes = f4; break;
     case OIS_BUF_SUMS_C: *ptr = e->sums_c; *bytes = f4; break;
     case OIS_BUF_PARAMS: *ptr = e->params; *bytes = f4; break;
-    case OIS_BUF_LAMBDA_N: *ptr = e->lam_n; *bytes = f4; break;
-    case OIS_BUF_LAMBDA_L: *ptr = e->lam_l; *bytes = f4; break;
-    case OIS_BUF_LAMBDA_T: *ptr = e->lam_t; *bytes = f4; break;
+    case OIS_BUF_LAMBDA_N: *ptr = e->lam_n; *bytes = f4 / 2; break;
+    case OIS_BUF_LAMBDA_L: *ptr = e->lam_l; *bytes = f4 / 2; break;
+    case OIS_BUF_LAMBDA_T: *ptr = e->lam_t; *bytes = f4 / 2; break;
     case OIS_BUF_ENV_ORIGINS: *ptr = e->env_origins; *bytes = f4; break;
     case OIS_BUF_TERRAIN_IDX: *ptr = e->terrain_idx; *bytes = N * 4 * sizeof(int32_t); break;
     case OIS_BUF_CMD_FRACTION: *ptr = e->cmd_fraction; *bytes = N * sizeof(float); break;
@@ -965,7 +1005,7 @@ static void reset_arena(orc_env* e, int i, uint32_t step_ctr, float gamma2, rese
     e->angvel[4 * i + k] = c->init_ang_vel[k];
   }
   for (int k = 0; k < 4; ++k) e->wheel_vel[4 * i + k] = c->init_dof_vel[k]; /* :438, :446 */
-  for (int k = 0; k < 4; ++k) e->lam_n[4 * i + k] = e->lam_l[4 * i + k] = e->lam_t[4 * i + k] = 0.0f; /* teleport: drop the contact cache */
+  for (int k = 0; k < 4; ++k) e->lam_n[4 * i + k] = e->lam_l[4 * i + k] = e->lam_t[4 * i + k] = 0; /* teleport: drop the contact cache */
   memcpy(&e->commands[4 * i], cmd, sizeof cmd);
   cnt[0] = 0;   /* :462 */
   cnt[2] += 1;  /* :463 */
@@ -1043,7 +1083,7 @@ int orc_reset(orc_env* e, uint64_t seed) {
   memset(e->wheel_torqs, 0, f4); memset(e->pose, 0, f4); memset(e->quat, 0, f4); memset(e->linvel, 0, f4);
   memset(e->angvel, 0, f4); memset(e->wheel_vel, 0, f4); memset(e->commands, 0, f4);
   memset(e->sums_a, 0, f4); memset(e->sums_b, 0, f4); memset(e->sums_c, 0, f4);
-  memset(e->lam_n, 0, f4); memset(e->lam_l, 0, f4); memset(e->lam_t, 0, f4);
+  memset(e->lam_n, 0, f4 / 2); memset(e->lam_l, 0, f4 / 2); memset(e->lam_t, 0, f4 / 2);
   memset(e->cmd_fraction, 0, (size_t)N * sizeof(float)); /* :498 at post_reset: the sums are zero */
   memset(e->done, 0, (size_t)N); memset(e->timeout, 0, (size_t)N);
   memset(e->counters, 0, (size_t)N * 4 * sizeof(int32_t));
@@ -1132,9 +1172,8 @@ static float step_arena(orc_env* e, int i, const float* act /*[A]*/, uint8_t* rs
   rotT(R, w, wb);
   for (int k = 0; k < 4; ++k) spin[k] = JV[k] + wb[1];
   int nsub = c->decimation + c->extra_substeps;
-  float* LN = &e->lam_n[4 * i];
-  float* LL = &e->lam_l[4 * i];
-  float* LT = &e->lam_t[4 * i];
+  float LN[4], LL[4], LT[4]; /* the stored binary16 impulses, widened */
+  for (int k = 0; k < 4; ++k) { LN[k] = orc_h2f(e->lam_n[4 * i + k]); LL[k] = orc_h2f(e->lam_l[4 * i + k]); LT[k] = orc_h2f(e->lam_t[4 * i + k]); }
   rcache C;
   const terrain_ctx* T = e->terrain_on ? &e->terrain : NULL;
   footprints FP;
@@ -1144,6 +1183,9 @@ static float step_arena(orc_env* e, int i, const float* act /*[A]*/, uint8_t* rs
    * state; such an arena would never reset (every comparison of is_done is false on NaN) and
    * would poison the policy's batch. A non-finite outcome is discarded: the arena keeps its
    * pre-step pose at rest and is reset as fallen. */
+  /* the impulses cross a policy-step boundary in binary16 (SPEC 3.5); rounded before the check, so an
+   * impulse beyond the half range (inf) counts as non-finite */
+  for (int k = 0; k < 4; ++k) { LN[k] = round_half(LN[k]); LL[k] = round_half(LL[k]); LT[k] = round_half(LT[k]); }
   float chk = 0.0f;
   for (int k = 0; k < 3; ++k) chk += fabsf(p[k]) + fabsf(v[k]) + fabsf(wb[k]);
   for (int k = 0; k < 4; ++k) chk += fabsf(q[k]) + fabsf(spin[k]) + fabsf(LN[k]) + fabsf(LL[k]) + fabsf(LT[k]);
@@ -1179,6 +1221,7 @@ static float step_arena(orc_env* e, int i, const float* act /*[A]*/, uint8_t* rs
   V[0] = v[0]; V[1] = v[1]; V[2] = v[2]; V[3] = prev_lin;
   W[0] = w[0]; W[1] = w[1]; W[2] = w[2]; W[3] = prev_ang;
   for (int k = 0; k < 4; ++k) JV[k] = jv[k];
+  for (int k = 0; k < 4; ++k) { e->lam_n[4 * i + k] = orc_f2h(LN[k]); e->lam_l[4 * i + k] = orc_f2h(LL[k]); e->lam_t[4 * i + k] = orc_f2h(LT[k]); }
   rs[i] = reset;
   if (reset) reset_arena(e, i, (uint32_t)cnt[1], gamma2, &rc[i]); /* :691-693 */
   /* get_observations (:825-833): desired_* are views of commands -> post-reset values */

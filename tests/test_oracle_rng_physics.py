@@ -61,7 +61,8 @@ def test_rest_equilibrium_is_exact():
     np.testing.assert_allclose(env.buffer(_abi.BUF_POSE)[:, 2], z_expected, atol=2e-6)
     np.testing.assert_allclose(env.buffer(_abi.BUF_LINVEL)[:, :3], 0.0, atol=1e-5)
     np.testing.assert_allclose(env.buffer(_abi.BUF_ANGVEL)[:, :3], 0.0, atol=1e-5)
-    np.testing.assert_allclose(env.buffer(_abi.BUF_LAMBDA_N), cfg.body_mass * cfg.gravity * cfg.sim_dt / 4, rtol=1e-4)
+    # the carried impulses are stored in binary16 (include/ois.h OIS_BUF_LAMBDA_*): 11 significant bits
+    np.testing.assert_allclose(env.buffer(_abi.BUF_LAMBDA_N).astype(np.float32), cfg.body_mass * cfg.gravity * cfg.sim_dt / 4, rtol=5e-4)
     q = env.buffer(_abi.BUF_QUAT)
     np.testing.assert_allclose(np.linalg.norm(q, axis=1), 1.0, atol=1e-6)
 
@@ -80,7 +81,7 @@ def test_constant_torque_steady_state():
     np.testing.assert_allclose(env.buffer(_abi.BUF_ANGVEL)[:, 2], 0.0, atol=1e-4)
     # no NET lateral force (the 4 lateral rows on 3 chassis DoF admit a self-equilibrated
     # left/right squeeze, which the warm start legitimately keeps from the initial drop)
-    np.testing.assert_allclose(env.buffer(_abi.BUF_LAMBDA_T).sum(axis=1), 0.0, atol=1e-4)
+    np.testing.assert_allclose(env.buffer(_abi.BUF_LAMBDA_T).astype(np.float32).sum(axis=1), 0.0, atol=2e-4)
     np.testing.assert_allclose(env.buffer(_abi.BUF_LINVEL)[:, 2], 0.0, atol=1e-5)
 
 
@@ -243,3 +244,22 @@ def test_calibration_against_the_reference_artefacts():
     te, fig = r["te_by_command"], ref["figure_controller"]["te"]
     assert te[2] < te[0] and te[2] < te[4]
     assert abs(te[0] - fig["1.0-1.3"]) < 0.06 and abs(te[2] - fig["1.53"]) < 0.03 and abs(te[4] - fig["2.0"]) < 0.06
+
+
+def test_binary16_conversion_is_ieee_round_to_nearest_even(oracle_lib):
+    """the oracle's software binary16 conversion (storage of the carried contact impulses) against
+    numpy's IEEE conversion: every half value, ties, subnormals, overflow"""
+    L = oracle_lib
+    allh = np.arange(0x10000, dtype=np.uint16)
+    f = allh.view(np.float16).astype(np.float32)
+    for h, x in zip(allh[::7].tolist() + [0x0001, 0x03ff, 0x0400, 0x7bff, 0x7c00, 0xfbff, 0x8000], list(f[::7]) + [f[1], f[0x3ff], f[0x400], f[0x7bff], f[0x7c00], f[0xfbff], f[0x8000]]):
+        got = L.orc_h2f(int(h))
+        assert (np.isnan(x) and np.isnan(got)) or np.float32(got).tobytes() == np.float32(x).tobytes()
+    rng = np.random.default_rng(0)
+    xs = np.concatenate([rng.standard_normal(20000).astype(np.float32) * np.float32(10.0) ** rng.integers(-9, 6, 20000).astype(np.float32),
+                         np.array([0.0, -0.0, 65504.0, 65519.99, 65520.0, 1e9, -1e9, 5.96e-8, 2.98e-8, 2.9802322e-8, 2.99e-8, 6.1e-5, 6.097e-5], np.float32),
+                         (f[0x3c00:0x3c40] + np.float32(2.0 ** -11)).astype(np.float32)])  # exact ties
+    with np.errstate(over="ignore"):
+        want = xs.astype(np.float16).view(np.uint16)
+    got = np.array([L.orc_f2h(float(x)) for x in xs], np.uint16)
+    assert np.array_equal(got, want)
