@@ -384,12 +384,16 @@ typedef struct ois_terrain {
 } ois_terrain;
 /* heights_device: int16 [rows, cols]; terrain_origins_device: float [num_levels, num_types, 3];
  * levels_types_host: int32 [N, 2] initial terrain_levels / terrain_types (host memory, copied).
- * minfield_device: caller-owned int16 [rows, cols] scratch the library fills (on `stream`) with
- *   m[x][y] = min(h[x][y], h[x+1][y+1])  — the two-sample rule of get_heights (KAMMA.py:889-893)
- * folded into the field once, so that a footprint or a scan point is ONE gather instead of two
- * (same values; the indices are clamped to rows - 2 / cols - 2 before use, KAMMA.py:886-887, so
- * the last row and column are never read). Like the field it must outlive the attachment.
+ * minfield_device: caller-owned scratch of ois_minfield_bytes(rows, cols) bytes the library fills (on
+ *   `stream`) with m(x, y) = min(h[x][y], h[x+1][y+1])  — the two-sample rule of get_heights
+ * (KAMMA.py:889-893) folded into the field once, so that a footprint or a scan point is ONE gather
+ * instead of two (same values; the indices are clamped to rows - 2 / cols - 2 before use,
+ * KAMMA.py:886-887, so the last row and column are never read) — stored in tiles of 8 x 8 cells
+ * (one 128-byte line each; rows and cols rounded up to multiples of 8), because the points a robot
+ * samples are a rotated 10 cm lattice: 2-3 of them share a tile, none a row-major line.
+ * Like the field it must outlive the attachment.
  * Call before ois_reset. terrain == NULL detaches (back to the per-arena plane). */
+size_t ois_minfield_bytes(int rows, int cols);
 int ois_terrain_attach(ois_env* env, const ois_terrain* terrain, const int16_t* heights_device,
                        int16_t* minfield_device, const float* terrain_origins_device,
                        const int32_t* levels_types_host, void* stream);

@@ -20,7 +20,7 @@ SYMBOLS = (
     "ois_episode_info", "ois_stats_fetch", "ois_env0_diag", "ois_state_bytes", "ois_save_state",
     "ois_load_state", "ois_replay_bytes", "ois_replay_attach", "ois_replay_buffer", "ois_replay_cursor",
     "ois_gae_scratch_bytes", "ois_gae", "ois_terrain_attach", "ois_height_scan", "ois_replay_sample",
-    "ois_profile_begin", "ois_profile_end",
+    "ois_profile_begin", "ois_profile_end", "ois_minfield_bytes",
 )
 
 _lib = None
@@ -83,6 +83,8 @@ def load() -> C.CDLL:
     L.ois_replay_sample.argtypes = [vp, vp, C.c_int, vp, vp, vp, vp, vp, vp]
     L.ois_terrain_attach.argtypes = [vp, C.POINTER(_abi.OisTerrain), vp, vp, vp, C.POINTER(C.c_int32), vp]
     L.ois_height_scan.argtypes = [vp, vp, vp]
+    L.ois_minfield_bytes.argtypes = [C.c_int, C.c_int]
+    L.ois_minfield_bytes.restype = C.c_size_t
     L.ois_profile_begin.argtypes = [vp]
     L.ois_profile_end.argtypes = [vp, C.POINTER(C.c_double), C.POINTER(C.c_longlong)]
     if L.ois_abi_version() != _abi.ABI_VERSION:

@@ -56,6 +56,7 @@ struct DevTerrain {
   const int16_t* m;        // [rows][cols] min(h[x][y], h[x+1][y+1]), filled at attach (caller-owned scratch)
   const float* origins;    // [levels][types][3] terrain_origins table (caller-owned)
   int rows, cols, ntypes, max_level, curriculum, on;
+  int tiles_per_row;  // the min-field is stored in 8 x 8-cell tiles of 128 B: ceil(cols / 8) tiles per tile row
   float inv_hs, hs, vs, border, thr_lo, thr_hi;
 };
 

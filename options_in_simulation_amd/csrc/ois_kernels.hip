@@ -441,36 +441,53 @@ __global__ __launch_bounds__(kBlock) void step_kernel_terrain(DevConsts K, DevBu
 }
 
 // ------------------------------------------------------------------ get_heights -------
-// KAMMA.py:872-893: one thread per (arena, point); the 140 points of an arena are consecutive
-// threads, so the output rows are written coalesced. Mirrors oracle orc_get_heights.
+// KAMMA.py:872-893. A workgroup takes kScanArenas consecutive arenas: their per-arena part (base-link
+// position in the field's frame, the normalised yaw quaternion of quat_apply_yaw :895-899) is computed once by
+// one lane per arena and parked in LDS; then the workgroup's 140 * kScanArenas points are dealt to the lanes
+// in output order, so the rows of measured_heights are written coalesced and a wave's lanes read the
+// same one or two LDS records. (One thread per point recomputing the arena part: 154 VALU instructions
+// per point, ~24 us of issue at 65 536 arenas; here ~45.) Same float operations per point as the oracle's
+// orc_get_heights: bit-identical to tests/golden/refmath_heights.npz.
+constexpr int kScanArenas = 32;
 __global__ __launch_bounds__(256) void height_scan_kernel(DevConsts K, DevBuffers B, int N, float* __restrict__ out) {
-  const size_t t = (size_t)blockIdx.x * 256 + threadIdx.x;
-  if (t >= (size_t)N * OIS_HEIGHT_POINTS) return;
-  const int i = (int)(t / OIS_HEIGHT_POINTS), pt = (int)(t % OIS_HEIGHT_POINTS);
-  const int a = pt / 10, b = pt % 10;
-  const int gx = a < 7 ? a - 8 : a - 5;   // -8..-2, 2..8   (KAMMA.py:283-285)
-  const int gy = b < 5 ? b - 5 : b - 4;   // -5..-1, 1..5   (KAMMA.py:280-282)
-  const float4 po = B.pose[i], qu = B.quat[i], eo = B.env_origins[i];
-  const float q[4] = {qu.x, qu.y, qu.z, qu.w};
-  float R[9];
-  rotmat(q, R);
-  // base-link position in the world = arena-local COM - R com + tile origin
-  const float pwx = __builtin_fmaf(-R[2], K.com_height, po.x) + eo.x;
-  const float pwy = __builtin_fmaf(-R[5], K.com_height, po.y) + eo.y;
-  float nrm = sqrtf(qu.x * qu.x + qu.w * qu.w);  // quat_apply_yaw: x, y zeroed, then normalize (:895-899)
-  nrm = fmaxf(nrm, 1e-9f);
-  const float qw = qu.x / nrm, qz = qu.w / nrm;
-  const float bx = 0.1f * (float)gx, by = 0.1f * (float)gy;
-  const float tx = -(qz * by) * 2.0f, ty = (qz * bx) * 2.0f;
-  const float cx = -(qz * ty), cy = qz * tx;
-  float X = (bx + qw * tx) + cx, Y = (by + qw * ty) + cy;
-  X += pwx; Y += pwy;                       // :878
-  X += B.ter.border; Y += B.ter.border;     // :882
-  float fx = X / B.ter.hs, fy = Y / B.ter.hs;  // :883
-  fx = fminf(fmaxf(fx, 0.0f), (float)(B.ter.rows - 2));  // :886-887
-  fy = fminf(fmaxf(fy, 0.0f), (float)(B.ter.cols - 2));
-  const int px = (int)fx, py = (int)fy;
-  out[t] = (float)B.ter.m[(size_t)px * B.ter.cols + py] * B.ter.vs;  // :889-893, the min of the two samples is in the min-field
+  __shared__ float4 rec[kScanArenas];  // pwx, pwy, qw, qz
+  const int arena0 = blockIdx.x * kScanArenas;
+  const int t = threadIdx.x;
+  if (t < kScanArenas && arena0 + t < N) {
+    const int i = arena0 + t;
+    const float4 po = B.pose[i], qu = B.quat[i], eo = B.env_origins[i];
+    const float q[4] = {qu.x, qu.y, qu.z, qu.w};
+    float R[9];
+    rotmat(q, R);
+    // base-link position in the world = arena-local COM - R com + tile origin
+    const float pwx = __builtin_fmaf(-R[2], K.com_height, po.x) + eo.x;
+    const float pwy = __builtin_fmaf(-R[5], K.com_height, po.y) + eo.y;
+    float nrm = sqrtf(qu.x * qu.x + qu.w * qu.w);  // quat_apply_yaw: x, y zeroed, then normalize (:895-899)
+    nrm = fmaxf(nrm, 1e-9f);
+    rec[t] = make_float4(pwx, pwy, qu.x / nrm, qu.w / nrm);
+  }
+  __syncthreads();
+  const int narenas = min(kScanArenas, N - arena0);
+  const int npts = narenas * OIS_HEIGHT_POINTS;
+  float* o = out + (size_t)arena0 * OIS_HEIGHT_POINTS;
+  for (int p = t; p < npts; p += 256) {
+    const int la = p / OIS_HEIGHT_POINTS, pt = p - la * OIS_HEIGHT_POINTS;
+    const int a = pt / 10, b = pt - a * 10;
+    const int gx = a < 7 ? a - 8 : a - 5;   // -8..-2, 2..8   (KAMMA.py:283-285)
+    const int gy = b < 5 ? b - 5 : b - 4;   // -5..-1, 1..5   (KAMMA.py:280-282)
+    const float4 r = rec[la];
+    const float qw = r.z, qz = r.w;
+    const float bx = 0.1f * (float)gx, by = 0.1f * (float)gy;
+    const float tx = -(qz * by) * 2.0f, ty = (qz * bx) * 2.0f;
+    const float cx = -(qz * ty), cy = qz * tx;
+    float X = (bx + qw * tx) + cx, Y = (by + qw * ty) + cy;
+    X += r.x; Y += r.y;                       // :878
+    X += B.ter.border; Y += B.ter.border;     // :882
+    float fx = X / B.ter.hs, fy = Y / B.ter.hs;  // :883
+    fx = fminf(fmaxf(fx, 0.0f), (float)(B.ter.rows - 2));  // :886-887
+    fy = fminf(fmaxf(fy, 0.0f), (float)(B.ter.cols - 2));
+    o[p] = terrain_cell_height(B.ter, (int)fx, (int)fy);  // :889-893, the min of the two samples is in the min-field
+  }
 }
 
 // m[x][y] = min(h[x][y], h[x+1][y+1]) (last row / column: h itself; never read, see ois.h)
@@ -481,7 +498,8 @@ __global__ __launch_bounds__(256) void minfield_kernel(const int16_t* __restrict
   const int16_t a = h[t];
   int16_t b = a;
   if (x + 1 < rows && y + 1 < cols) b = h[t + cols + 1];
-  m[t] = a < b ? a : b;
+  const size_t o = ((size_t)((x >> 3) * ((cols + 7) >> 3) + (y >> 3)) << 6) + (size_t)(((x & 7) << 3) | (y & 7));  // 8 x 8 tiles
+  m[o] = a < b ? a : b;
 }
 
 // ------------------------------------------------------------------ post_reset --------
@@ -1251,6 +1269,7 @@ int ois_terrain_attach(ois_env* e, const ois_terrain* t, const int16_t* heights_
   HIP_TRY(hipStreamSynchronize(s));
   {
     const size_t cells = (size_t)t->rows * (size_t)t->cols;
+    e->B.ter.tiles_per_row = (t->cols + 7) >> 3;
     hipLaunchKernelGGL(minfield_kernel, dim3((unsigned)((cells + 255) / 256)), dim3(256), 0, s, heights_device, minfield_device,
                        t->rows, t->cols);
     HIP_TRY(hipGetLastError());
@@ -1273,9 +1292,8 @@ int ois_height_scan(ois_env* e, float* heights_out_device, void* stream) {
   if (!e->B.ter.on) return fail(OIS_ESTATE, "ois_height_scan needs an attached terrain");
   if (!e->reset_done) return fail(OIS_ESTATE, "ois_height_scan called before ois_reset");
   OIS_ON_DEVICE(e->device);
-  const size_t pts = (size_t)e->N * OIS_HEIGHT_POINTS;
-  hipLaunchKernelGGL(height_scan_kernel, dim3((unsigned)((pts + 255) / 256)), dim3(256), 0, (hipStream_t)stream, e->K, e->B,
-                     e->N, heights_out_device);
+  hipLaunchKernelGGL(height_scan_kernel, dim3((unsigned)((e->N + kScanArenas - 1) / kScanArenas)), dim3(256), 0, (hipStream_t)stream,
+                     e->K, e->B, e->N, heights_out_device);
   HIP_TRY(hipGetLastError());
   return OIS_OK;
 }
@@ -1403,6 +1421,11 @@ int ois_replay_sample(ois_env* e, const int64_t* indexes_device, int count, floa
                      count, states_out, actions_out, rewards_out, next_states_out, terminated_out);
   HIP_TRY(hipGetLastError());
   return OIS_OK;
+}
+
+size_t ois_minfield_bytes(int rows, int cols) {
+  if (rows < 1 || cols < 1) return 0;
+  return (size_t)((rows + 7) >> 3) * (size_t)((cols + 7) >> 3) * 64 * sizeof(int16_t);
 }
 
 size_t ois_state_bytes(const ois_env* e) { return e ? sizeof(StateHeader) + e->L.total : 0; }

@@ -73,8 +73,12 @@ OIS_DEV void terrain_cell(const DevTerrain& T, float x, float y, int& px, int& p
   px = (int)fx; py = (int)fy;
 }
 OIS_DEV float terrain_cell_height(const DevTerrain& T, int px, int py) {
-  // T.m[x][y] = min(h[x][y], h[x+1][y+1]), built once at ois_terrain_attach: one gather per sample
-  return (float)T.m[(size_t)px * T.cols + py] * T.vs;
+  // m(x, y) = min(h[x][y], h[x+1][y+1]), built once at ois_terrain_attach: one gather per sample. Stored in
+  // tiles of 8 x 8 cells = 128 B (one cache line): the 140 scan points of a robot are 5 cells apart and rotated
+  // by its yaw, so in a row-major field nearly every point is on a line of its own whatever the heading; a
+  // tile holds 2-3 of them (height scan at 65 536 arenas 53.9 -> 41.8 us, tools/height_scan_probe.py)
+  const size_t idx = ((size_t)((px >> 3) * T.tiles_per_row + (py >> 3)) << 6) + (size_t)(((px & 7) << 3) | (py & 7));
+  return (float)T.m[idx] * T.vs;
 }
 // footprints of the 4 wheels at the current pose: world xy under the wheel centres and the field
 // height there (4 gathers of the min-field, issued here, consumed one substep later). A wheel moves at most ~2 cm

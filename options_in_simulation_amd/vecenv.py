@@ -214,7 +214,8 @@ class NativeEnv:
         t.curriculum = int(bool(cur))
         t.threshold_low, t.threshold_high = float(threshold_low), float(threshold_high)
         t.max_level = int(min(5, t.num_levels - 1) if max_level is None else max_level)  # KAMMA.py:525
-        minfield = torch.empty_like(field)  # scratch the library fills with min(h[x][y], h[x+1][y+1])
+        # scratch the library fills with min(h[x][y], h[x+1][y+1]) in 8 x 8-cell tiles
+        minfield = torch.empty(self.L.ois_minfield_bytes(t.rows, t.cols) // 2, dtype=torch.int16, device=self.device)
         torch.cuda.synchronize(self.device)
         _native.check(self.L.ois_terrain_attach(self.h, C.byref(t), C.c_void_p(field.data_ptr()),
                                                 C.c_void_p(minfield.data_ptr()), C.c_void_p(origins.data_ptr()),

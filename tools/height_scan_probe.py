@@ -20,4 +20,29 @@ e0.record()
 for _ in range(reps):
     env.height_scan(scan)
 e1.record(); torch.cuda.synchronize()
-print(json.dumps({"arenas": N, "height_scan_us": e0.elapsed_time(e1) * 1e3 / reps, "checksum": float(scan.double().sum())}))
+out = {"arenas": N, "height_scan_us": e0.elapsed_time(e1) * 1e3 / reps, "checksum": float(scan.double().sum())}
+# how much of it is line traffic: the same scan with every robot axis-aligned (a row of the row-major field
+# holds a whole line of scan points) and with every robot at 45 degrees (every point on another row)
+if "--yaw" in sys.argv:
+    q = env.buffer(_abi.BUF_QUAT)
+    q0 = q.clone()
+    def timeit():
+        env.height_scan(scan); torch.cuda.synchronize()
+        e0.record()
+        for _ in range(reps):
+            env.height_scan(scan)
+        e1.record(); torch.cuda.synchronize()
+        return e0.elapsed_time(e1) * 1e3 / reps
+    out["again_us"] = timeit()
+    q[:, 1:3] = 0; q.div_(q.norm(dim=1, keepdim=True))
+    out["own_yaw_only_us"] = timeit()
+    q.copy_(q0); out["restored_us"] = timeit()
+    for name, yaw in (("aligned_yaw0", 0.0), ("yaw90", np.pi / 2), ("yaw45", np.pi / 4)):
+        q.zero_(); q[:, 0] = float(np.cos(yaw / 2)); q[:, 3] = float(np.sin(yaw / 2))
+        env.height_scan(scan); torch.cuda.synchronize()
+        e0.record()
+        for _ in range(reps):
+            env.height_scan(scan)
+        e1.record(); torch.cuda.synchronize()
+        out[name + "_us"] = e0.elapsed_time(e1) * 1e3 / reps
+print(json.dumps(out))
