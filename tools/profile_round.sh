@@ -53,5 +53,5 @@ print(json.dumps(out))
 PY
 grep step_kernel $OUT/${R}_bench_kernel_stats.csv | cut -c1-200
 # the multi-process path on this 1-GPU box: two gloo ranks sharing the card, launched by bench.py itself
-OIS_DIST_BACKEND=gloo python bench.py --gpus 2 --steps 60 --warmup 10 > $OUT/${R}_bench_gloo2.json 2>> $OUT/${R}_bench.err
+OIS_DIST_BACKEND=gloo python bench.py --gpus 2 --steps 120 --warmup 10 > $OUT/${R}_bench_gloo2.json 2>> $OUT/${R}_bench.err
 tail -c 400 $OUT/${R}_bench_gloo2.json
