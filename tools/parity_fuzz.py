@@ -22,7 +22,7 @@ N = int(sys.argv[1]) if len(sys.argv) > 1 else 2048
 STEPS = int(sys.argv[2]) if len(sys.argv) > 2 else 230
 FLOATS = [_abi.BUF_POSE, _abi.BUF_QUAT, _abi.BUF_LINVEL, _abi.BUF_ANGVEL, _abi.BUF_WHEEL_VEL, _abi.BUF_COMMANDS, _abi.BUF_SUMS_A,
           _abi.BUF_SUMS_B, _abi.BUF_LAMBDA_N, _abi.BUF_LAMBDA_L, _abi.BUF_LAMBDA_T, _abi.BUF_WHEEL_TORQS, _abi.BUF_OBS, _abi.BUF_REW]
-EXACT = [_abi.BUF_COUNTERS, _abi.BUF_DONE, _abi.BUF_TIMEOUT]
+EXACT = [_abi.BUF_COUNTERS, _abi.BUF_DONE, _abi.BUF_TIMEOUT, _abi.BUF_TERRAIN_IDX, _abi.BUF_CMD_FRACTION]
 
 
 def same(dev, orc, where):
@@ -40,10 +40,10 @@ def same(dev, orc, where):
 cases = 0
 t0 = time.time()
 for variant in sorted(VARIANTS):
-    for ground in ("plane", "domain-rand", "field"):
+    for ground in ("plane", "domain-rand", "field", "field+curriculum"):
         for shell in ("1", "2"):
             os.environ["OIS_STEP_WAVES"] = shell
-            if ground == "field" and shell == "2":
+            if ground.startswith("field") and shell == "2":
                 continue  # the terrain kernels have one shell
             seed = 100 + cases
             cfg = build_config(variant=variant, num_envs=N, seed=seed, max_sim_steps=float(STEPS))
@@ -51,10 +51,11 @@ for variant in sorted(VARIANTS):
             if ground == "domain-rand":
                 sl = [-0.3, -0.2, 0.0, 0.2, 0.3]
                 dev.randomize_params(0.5, 1.0, sl); orc.randomize_params(0.5, 1.0, sl)
-            if ground == "field":
+            if ground.startswith("field"):
                 T = tg.Terrain({"numLevels": 3, "numTerrains": 2, "mapLength": 8.0, "mapWidth": 8.0}, N, seed=seed)
                 lt = T.sample_levels_types(N, rng=np.random.RandomState(seed))
-                dev.attach_terrain(T, lt); orc.attach_terrain(T, lt)
+                kw = dict(curriculum=True, threshold_low=-600.0, threshold_high=-330.0, max_level=2) if ground.endswith("curriculum") else {}
+                dev.attach_terrain(T, lt, **kw); orc.attach_terrain(T, lt, **kw)  # with the curriculum: level moves + per-level commands
             dev.reset(seed); orc.reset(seed)
             rng = np.random.default_rng(seed)
             lo = -1.0 if variant.startswith("KA_DDPG") else 0.0
@@ -65,7 +66,7 @@ for variant in sorted(VARIANTS):
                     same(dev, orc, f"{variant} {ground} shell {shell} step {t}")
             dev.rollout(25, _abi.POLICY_RANDOM); orc.rollout(25, _abi.POLICY_RANDOM)
             same(dev, orc, f"{variant} {ground} shell {shell} fused rollout")
-            if not np.array_equal(dev.episode_info().cpu().numpy(), orc.episode_info()):
+            if not np.array_equal(dev.episode_info().cpu().numpy(), orc.episode_info(), equal_nan=True):
                 print(f"DIFFERENCE {variant} {ground}: episode_info"); sys.exit(1)
             dev.close(); orc.close()
             cases += 1
