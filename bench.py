@@ -276,8 +276,12 @@ def main(argv=None):
     torch.cuda.set_device(dev_index)
     device = torch.device("cuda", dev_index)
     comm_device = torch.device("cpu") if backend == "gloo" else device
-    if world > 1:
+    # OIS_BENCH_FORCE_DIST=1: join a process group even with one rank, so that a 1-GPU box runs every
+    # collective of the N-rank path through RCCL (rehearsal; the line then still says n_gpus = 1)
+    dist_on = world > 1 or bool(os.environ.get("OIS_BENCH_FORCE_DIST"))
+    if dist_on:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", str(free_port()))
         if backend == "nccl":
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
         else:
@@ -314,13 +318,13 @@ def main(argv=None):
             env.step(a)
 
     def barrier():
-        if world > 1:
+        if dist_on:
             dist.barrier()
         torch.cuda.synchronize()
 
     for _ in range(args.warmup):
         one_step()
-    if world > 1:  # warm the collective too
+    if dist_on:  # warm the collective too
         gather_stats(env.stats(reset_after=True), device)
     barrier()
     env.profile_begin()  # start / stop events on every step kernel's own dispatch packet
@@ -330,11 +334,11 @@ def main(argv=None):
         one_step()
         if (s + 1) % args.log_interval == 0 or s + 1 == args.steps:
             st = env.stats(reset_after=True)           # one tiny D2H per logging interval
-            gathered = gather_stats(st, device) if world > 1 else [st]
+            gathered = gather_stats(st, device) if dist_on else [st]
     barrier()
     elapsed = time.perf_counter() - t0
     kernel_ms_total, launches = env.profile_end()
-    if world > 1:
+    if dist_on:
         t = torch.tensor([elapsed], dtype=torch.float64, device=comm_device)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
@@ -375,8 +379,8 @@ def main(argv=None):
                        "arenas_per_gpu": N, "substeps_per_step": cfg.decimation + cfg.extra_substeps,
                        "solver_iterations": cfg.solver_iterations, "sharding": f"arenas x{world}, no data-path collective",
                        "stats_allgather_every": args.log_interval,
-                       "ranks": dist.get_world_size() if world > 1 else 1,
-                       "backend": (dist.get_backend() + (" (RCCL)" if backend == "nccl" else "")) if world > 1 else "none",
+                       "ranks": dist.get_world_size() if dist_on else 1,
+                       "backend": (dist.get_backend() + (" (RCCL)" if backend == "nccl" else "")) if dist_on else "none",
                        "rank_table": [{"rank": r, "device": d, "arena_offset": o, "arenas": n} for r, d, o, n in rank_table]},
             "roofline": {"bound": "valu", "achieved": flops, "peak": FP32_VECTOR_PEAK_TFLOPS, "unit": "TFLOP/s",
                          "frac": flops / FP32_VECTOR_PEAK_TFLOPS, "traffic": traffic,
@@ -412,7 +416,7 @@ def main(argv=None):
                 out["cpu_baseline"] = {"value": None, "unit": "env-steps/s", "cores": 0, "kind": "port",
                                        "sample": f"not measured: {type(exc).__name__}: {exc}"}
         print(json.dumps(out), flush=True)
-    if world > 1:
+    if dist_on:
         dist.barrier()
         dist.destroy_process_group()
     env.close()
