@@ -346,7 +346,9 @@ int ois_replay_sample(ois_env* env, const int64_t* indexes_device, int count, fl
  * evaluates, so the un-normalised outputs are bit-identical to the torch loop; gamma and lambda
  * are the Python doubles (torch rounds a scalar operand to float32 when it meets a float32
  * tensor: ppo uses f32(gamma) and f32(lambda), ppoc f32(gamma) and f32(gamma*lambda)).
- * scratch_device: ois_gae_scratch_bytes(N) bytes, only needed when normalize != 0. */
+ * scratch_device: ois_gae_scratch_bytes(N) bytes, only needed when normalize != 0.
+ * ois_gae has no environment handle: it launches on the CALLER's current device, which must be the one the
+ * pointers belong to (the Python wrapper holds a torch.cuda.device guard around the call). */
 enum ois_gae_mode { OIS_GAE_PPO = 0, OIS_GAE_PPOC = 1 };
 size_t ois_gae_scratch_bytes(int num_envs);
 int ois_gae(int mode, int T, int num_envs, const float* rewards, const uint8_t* terminated,
