@@ -275,7 +275,8 @@ int ois_rollout(ois_env* env, int k, int policy, const float* actions_device,
  * dispatch packet (hipExtLaunchKernel), so the elapsed time is the kernel's begin -> end as
  * rocprofv3 --kernel-trace reports it: no launch gap, no marker packets between kernels. end
  * synchronises with the last profiled launch and returns the summed kernel time and the launch
- * count. Not for use under HIP-graph capture. */
+ * count. Not for use under HIP-graph capture (OIS_ESTATE), like a step with a transition memory attached:
+ * both keep a host-side cursor that advances per call, not per replay. */
 int ois_profile_begin(ois_env* env);
 int ois_profile_end(ois_env* env, double* kernel_ms_total, long long* launches);
 

@@ -1147,6 +1147,15 @@ static int prof_next_pair(ois_env* e, hipEvent_t* a, hipEvent_t* b) {
 
 static int launch_kernel(ois_env* e, int k, int policy, const float* actions, float* reward_sum, void* stream) {
   OIS_ON_DEVICE(e->device);
+  if (e->B.rp_size > 0 || e->prof_on) {
+    // the transition-memory cursor and the profiling events live on the host and advance per CALL: a
+    // captured launch would write the same memory row on every replay of the graph
+    hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+    if (hipStreamIsCapturing((hipStream_t)stream, &cap) == hipSuccess && cap != hipStreamCaptureStatusNone)
+      return fail(OIS_ESTATE, e->prof_on ? "ois_profile_* is not for use under stream capture"
+                                         : "a transition memory is attached: its cursor advances on the host per call, so a step that "
+                                           "writes it cannot be captured into a HIP graph (detach it, or keep the step out of the graph)");
+  }
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
   if (e->prof_on) {
     int rc = prof_next_pair(e, &ev0, &ev1);

@@ -120,3 +120,58 @@ def test_merge_stats_std_at_half_a_million_episodes():
     assert m["return_mean"] == pytest.approx(ref_mean, rel=1e-6)
     assert m["return_std"] == pytest.approx(ref_std, rel=1e-4)
     assert st.return_min == pytest.approx(x.min(), rel=1e-6) and st.return_max == pytest.approx(x.max(), rel=1e-6)
+
+
+def _product_worker(rank, world, port, total, steps, out_dir):
+    """one PRODUCT environment shard per rank (the HIP path; the ranks share the box's one GPU, which gloo
+    allows and RCCL does not), the statistics and the extras through the real collectives"""
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from options_in_simulation_amd.vecenv import NativeEnv
+    lo, hi = shard_range(total, rank, world)
+    env = NativeEnv(build_config(variant="KAMMA_medium", num_envs=hi - lo, seed=11, arena_offset=lo, max_sim_steps=80.0), "cuda:0")
+    env.reset(11)
+    env.rollout(steps, _abi.POLICY_RANDOM)
+    parts = gather_stats(env.stats(reset_after=True))
+    merged = merge_stats(parts)
+    np.save(os.path.join(out_dir, f"state_{rank}.npy"), env.buffer(_abi.BUF_POSE).cpu().numpy())
+    info = gather_episode_info(env.episode_info().cpu().numpy(), hi - lo)
+    if rank == 0:
+        np.save(os.path.join(out_dir, "info.npy"), np.array([info[k] for k in sorted(info)]))
+        np.save(os.path.join(out_dir, "merged.npy"), np.array([merged["episodes"], merged["return_mean"], merged["return_std"], merged["return_min"],
+                                                                 merged["return_max"], merged["steps"], merged["length_mean"]]))
+    dist.barrier()
+    dist.destroy_process_group()
+    env.close()
+
+
+@pytest.mark.gpu
+def test_two_product_shards_on_gloo_match_the_unsharded_product_run(tmp_path):
+    """the multi-rank rehearsals used the oracle as the rank environment. Here two processes
+    each run a shard on the HIP path (arena_offset = shard start), gather through gloo, and the parent
+    compares with ONE product environment over all arenas: identical arenas, equal merged statistics."""
+    from options_in_simulation_amd.vecenv import NativeEnv
+    total, steps, world = 4000, 205, 2
+    mp.spawn(_product_worker, args=(world, _free_port(), total, steps, str(tmp_path)), nprocs=world, join=True)
+    full = NativeEnv(build_config(variant="KAMMA_medium", num_envs=total, seed=11, max_sim_steps=80.0), "cuda:0")
+    full.reset(11)
+    full.rollout(steps, _abi.POLICY_RANDOM)
+    cat = np.concatenate([np.load(tmp_path / f"state_{r}.npy") for r in range(world)])
+    assert np.array_equal(cat, full.buffer(_abi.BUF_POSE).cpu().numpy())
+    merged = np.load(tmp_path / "merged.npy")
+    st = full.stats()
+    assert merged[0] == st.episodes == 2 * total
+    mean = st.return_sum / st.episodes
+    assert merged[1] == pytest.approx(mean, rel=1e-12)
+    assert merged[2] == pytest.approx((st.return_sqsum / st.episodes - mean * mean) ** 0.5, rel=1e-9)
+    assert merged[3] == st.return_min and merged[4] == st.return_max
+    assert merged[5] == total * steps and merged[6] == 99.0
+    ei = full.episode_info().cpu().numpy()
+    ref = {key: float(ei[slot]) for slot, key in _abi.EPISODE_INFO_KEYS.items()}
+    ref["count"], ref["step"] = float(ei[_abi.EI_COUNT]), float(ei[_abi.EI_STEP])
+    for slot, key in _abi.EPISODE_INFO_EVAL_KEYS.items():
+        ref[key] = float(ei[slot])
+    got = dict(zip(sorted(ref), np.load(tmp_path / "info.npy")))
+    assert got["count"] == ref["count"] == total and got["step"] == ref["step"] == 198
+    for key in ref:
+        assert got[key] == pytest.approx(ref[key], rel=1e-5, abs=1e-6, nan_ok=True), key

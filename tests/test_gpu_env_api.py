@@ -132,6 +132,31 @@ def test_full_size_properties(N):
     assert float(a.episode_info()[_abi.EI_COUNT]) == N
 
 
+def test_capture_with_a_transition_memory_attached_is_refused():
+    """graph replays do not advance the host-side replay cursor — so such a capture is refused
+    instead of silently writing one memory row over and over"""
+    from options_in_simulation_amd.vecenv import NativeEnv
+    N = 256
+    env = NativeEnv(build_config(variant="KAMMA_medium", num_envs=N, seed=1), "cuda:0")
+    env.reset(1)
+    env.attach_replay(8)
+    a = torch.rand((N, 4), device="cuda")
+    env.step(a)
+    torch.cuda.synchronize()
+    g = torch.cuda.CUDAGraph()
+    s = torch.cuda.Stream()
+    s.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(s):
+        with pytest.raises(RuntimeError, match="transition memory"):
+            with torch.cuda.graph(g, stream=s):
+                env.step(a)
+    torch.cuda.synchronize()
+    env.detach_replay()
+    env.step(a)  # and the environment is still usable
+    torch.cuda.synchronize()
+    assert env.replay_cursor() == (0, False)
+
+
 def _blocks(N, width=64):
     """contiguous arena blocks spread over [0, N): the oracle steps them as small envs at arena_offset"""
     starts = sorted({0, (N // 3) // 16 * 16 + 5, (2 * N // 3) // 16 * 16 + 11, N - width})
