@@ -31,6 +31,7 @@
  *   ois_terrain_attach          <- get_terrain / _create_trimesh / update_SI_level
  *                                  (KAMMA.py:296-349, 502-529; commented out there)
  *   ois_height_scan             <- get_heights (KAMMA.py:872-893)
+ *   ois_push_robots             <- push_robots (KAMMA.py:729-733; defined, never called there)
  *   ois_randomize_params, ois_save_state / ois_load_state: no reference counterpart
  *                                  (BASELINE.json configs[3]; SURVEY.md §5 checkpoint)
  *
@@ -288,6 +289,11 @@ int ois_buffer(ois_env* env, int id, void** ptr_device, size_t* bytes);
  * from Philox keyed by the global arena id. n_slopes == 0 keeps the flat plane. */
 int ois_randomize_params(ois_env* env, float mu_lo, float mu_hi, const float* slopes_host,
                          int n_slopes, void* stream);
+
+/* push_robots (KAMMA.py:729-733): the world linear velocity x, y of EVERY arena is replaced by U(-1, 1)
+ * draws (Philox purpose 7, counter = the arena's sim_steps; torch_rand_float(-1.0, 1.0, ...)). The reference
+ * defines it and never calls it; here for scripts that do. */
+int ois_push_robots(ois_env* env, void* stream);
 
 /* Reduce the per-wave partial sums of the most recent reset event into OIS_BUF_EPISODE_INFO
  * (device). No host synchronisation. */

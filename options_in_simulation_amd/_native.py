@@ -20,7 +20,7 @@ SYMBOLS = (
     "ois_episode_info", "ois_stats_fetch", "ois_env0_diag", "ois_state_bytes", "ois_save_state",
     "ois_load_state", "ois_replay_bytes", "ois_replay_attach", "ois_replay_buffer", "ois_replay_cursor",
     "ois_gae_scratch_bytes", "ois_gae", "ois_terrain_attach", "ois_height_scan", "ois_replay_sample",
-    "ois_profile_begin", "ois_profile_end", "ois_minfield_bytes",
+    "ois_profile_begin", "ois_profile_end", "ois_minfield_bytes", "ois_push_robots",
 )
 
 _lib = None
@@ -65,6 +65,7 @@ def load() -> C.CDLL:
     L.ois_buffer.argtypes = [vp, C.c_int, C.POINTER(vp), C.POINTER(C.c_size_t)]
     L.ois_randomize_params.argtypes = [vp, C.c_float, C.c_float, fp, C.c_int, vp]
     L.ois_episode_info.argtypes = [vp, vp]
+    L.ois_push_robots.argtypes = [vp, vp]
     L.ois_stats_fetch.argtypes = [vp, C.POINTER(_abi.OisStats), C.c_int, vp]
     L.ois_env0_diag.argtypes = [vp, fp, vp]
     L.ois_state_bytes.argtypes = [vp]

@@ -103,7 +103,7 @@ OIS_DEV void philox4x32_10(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, u
   o[0] = c0; o[1] = c1; o[2] = c2; o[3] = c3;
 }
 OIS_DEV float u01(uint32_t x) { return (float)(x >> 8) * 5.9604644775390625e-08f; }
-enum { PURPOSE_MASK = 0, PURPOSE_RESET_A = 1, PURPOSE_RESET_B = 2, PURPOSE_ACTION = 3, PURPOSE_PARAMS = 4, PURPOSE_RESET_C = 5, PURPOSE_CMD = 6 };
+enum { PURPOSE_MASK = 0, PURPOSE_RESET_A = 1, PURPOSE_RESET_B = 2, PURPOSE_ACTION = 3, PURPOSE_PARAMS = 4, PURPOSE_RESET_C = 5, PURPOSE_CMD = 6, PURPOSE_PUSH = 7 };
 OIS_DEV void draw4(const DevConsts& K, int64_t gid, uint32_t step, uint32_t purpose, float u[4]) {
   uint32_t o[4];
   philox4x32_10((uint32_t)((uint64_t)gid & 0xffffffffu), (uint32_t)((uint64_t)gid >> 32), step, purpose,

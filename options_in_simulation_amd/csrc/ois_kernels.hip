@@ -587,6 +587,18 @@ __global__ __launch_bounds__(256) void level_command_kernel(DevConsts K, DevBuff
   B.commands[i] = c;
 }
 
+// push_robots (KAMMA.py:729-733): base_velocities[:, 0:2] = torch_rand_float(-1.0, 1.0, (num_envs, 2))
+__global__ __launch_bounds__(256) void push_robots_kernel(DevConsts K, DevBuffers B, int N) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= N) return;
+  float u[4];
+  draw4(K, K.arena_offset + i, (uint32_t)B.counters[i].y, PURPOSE_PUSH, u);
+  float4 v = B.linvel[i];
+  v.x = rand_float(-1.0f, 1.0f, u[0]);
+  v.y = rand_float(-1.0f, 1.0f, u[1]);
+  B.linvel[i] = v;
+}
+
 __global__ void init_params_kernel(DevBuffers B, int N, float mu) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i < N) B.params[i] = make_float4(mu, 0.0f, 0.0f, 1.0f);
@@ -1318,6 +1330,15 @@ int ois_height_scan(ois_env* e, float* heights_out_device, void* stream) {
   OIS_ON_DEVICE(e->device);
   hipLaunchKernelGGL(height_scan_kernel, dim3((unsigned)((e->N + kScanArenas - 1) / kScanArenas)), dim3(256), 0, (hipStream_t)stream,
                      e->K, e->B, e->N, heights_out_device);
+  HIP_TRY(hipGetLastError());
+  return OIS_OK;
+}
+
+int ois_push_robots(ois_env* e, void* stream) {
+  if (!e) return fail(OIS_EINVAL, "null env");
+  if (!e->reset_done) return fail(OIS_ESTATE, "ois_push_robots called before ois_reset");
+  OIS_ON_DEVICE(e->device);
+  hipLaunchKernelGGL(push_robots_kernel, dim3((e->N + 255) / 256), dim3(256), 0, (hipStream_t)stream, e->K, e->B, e->N);
   HIP_TRY(hipGetLastError());
   return OIS_OK;
 }

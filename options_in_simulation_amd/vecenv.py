@@ -162,6 +162,11 @@ class NativeEnv:
         ptr = s.ctypes.data_as(C.POINTER(C.c_float)) if s.size else None
         _native.check(self.L.ois_randomize_params(self.h, mu_lo, mu_hi, ptr, int(s.size), _stream_ptr(self.device)))
 
+    def push_robots(self):
+        """push_robots (KAMMA.py:729-733): linear velocity x, y of every arena <- U(-1, 1)"""
+        _native.check(self.L.ois_push_robots(self.h, _stream_ptr(self.device)))
+        self.epoch += 1
+
     def episode_info(self) -> torch.Tensor:
         """launch the finalisation kernel; returns the device vector (no host sync)."""
         _native.check(self.L.ois_episode_info(self.h, _stream_ptr(self.device)))
@@ -521,6 +526,16 @@ class TorqueDistributionTask:
         return torch.clip(z.unsqueeze(1) - self.get_heights() - 0.0622, -1.0, 1.0) * height_meas_scale
 
     # ---- reference call sequence ----
+    def push_robots(self):
+        """KAMMA.py:729-733 (defined there, never called): random planar velocity for every robot"""
+        self.native.push_robots()
+
+    def refresh_dof_state_tensors(self):
+        """KAMMA.py:587-589: nothing to fetch, dof_vel is a view of the library's buffer"""
+
+    def refresh_body_state_tensors(self):
+        """KAMMA.py:591-593: nothing to fetch, base_pos / base_quat / base_velocities read the live buffers"""
+
     def post_reset(self, seed: Optional[int] = None):
         """KAMMA.py:366-414"""
         self.native.reset(seed)

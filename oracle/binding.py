@@ -44,6 +44,7 @@ def lib() -> C.CDLL:
         L.orc_rollout.argtypes = [C.c_void_p, C.c_int, C.c_int, fp, fp]
         L.orc_randomize_params.argtypes = [C.c_void_p, C.c_float, C.c_float, fp, C.c_int]
         L.orc_set_threads.argtypes = [C.c_void_p, C.c_int]
+        L.orc_push_robots.argtypes = [C.c_void_p]
         L.orc_buffer.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.c_void_p), C.POINTER(C.c_size_t)]
         L.orc_episode_info.argtypes = [C.c_void_p]
         L.orc_stats_fetch.argtypes = [C.c_void_p, C.POINTER(_abi.OisStats), C.c_int]
@@ -206,6 +207,9 @@ class OracleEnv:
         self._check(self.L.orc_rollout(self.h, k, policy, fptr(a) if a is not None else None,
                                        fptr(rs) if rs is not None else None))
         return rs
+
+    def push_robots(self):
+        self._check(self.L.orc_push_robots(self.h))
 
     def randomize_params(self, mu_lo, mu_hi, slopes=()):
         s = np.asarray(slopes, np.float32)

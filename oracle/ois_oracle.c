@@ -49,7 +49,7 @@ void orc_philox4x32_10(const uint32_t ctr[4], const uint32_t key[2], uint32_t ou
 /* 24 random bits -> [0,1), exact in float32 */
 float orc_u01(uint32_t x) { return (float)(x >> 8) * 5.9604644775390625e-08f; }
 
-enum { PURPOSE_MASK = 0, PURPOSE_RESET_A = 1, PURPOSE_RESET_B = 2, PURPOSE_ACTION = 3, PURPOSE_PARAMS = 4, PURPOSE_RESET_C = 5, PURPOSE_CMD = 6 };
+enum { PURPOSE_MASK = 0, PURPOSE_RESET_A = 1, PURPOSE_RESET_B = 2, PURPOSE_ACTION = 3, PURPOSE_PARAMS = 4, PURPOSE_RESET_C = 5, PURPOSE_CMD = 6, PURPOSE_PUSH = 7 };
 
 static void draw4(uint64_t seed, int64_t arena, uint32_t step, uint32_t purpose, float u[4]) {
   uint32_t ctr[4] = {(uint32_t)((uint64_t)arena & 0xffffffffu), (uint32_t)((uint64_t)arena >> 32), step, purpose};
@@ -1522,6 +1522,18 @@ int orc_stats_fetch(orc_env* e, ois_stats* out, int reset_after) {
   out->episodes = cnt; out->return_sum = ret; out->return_sqsum = ret2; out->return_min = mn;
   out->return_max = mx; out->length_sum = len; out->steps = e->steps_done; out->reserved = 0.0;
   if (reset_after) stats_clear(e);
+  return OIS_OK;
+}
+
+/* push_robots (KAMMA.py:729-733): base_velocities[:, 0:2] = torch_rand_float(-1.0, 1.0, (num_envs, 2)) */
+int orc_push_robots(orc_env* e) {
+  if (!e) return fail(OIS_EINVAL, "null env");
+  for (int i = 0; i < e->N; ++i) {
+    float u[4];
+    draw4(e->seed, e->cfg.arena_offset + i, (uint32_t)e->counters[4 * i + 1], PURPOSE_PUSH, u);
+    e->linvel[4 * i + 0] = rand_float(-1.0f, 1.0f, u[0]);
+    e->linvel[4 * i + 1] = rand_float(-1.0f, 1.0f, u[1]);
+  }
   return OIS_OK;
 }
 

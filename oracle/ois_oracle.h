@@ -124,6 +124,8 @@ void orc_substep(const ois_config* cfg, float mu, const float n_world[3], const 
                  float p[3], float q[4], float v[3], float w[3], float spin[4], float lam_n[4],
                  float lam_l[4], float lam_t[4]);
 
+int orc_push_robots(orc_env* env);
+
 /* IEEE binary16 <-> binary32, round to nearest even (the storage format of OIS_BUF_LAMBDA_*) */
 uint16_t orc_f2h(float f);
 float orc_h2f(uint16_t h);

@@ -157,6 +157,33 @@ def test_capture_with_a_transition_memory_attached_is_refused():
     assert env.replay_cursor() == (0, False)
 
 
+def test_push_robots_matches_the_oracle_and_only_touches_planar_velocity():
+    """push_robots (KAMMA.py:729-733): base_velocities[:, 0:2] ~ U(-1, 1) for every arena, nothing else"""
+    from options_in_simulation_amd.vecenv import VecEnv
+    from oracle.binding import OracleEnv
+    N = 300
+    env = VecEnv(num_envs=N, device="cuda:0", variant="KAMMA_medium", seed=9)
+    orc = OracleEnv(build_config(variant="KAMMA_medium", num_envs=N, seed=9))
+    env.reset(); orc.reset(9); orc.step(np.zeros((N, 4), np.float32))
+    a = np.full((N, 4), 0.3, np.float32)
+    for _ in range(3):
+        env.step(torch.from_numpy(a).cuda()); orc.step(a)
+    before = {b: env.task.native.buffer(b).clone() for b in (_abi.BUF_POSE, _abi.BUF_QUAT, _abi.BUF_ANGVEL, _abi.BUF_WHEEL_VEL)}
+    vz = env.task.native.buffer(_abi.BUF_LINVEL)[:, 2:].clone()
+    env.task.push_robots(); orc.push_robots()
+    env.task.refresh_body_state_tensors(); env.task.refresh_dof_state_tensors()
+    torch.cuda.synchronize()
+    lv = env.task.native.buffer(_abi.BUF_LINVEL)
+    assert np.array_equal(lv.cpu().numpy(), orc.buffer(_abi.BUF_LINVEL))
+    assert float(lv[:, :2].abs().max()) <= 1.0 and float(lv[:, :2].std()) > 0.4 and torch.equal(lv[:, 2:], vz)
+    for b, v in before.items():
+        assert torch.equal(env.task.native.buffer(b), v)
+    assert torch.equal(env.task.base_velocities[:, :2], lv[:, :2])
+    env.step(torch.from_numpy(a).cuda()); orc.step(a)   # and the pushed state steps identically
+    assert np.array_equal(env.task.native.buffer(_abi.BUF_POSE).cpu().numpy(), orc.buffer(_abi.BUF_POSE))
+    env.close()
+
+
 def _blocks(N, width=64):
     """contiguous arena blocks spread over [0, N): the oracle steps them as small envs at arena_offset"""
     starts = sorted({0, (N // 3) // 16 * 16 + 5, (2 * N // 3) // 16 * 16 + 11, N - width})
