@@ -263,6 +263,9 @@ OIS_DEV void step_body(const DevConsts& K, const DevBuffers& B, const float* __r
       if constexpr (PK && LPA == 1) {  // packed fp32 over wheel pairs (ois_physics_pk.h)
         substep_pk<true, TER, NIT>(K, B.ter, X);
         for (int i = 1; i < K.nsub; ++i) substep_pk<false, TER, NIT>(K, B.ter, X);
+      } else if constexpr (PK && LPA == 2) {  // a lane pair per arena, each lane one packed side pair
+        substep_pk2<true, NIT>(K, wheel0, X);
+        for (int i = 1; i < K.nsub; ++i) substep_pk2<false, NIT>(K, wheel0, X);
       } else {
         substep<true, LPA, TER, NIT>(K, B.ter, wheel0, X);
         for (int i = 1; i < K.nsub; ++i) substep<false, LPA, TER, NIT>(K, B.ter, wheel0, X);
@@ -920,7 +923,9 @@ struct ois_env {
   Layout L;
   char* ws;
   int N, device, grid;
-  int lpa;  // lanes per arena of the step kernel (1 | 2)
+  int lpa;  // lanes per arena of the step kernel (1 | 2), chosen by pick_lpa()
+  int lpa_forced;  // OIS_LANES_PER_ARENA: 0 = choose by size
+  int simds;
   bool packed;  // LPA = 1 only: per-wheel math on v_pk_*_f32 (ois_physics_pk.h)
   bool waves2;  // plane kernel shell held to 256 registers (step_kernel_w2), chosen by arena count
   uint64_t seed;  // seed of the last ois_reset (RNG key of the episode stream)
@@ -939,6 +944,20 @@ struct ois_env {
   double prof_ms;                   // kernel time of pairs already folded in (pool wrap-around)
   long long prof_launches;
 };
+
+// Lanes per arena of the step kernel.
+//  1: a lane owns an arena (two packed axle pairs). The layout for every arena count that gives each SIMD a
+//     wave of its own: 24.4 us per policy step from 4 096 to 65 536 arenas (fused rollouts).
+//  2: a lane PAIR owns an arena, each lane one packed side pair, the chassis replicated, four-wheel sums through
+//     one DPP add (substep_pk2): 431 instead of 614 VALU instructions per lane and substep, 18.3 us per policy
+//     step — while the doubled wave count still fits one wave per SIMD, i.e. up to simds * 32 arenas (32 768 on
+//     an MI355X); at 65 536 arenas the pairs put two waves on every SIMD and the step takes 32.6 us.
+// Both are bit-identical to the oracle. The terrain contact needs all four wheels in one lane.
+static void pick_lpa(ois_env* e) {
+  if (e->B.ter.on) e->lpa = 1;
+  else if (e->lpa_forced) e->lpa = e->lpa_forced;
+  else e->lpa = (e->packed && (long)e->N * 2 <= (long)e->simds * kBlock) ? 2 : 1;
+}
 
 namespace {
 size_t replay_layout(int N, int M, size_t off[OIS_RP_COUNT_], size_t bytes[OIS_RP_COUNT_]) {
@@ -1034,14 +1053,9 @@ int ois_create(const ois_config* cfg, int device, void* workspace_device, size_t
   e->device = device;
   e->grid = (e->N + kBlock - 1) / kBlock;
   {
-    // Lanes per arena. Measured on MI355X at 65 536 arenas: a lane pair per arena
-    // (2 waves per SIMD, 31 DPP adds per substep) ran a fused rollout in 45 us per policy step and
-    // a single-step launch in 68 us, against 30.5 us / 42 us for one lane per arena with packed
-    // wheel pairs (27.5 / 38 us since the solver shares the chassis' linear velocity). One lane per arena is the default; OIS_LANES_PER_ARENA=2 selects the pair
-    // layout (an experiment kept because it is bit-identical to the oracle and covered by the
-    // tests; no terrain, no unrolled-iteration variant).
+    // Lanes per arena: see pick_lpa() below. OIS_LANES_PER_ARENA=1|2 overrides the choice.
     const char* w = getenv("OIS_LANES_PER_ARENA");
-    e->lpa = (w && w[0] == '2') ? 2 : 1;
+    e->lpa_forced = (w && (w[0] == '1' || w[0] == '2')) ? w[0] - '0' : 0;
     // Packed fp32 over wheel pairs is the default at every size: two thirds of the VALU instructions
     // per substep (691 vs 1 081), and the advantage holds with one wave per SIMD (32.7 vs 41.4 us
     // per policy step at 65 536 arenas, tools/terrain_probe.py) as with two (131 072 arenas and up).
@@ -1053,9 +1067,12 @@ int ois_create(const ois_config* cfg, int device, void* workspace_device, size_t
     int simds = 1024;
     hipDeviceProp_t prop;
     if (hipGetDeviceProperties(&prop, device) == hipSuccess && prop.multiProcessorCount > 0) simds = 4 * prop.multiProcessorCount;
+    e->simds = simds;
     const char* wv = getenv("OIS_STEP_WAVES");
     e->waves2 = wv ? (wv[0] == '2') : ((long)e->N > (long)simds * kBlock);
   }
+  std::memset(&e->B.ter, 0, sizeof e->B.ter);
+  pick_lpa(e);
   e->seed = cfg->seed;
   e->reset_done = false;
   e->steps_done = 0.0;
@@ -1188,7 +1205,10 @@ static int launch_kernel(ois_env* e, int k, int policy, const float* actions, fl
   // instantiations: lanes per arena (2 = experiment), packed wheel pairs, height-field terrain
   // (ois_terrain_attach refuses LPA = 2), solver iterations unrolled (the default 4) or run-time
   const bool it4 = e->K.iters == 4;
-  if (e->lpa == 2) OIS_LAUNCH((step_kernel<2, false, 0>), 2);
+  if (e->lpa == 2) {
+    if (e->packed) { if (it4) OIS_LAUNCH((step_kernel<2, true, 4>), 2); else OIS_LAUNCH((step_kernel<2, true, 0>), 2); }
+    else OIS_LAUNCH((step_kernel<2, false, 0>), 2);
+  }
   else if (e->B.ter.on) {
     if (e->packed) { if (it4) OIS_LAUNCH((step_kernel_terrain<true, 4>), 1); else OIS_LAUNCH((step_kernel_terrain<true, 0>), 1); }
     else           { if (it4) OIS_LAUNCH((step_kernel_terrain<false, 4>), 1); else OIS_LAUNCH((step_kernel_terrain<false, 0>), 1); }
@@ -1277,6 +1297,7 @@ int ois_terrain_attach(ois_env* e, const ois_terrain* t, const int16_t* heights_
   if (!t) {  // detach: back to the per-arena plane, origins and indices cleared
     std::memset(&e->B.ter, 0, sizeof e->B.ter);
     e->K.cmd_sampler = e->cfg.cmd_sampler;
+    pick_lpa(e);
     HIP_TRY(hipMemsetAsync(e->B.env_origins, 0, f4, s));
     HIP_TRY(hipMemsetAsync(e->B.terrain_idx, 0, f4, s));
     return OIS_OK;
@@ -1286,7 +1307,7 @@ int ois_terrain_attach(ois_env* e, const ois_terrain* t, const int16_t* heights_
       t->max_level < 0 || t->max_level >= t->num_levels || !heights_device || !minfield_device || !terrain_origins_device ||
       !levels_types_host)
     return fail(OIS_EINVAL, "bad terrain description");
-  if (e->lpa != 1) return fail(OIS_EINVAL, "the terrain contact needs one lane per arena (unset OIS_LANES_PER_ARENA)");
+  if (e->lpa_forced == 2) return fail(OIS_EINVAL, "the terrain contact needs one lane per arena (unset OIS_LANES_PER_ARENA)");
   // per-arena origin = terrain_origins[level, type] (KAMMA.py:397): built on the host from the
   // caller's table, so the table is read back once
   const size_t no = (size_t)t->num_levels * t->num_types * 3;
@@ -1319,6 +1340,7 @@ int ois_terrain_attach(ois_env* e, const ois_terrain* t, const int16_t* heights_
   e->tdesc = *t;
   // terrain.curriculum also switches the commands to the per-level generators (KAMMA.py:533, 719)
   e->K.cmd_sampler = t->curriculum ? OIS_CMD_LEVEL : e->cfg.cmd_sampler;
+  pick_lpa(e);
   if (t->curriculum && !(e->K.cmd_thr_high > 0.0f)) e->K.cmd_thr_high = 10.0f;
   return OIS_OK;
 }

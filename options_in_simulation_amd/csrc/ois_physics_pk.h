@@ -230,4 +230,143 @@ OIS_DEV void substep_pk(const DevConsts& K, const DevTerrain& T, PhysT<1>& S) {
 #undef OIS_PR
 }
 
+// ---- LPA = 2 on packed fp32: a lane pair per arena, lane h owns the SIDE pair (wheels 2h, 2h + 1 = front, rear
+// of the left / right side) in the halves of float2 operands; the chassis is replicated in both lanes and a sum
+// over the four wheels is the lane's pair sum plus the partner's (one quad_perm DPP add), which is the SPEC order
+// (w0 + w1) + (w2 + w3). Same operations, element for element, as substep<EXACT, 2> (ois_physics.h). For arena
+// counts that leave SIMDs empty with one lane per arena (N <= 32 768 on an MI355X): the per-lane instruction
+// stream is shorter (one packed pair instead of two) and the machine still holds one wave per SIMD.
+OIS_DEV float sum_side(f2 c) { return side_sum<2>(c.x + c.y); }
+
+template <bool EXACT, int NIT = 0>
+OIS_DEV void substep_pk2(const DevConsts& K, int wheel0, PhysT<2>& S) {
+  float R[9];
+  rotmat(S.q, R);
+  float vb[3], nb[3], wb[3] = {S.wb[0], S.wb[1], S.wb[2]};
+  const float n[3] = {S.n[0], S.n[1], S.n[2]};
+  rotT(R, S.v, vb);
+  rotT(R, n, nb);
+  vb[0] = __builtin_fmaf(-K.gdt, R[6], vb[0]);
+  vb[1] = __builtin_fmaf(-K.gdt, R[7], vb[1]);
+  vb[2] = __builtin_fmaf(-K.gdt, R[8], vb[2]);
+  f2 spin = {S.spin[0], S.spin[1]}, ln = {S.ln[0], S.ln[1]}, l1 = {S.l1[0], S.l1[1]}, l2 = {S.l2[0], S.l2[1]};
+  f2 mn = {S.mn[0], S.mn[1]}, m1 = {S.m1[0], S.m1[1]}, m2 = {S.m2[0], S.m2[1]};
+  const f2 tau = {S.tau[0], S.tau[1]};
+  // wheel drive + joint resistance, reaction on the chassis
+  const f2 jv = spin - wb[1];
+  const f2 over = jv - clamp2(jv, (f2)(K.wlim));
+  const f2 Tq = fma2(-K.climit, over, fma2(-K.damping, jv, tau));
+  spin = fma2(K.dt_over_Is, Tq, spin);
+  wb[1] = __builtin_fmaf(-K.dt_over_Iy, sum_side(Tq), wb[1]);
+  // contact frame shared by the four wheels
+  float s2 = __builtin_fmaf(nb[2], nb[2], nb[0] * nb[0]);
+  s2 = fmaxf(s2, 1e-12f);
+  const float inv_s = EXACT ? exact_rcp(sqrtf(s2)) : newton_rsqrt(S.inv_s, s2);
+  S.inv_s = inv_s;
+  const float dx = -(nb[0] * inv_s), dz = -(nb[2] * inv_s);
+  const float t1x = -dz, t1z = dx;
+  const float t2x = nb[1] * t1z;
+  const float t2y = __builtin_fmaf(nb[2], t1x, -(nb[0] * t1z));
+  const float t2z = -(nb[1] * t1x);
+  const float np = __builtin_fmaf(n[2], S.p[2], __builtin_fmaf(n[1], S.p[1], n[0] * S.p[0]));
+  const float cz = K.cz;
+  const f2 cx = {K.wx, -K.wx};                    // (front, rear) wheel of the side
+  const float cy = (wheel0 & 2) ? -K.wy : K.wy;   // left side = +y (urdf:112-142)
+  const f2 rx = fma2(K.rw, (f2)(dx), cx);
+  const float ry = cy, rz = __builtin_fmaf(K.rw, dz, cz);
+  const f2 gap = np + fma2(nb[2], (f2)(rz), fma2(nb[1], (f2)(ry), nb[0] * rx));
+  const f2 bA = -(gap * K.inv_dt), bB = -(gap * K.beta_inv_dt);
+  f2 b;
+  b.x = __builtin_fminf(__builtin_fminf(bA.x, bB.x), K.vdep);
+  b.y = __builtin_fminf(__builtin_fminf(bA.y, bB.y), K.vdep);
+  f2 an[3], a1[3], a2[3], Jan[3], Ja1[3], Ja2[3];
+  an[0] = (f2)(__builtin_fmaf(ry, nb[2], -(rz * nb[1])));
+  an[1] = fma2((f2)(rz), (f2)(nb[0]), -(rx * nb[2]));
+  an[2] = fma2(rx, (f2)(nb[1]), -(ry * nb[0]));
+  a1[0] = (f2)(cy * t1z);
+  a1[1] = fma2((f2)(cz), (f2)(t1x), -(cx * t1z));
+  a1[2] = (f2)(-(cy * t1x));
+  a2[0] = (f2)(__builtin_fmaf(ry, t2z, -(rz * t2y)));
+  a2[1] = fma2((f2)(rz), (f2)(t2x), -(rx * t2z));
+  a2[2] = fma2(rx, (f2)(t2y), -(ry * t2x));
+  Jan[0] = K.J4x * an[0]; Jan[1] = K.J4y * an[1]; Jan[2] = K.J4z * an[2];
+  Ja1[0] = K.J4x * a1[0]; Ja1[1] = K.J4y * a1[1]; Ja1[2] = K.J4z * a1[2];
+  Ja2[0] = K.J4x * a2[0]; Ja2[1] = K.J4y * a2[1]; Ja2[2] = K.J4z * a2[2];
+  const f2 kn = fma2(an[2], Jan[2], fma2(an[1], Jan[1], fma2(an[0], Jan[0], K.im4)));
+  const f2 k1 = fma2(a1[2], Ja1[2], fma2(a1[1], Ja1[1], fma2(a1[0], Ja1[0], K.im4))) + K.rw2_over_Is;
+  const f2 k2 = fma2(a2[2], Ja2[2], fma2(a2[1], Ja2[1], fma2(a2[0], Ja2[0], K.im4)));
+  if (EXACT) { mn = exact_rcp2(kn); m1 = exact_rcp2(k1); m2 = exact_rcp2(k2); }
+  else { mn = newton_rcp2(mn, kn); m1 = newton_rcp2(m1, k1); m2 = newton_rcp2(m2, k2); }
+  float un = __builtin_fmaf(nb[2], vb[2], __builtin_fmaf(nb[1], vb[1], nb[0] * vb[0]));
+  float u1 = __builtin_fmaf(t1z, vb[2], t1x * vb[0]);
+  float u2 = __builtin_fmaf(t2z, vb[2], __builtin_fmaf(t2y, vb[1], t2x * vb[0]));
+  // warm start
+  f2 ox = fma2(l2, Ja2[0], fma2(l1, Ja1[0], fma2(ln, Jan[0], wb[0])));
+  f2 oy = fma2(l2, Ja2[1], fma2(l1, Ja1[1], fma2(ln, Jan[1], wb[1])));
+  f2 oz = fma2(l2, Ja2[2], fma2(l1, Ja1[2], fma2(ln, Jan[2], wb[2])));
+  spin = fma2(-K.rw_over_Is, l1, spin);
+  {
+    const float Sn = sum_side(ln), S1 = sum_side(l1), S2 = sum_side(l2);
+    un = __builtin_fmaf(K.imq, Sn, un); u1 = __builtin_fmaf(K.imq, S1, u1); u2 = __builtin_fmaf(K.imq, S2, u2);
+  }
+  wb[0] = 0.25f * sum_side(ox); wb[1] = 0.25f * sum_side(oy); wb[2] = 0.25f * sum_side(oz);
+  const int iters = NIT > 0 ? NIT : K.iters;
+#pragma unroll
+  for (int it = 0; it < iters; ++it) {
+    // normal row
+    f2 u = fma2(an[2], wb[2], fma2(an[1], wb[1], fma2(an[0], wb[0], un)));
+    f2 nw = max2(fma2(b - u, mn, ln), (f2)(0.0f));
+    const f2 dn = nw - ln;
+    ln = nw;
+    ox = fma2(dn, Jan[0], wb[0]); oy = fma2(dn, Jan[1], wb[1]); oz = fma2(dn, Jan[2], wb[2]);
+    const f2 lim = S.mu * ln;
+    // longitudinal row (couples the wheel spin)
+    u = fma2(-K.rw, spin, fma2(a1[2], oz, fma2(a1[1], oy, fma2(a1[0], ox, u1))));
+    nw = clamp2(fma2(-u, m1, l1), lim);
+    const f2 d1 = nw - l1;
+    l1 = nw;
+    ox = fma2(d1, Ja1[0], ox); oy = fma2(d1, Ja1[1], oy); oz = fma2(d1, Ja1[2], oz);
+    spin = fma2(-K.rw_over_Is, d1, spin);
+    // lateral row
+    u = fma2(a2[2], oz, fma2(a2[1], oy, fma2(a2[0], ox, u2)));
+    nw = clamp2(fma2(-u, m2, l2), lim);
+    const f2 d2 = nw - l2;
+    l2 = nw;
+    ox = fma2(d2, Ja2[0], ox); oy = fma2(d2, Ja2[1], oy); oz = fma2(d2, Ja2[2], oz);
+    {
+      const float Sn = sum_side(dn), S1 = sum_side(d1), S2 = sum_side(d2);
+      un = __builtin_fmaf(K.imq, Sn, un); u1 = __builtin_fmaf(K.imq, S1, u1); u2 = __builtin_fmaf(K.imq, S2, u2);
+    }
+    wb[0] = 0.25f * sum_side(ox); wb[1] = 0.25f * sum_side(oy); wb[2] = 0.25f * sum_side(oz);
+  }
+  vb[0] = __builtin_fmaf(t2x, u2, __builtin_fmaf(t1x, u1, nb[0] * un));
+  vb[1] = __builtin_fmaf(t2y, u2, nb[1] * un);
+  vb[2] = __builtin_fmaf(t2z, u2, __builtin_fmaf(t1z, u1, nb[2] * un));
+  {
+    const f2 sp = clamp2(spin, (f2)(K.maxw));
+    S.spin[0] = sp.x; S.spin[1] = sp.y;
+    S.ln[0] = ln.x; S.ln[1] = ln.y; S.l1[0] = l1.x; S.l1[1] = l1.y; S.l2[0] = l2.x; S.l2[1] = l2.y;
+    S.mn[0] = mn.x; S.mn[1] = mn.y; S.m1[0] = m1.x; S.m1[1] = m1.y; S.m2[0] = m2.x; S.m2[1] = m2.y;
+  }
+  rot(R, vb, S.v);
+  const float w2 = __builtin_fmaf(wb[2], wb[2], __builtin_fmaf(wb[1], wb[1], wb[0] * wb[0]));
+  if (w2 > K.maxw2) {
+    const float sc = K.maxw / sqrtf(w2);
+    wb[0] *= sc; wb[1] *= sc; wb[2] *= sc;
+  }
+  S.wb[0] = wb[0]; S.wb[1] = wb[1]; S.wb[2] = wb[2];
+  S.p[0] = __builtin_fmaf(K.dt, S.v[0], S.p[0]);
+  S.p[1] = __builtin_fmaf(K.dt, S.v[1], S.p[1]);
+  S.p[2] = __builtin_fmaf(K.dt, S.v[2], S.p[2]);
+  const float qw = S.q[0], qx = S.q[1], qy = S.q[2], qz = S.q[3], h = K.half_dt;
+  const float nqw = __builtin_fmaf(-h, __builtin_fmaf(qz, wb[2], __builtin_fmaf(qy, wb[1], qx * wb[0])), qw);
+  const float nqx = __builtin_fmaf(h, __builtin_fmaf(-qz, wb[1], __builtin_fmaf(qy, wb[2], qw * wb[0])), qx);
+  const float nqy = __builtin_fmaf(h, __builtin_fmaf(-qx, wb[2], __builtin_fmaf(qz, wb[0], qw * wb[1])), qy);
+  const float nqz = __builtin_fmaf(h, __builtin_fmaf(-qy, wb[0], __builtin_fmaf(qx, wb[1], qw * wb[2])), qz);
+  const float nn = __builtin_fmaf(nqz, nqz, __builtin_fmaf(nqy, nqy, __builtin_fmaf(nqx, nqx, nqw * nqw)));
+  float inv = __builtin_fmaf(-0.5f, nn, 1.5f);
+  if (fabsf(nn - 1.0f) > 1e-3f) inv = 1.0f / sqrtf(nn);
+  S.q[0] = nqw * inv; S.q[1] = nqx * inv; S.q[2] = nqy * inv; S.q[3] = nqz * inv;
+}
+
 }  // namespace ois

@@ -1,6 +1,6 @@
 """Wide one-off parity sweep, kernel vs CPU oracle, bit for bit (GPU box; the oracle runs on the
 host cores): every task variant x {plane, per-arena friction + slope, height field} x kernel
-shell, N arenas x STEPS single steps with random actions, then one fused rollout.
+shell (one lane per arena in its two register budgets, a lane pair per arena), N arenas x STEPS single steps with random actions, then one fused rollout.
     python tools/parity_fuzz.py [N] [STEPS]
 Prints one line per case; exits non-zero on the first difference."""
 import os
@@ -41,9 +41,10 @@ cases = 0
 t0 = time.time()
 for variant in sorted(VARIANTS):
     for ground in ("plane", "domain-rand", "field", "field+curriculum"):
-        for shell in ("1", "2"):
-            os.environ["OIS_STEP_WAVES"] = shell
-            if ground.startswith("field") and shell == "2":
+        for shell in ("1", "2", "pair"):
+            os.environ["OIS_STEP_WAVES"] = "1" if shell == "pair" else shell
+            os.environ["OIS_LANES_PER_ARENA"] = "2" if shell == "pair" else "1"  # by size it would be the pair at this N
+            if ground.startswith("field") and shell != "1":
                 continue  # the terrain kernels have one shell
             seed = 100 + cases
             cfg = build_config(variant=variant, num_envs=N, seed=seed, max_sim_steps=float(STEPS))
