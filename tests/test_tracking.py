@@ -5,8 +5,10 @@ reward_components_env0_timeseries.csv of src/options_sim/cli/artifacts.py.
 Pinned: CRC-32C against the RFC 3720 B.4 vectors; the CSV header against the file the
 reference ships (my_runs/.../reward_components_env0_timeseries.csv: same columns, same order).
 The event-file bytes cannot be checked against TensorBoard itself (not installed here, no
-event file in the reference tree): writer and reader are checked against each other and
-against the published record framing (length, masked crc of the length, payload, masked crc).
+event file in the reference tree): writer and reader are checked against each other, against
+the published record framing (length, masked crc of the length, payload, masked crc), and the
+payloads are decoded by Google's protobuf runtime against TensorFlow's published Event / Summary
+schema (test_event_bytes_parse_with_the_protobuf_runtime).
 """
 import csv
 import os
@@ -149,3 +151,55 @@ def test_tracking_error_vs_speed_csv(tmp_path):
     w3 = tr.EventFileWriter(str(tmp_path / "c")); w3.close()
     with pytest.raises(ValueError):
         tr.write_tracking_error_vs_speed(w3.path)
+
+
+def test_event_bytes_parse_with_the_protobuf_runtime(tmp_path):
+    """The event files are written without TensorBoard (not importable here), and until now only the
+    module's own reader had read them back. This parses the records with Google's protobuf runtime against
+    descriptors built from TensorFlow's published schema (tensorflow/core/util/event.proto: Event{wall_time = 1
+    double, step = 2 int64, file_version = 3 string, summary = 5}; framework/summary.proto: Summary{value = 1
+    repeated}, Value{tag = 1 string, simple_value = 2 float}): an independent decoder for the wire format that
+    EventAccumulator (src/options_sim/cli/artifacts.py:68-92) reads. The TFRecord framing is checked by hand:
+    uint64 length, masked crc32c of the length, payload, masked crc32c of the payload."""
+    import struct
+    from google.protobuf import descriptor_pb2, descriptor_pool, message_factory
+    fd = descriptor_pb2.FileDescriptorProto(name="ois_event_check.proto", package="oisck", syntax="proto3")
+    val = fd.message_type.add(name="Value")
+    val.field.add(name="tag", number=1, type=descriptor_pb2.FieldDescriptorProto.TYPE_STRING, label=1)
+    val.field.add(name="simple_value", number=2, type=descriptor_pb2.FieldDescriptorProto.TYPE_FLOAT, label=1)
+    summ = fd.message_type.add(name="Summary")
+    summ.field.add(name="value", number=1, type=descriptor_pb2.FieldDescriptorProto.TYPE_MESSAGE, label=3, type_name=".oisck.Value")
+    ev = fd.message_type.add(name="Event")
+    ev.field.add(name="wall_time", number=1, type=descriptor_pb2.FieldDescriptorProto.TYPE_DOUBLE, label=1)
+    ev.field.add(name="step", number=2, type=descriptor_pb2.FieldDescriptorProto.TYPE_INT64, label=1)
+    ev.field.add(name="file_version", number=3, type=descriptor_pb2.FieldDescriptorProto.TYPE_STRING, label=1)
+    ev.field.add(name="summary", number=5, type=descriptor_pb2.FieldDescriptorProto.TYPE_MESSAGE, label=1, type_name=".oisck.Summary")
+    pool = descriptor_pool.DescriptorPool()
+    pool.Add(fd)
+    Event = message_factory.GetMessageClass(pool.FindMessageTypeByName("oisck.Event"))
+
+    w = tr.EventFileWriter(str(tmp_path))
+    w.add_scalar("Reward_comp_env0 / v_delta", 0.1645, 800)
+    w.add_scalars({"Info / rew_Final reward": -36.5, "Info / gamma_1 action assist": 0.9984}, 1600)
+    w.add_scalar("Reward / Total reward (mean)", -3.0e5, 2 ** 40)  # int64 step beyond 32 bits
+    w.close()
+    path = [os.path.join(tmp_path, f) for f in os.listdir(tmp_path) if "tfevents" in f][0]
+    data = open(path, "rb").read()
+    events, i = [], 0
+    while i < len(data):
+        (n,) = struct.unpack("<Q", data[i:i + 8])
+        assert struct.unpack("<I", data[i + 8:i + 12])[0] == tr.masked_crc(data[i:i + 8])
+        payload = data[i + 12:i + 12 + n]
+        assert struct.unpack("<I", data[i + 12 + n:i + 16 + n])[0] == tr.masked_crc(payload)
+        e = Event()
+        e.ParseFromString(payload)          # raises on a malformed message
+        from google.protobuf import unknown_fields
+        assert len(unknown_fields.UnknownFieldSet(e)) == 0  # every byte belonged to a field of the schema
+        events.append(e)
+        i += 16 + n
+    assert events[0].file_version == "brain.Event:2" and events[0].wall_time > 1e9
+    got = [(e.step, {v.tag: v.simple_value for v in e.summary.value}) for e in events[1:]]
+    assert got[0] == (800, {"Reward_comp_env0 / v_delta": np.float32(0.1645)})
+    assert got[1][0] == 1600 and got[1][1]["Info / rew_Final reward"] == np.float32(-36.5)
+    assert got[1][1]["Info / gamma_1 action assist"] == np.float32(0.9984)
+    assert got[2] == (2 ** 40, {"Reward / Total reward (mean)": np.float32(-3.0e5)})
