@@ -159,7 +159,7 @@ typedef struct ois_config {
   float wheel_pos[3];         /* |x|,|y|,z of wheel centres in base-link frame   urdf:115-139 */
   float wheel_radius;         /* 0.1175                            urdf:40, KAMMA.py:79 */
   float wheel_spin_inertia;   /* 0.01                              urdf:35      */
-  float wheel_damping;        /* viscous joint damping [N m s/rad], CALIBRATED */
+  float wheel_damping;        /* viscous joint damping c1 [N m s/rad], CALIBRATED (0: tests/golden/ref_stats.json) */
   float friction;             /* default mu (0.85 from scripts)    train_*.py:66-67 */
   float baumgarte;            /* penetration bias factor                          */
   float max_depenetration_velocity; /* 100                         KAMMA.py:105 */

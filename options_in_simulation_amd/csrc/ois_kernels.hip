@@ -1057,7 +1057,7 @@ int ois_create(const ois_config* cfg, int device, void* workspace_device, size_t
     const char* w = getenv("OIS_LANES_PER_ARENA");
     e->lpa_forced = (w && (w[0] == '1' || w[0] == '2')) ? w[0] - '0' : 0;
     // Packed fp32 over wheel pairs is the default at every size: two thirds of the VALU instructions
-    // per substep (691 vs 1 081), and the advantage holds with one wave per SIMD (32.7 vs 41.4 us
+    // per substep (614 vs 1 000), and the advantage holds with one wave per SIMD (29.9 vs 39.5 us
     // per policy step at 65 536 arenas, tools/terrain_probe.py) as with two (131 072 arenas and up).
     // OIS_PACKED=0 selects the scalar kernel.
     const char* pk = getenv("OIS_PACKED");

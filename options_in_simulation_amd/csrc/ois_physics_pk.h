@@ -6,7 +6,7 @@
 // v_pk_add_f32 (IEEE per element). Why it pays: at 65 536 arenas there is one wave per SIMD, and
 // a lone wave issues one VALU instruction per ~4-5 cycles whether it is a v_fma_f32 or a
 // v_pk_fma_f32 (tools/valu_rate.hip: 2.0-2.4 ns vs 2.5 ns), so a packed instruction does two
-// wheels for the price of one: 691 instead of 1 081 VALU instructions per substep. With two
+// wheels for the price of one: 614 instead of 1 000 VALU instructions per substep. With two
 // waves per SIMD (more arenas) the gap narrows but stays.
 // (In the earlier 4-lanes-per-arena layout, with 4 waves per SIMD, packed ran at half rate and
 // bought nothing: DESIGN.md section 4.)
