@@ -400,6 +400,58 @@ def test_task_terrain_surface():
 
 
 @pytest.mark.gpu
+def test_full_size_on_the_reference_terrain_against_the_oracle():
+    """BASELINE.json configs[3] on the reference's own terrain family at the stated size: 65 536 arenas on
+    the 6 x 2-tile field bench.py --terrain uses, EXTERNAL actions, per-arena friction. Four 64-arena blocks
+    across the range are stepped by the oracle (arena_offset = block start, the same field, the block's rows
+    of the level / type table): every state buffer and the height scan bit-identical. (Without the level
+    curriculum: its `fraction` snapshot is per environment, so a block is not the whole there -
+    tests/test_curriculum.py compares whole environments.)"""
+    from options_in_simulation_amd.vecenv import NativeEnv
+    N, width = 65536, 64
+    kw = dict(variant="KAMMA_medium", seed=23, max_sim_steps=150.0)
+    T = tg.Terrain({"numLevels": 6, "numTerrains": 2, "mapLength": 10.0, "mapWidth": 10.0}, N, seed=42)
+    lt = T.sample_levels_types(N, rng=np.random.RandomState(0))
+    dev = NativeEnv(build_config(num_envs=N, **kw), "cuda:0")
+    dev.attach_terrain(T, lt)
+    starts = sorted({0, (N // 3) // 16 * 16 + 5, (2 * N // 3) // 16 * 16 + 11, N - width})
+    orcs = []
+    for s0 in starts:
+        o = OracleEnv(build_config(num_envs=width, arena_offset=s0, **kw))
+        o.attach_terrain(T, lt[s0:s0 + width])
+        orcs.append(o)
+    dev.randomize_params(0.5, 1.0)
+    dev.reset(23)
+    for o in orcs:
+        o.randomize_params(0.5, 1.0)
+        o.reset(23)
+    bufs = STATE
+
+    def check(where):
+        torch.cuda.synchronize()
+        for s0, o in zip(starts, orcs):
+            for bid in bufs:
+                got = dev.buffer(bid)[s0:s0 + width].cpu().numpy()
+                got = got.astype(np.uint8) if got.dtype == np.bool_ else got
+                assert np.array_equal(got, o.buffer(bid)), f"{where}: arenas {s0}..{s0 + width}: buffer {bid} not bit-identical"
+    check("post_reset")
+    g = torch.Generator(device="cuda").manual_seed(9)
+    for t in range(104):
+        a = torch.rand((N, 4), device="cuda", generator=g)
+        dev.step(a)
+        for s0, o in zip(starts, orcs):
+            o.step(a[s0:s0 + width].cpu().numpy())
+        if t in (0, 50, 98, 99, 103):
+            check(f"step {t}")
+    hs = dev.height_scan()
+    for s0, o in zip(starts, orcs):
+        assert np.array_equal(hs[s0:s0 + width].cpu().numpy(), o.height_scan())
+    assert torch.isfinite(dev.buffer(_abi.BUF_OBS)).all() and dev.stats().episodes >= N
+    fell = (dev.buffer(_abi.BUF_COUNTERS)[:, 2] > 2).sum().item()  # more episodes than the two resets every arena had
+    assert fell > 0, "some robots must have tipped over on the obstacles for the test to cover it"
+
+
+@pytest.mark.gpu
 def test_terrain_sharding_invariance():
     """arena i stands on the same tile and follows the same trajectory whether it lives in a
     1-GPU env or in shard 1 of 2 (levels / types are drawn for the global arena range)"""
