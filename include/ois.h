@@ -399,8 +399,11 @@ typedef struct ois_terrain {
  * instead of two (same values; the indices are clamped to rows - 2 / cols - 2 before use,
  * KAMMA.py:886-887, so the last row and column are never read) — stored in tiles of 8 x 8 cells
  * (one 128-byte line each; rows and cols rounded up to multiples of 8), because the points a robot
- * samples are a rotated 10 cm lattice: 2-3 of them share a tile, none a row-major line.
- * Like the field it must outlive the attachment.
+ * samples are a rotated 10 cm lattice: 2-3 of them share a tile, none a row-major line. Behind it, in
+ * the same scratch, the field once more for ois_height_scan as 8-bit offsets from a per-tile minimum in
+ * tiles of 16 x 8 cells (a line holds twice the cells; a tile spanning more than 254 height units is
+ * marked and read from the 16-bit tiles: same values always). 256-byte aligned; the whole scratch must
+ * stay below 2^31 bytes (OIS_EINVAL otherwise). Like the field it must outlive the attachment.
  * Call before ois_reset. terrain == NULL detaches (back to the per-arena plane). */
 size_t ois_minfield_bytes(int rows, int cols);
 int ois_terrain_attach(ois_env* env, const ois_terrain* terrain, const int16_t* heights_device,

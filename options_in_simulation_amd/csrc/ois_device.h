@@ -51,9 +51,12 @@ struct DevConsts {
 };
 
 // height-field terrain (include/ois.h ois_terrain_attach); on == 0: the per-arena plane of `params`
+constexpr int kWideTile = -32768;  // DevTerrain::mb value of a tile whose heights do not fit base + 0..254
 struct DevTerrain {
   const int16_t* h;        // [rows][cols] raw heights (caller-owned)
   const int16_t* m;        // [rows][cols] min(h[x][y], h[x+1][y+1]), filled at attach (caller-owned scratch)
+  const uint8_t* m8;       // the same min-field as 8-bit offsets from a per-tile base, tiles of 16 x 8 cells = 128 B (height scan)
+  const int16_t* mb;       // base of each 16 x 8 tile, in blocks of 8 x 8 tiles (base_index); kWideTile: range > 254, read m instead
   const float* origins;    // [levels][types][3] terrain_origins table (caller-owned)
   int rows, cols, ntypes, max_level, curriculum, on;
   int tiles_per_row;  // the min-field is stored in 8 x 8-cell tiles of 128 B: ceil(cols / 8) tiles per tile row

@@ -466,9 +466,14 @@ __global__ __launch_bounds__(kBlock) void step_kernel_terrain(DevConsts K, DevBu
 // same one or two LDS records. (One thread per point recomputing the arena part: 154 VALU instructions
 // per point, ~24 us of issue at 65 536 arenas; here ~45.) Same float operations per point as the oracle's
 // orc_get_heights: bit-identical to tests/golden/refmath_heights.npz.
+OIS_DEV unsigned base_index(unsigned trow, unsigned tcol, unsigned tpr) {  // 8 x 8-tile blocks of the base table
+  return ((((trow >> 3) * ((tpr + 7u) >> 3) + (tcol >> 3)) << 6) | ((trow & 7u) << 3) | (tcol & 7u));
+}
 constexpr int kScanArenas = 32;
+constexpr int kScanUnroll = 3;  // gathers a lane keeps in flight
 __global__ __launch_bounds__(256) void height_scan_kernel(DevConsts K, DevBuffers B, int N, float* __restrict__ out) {
-  __shared__ float4 rec[kScanArenas];  // pwx, pwy, qw, qz
+  __shared__ float4 rec[kScanArenas];        // pwx, pwy, qw, qz
+  __shared__ float2 tab[OIS_HEIGHT_POINTS];  // body-frame lattice point of scan point pt (KAMMA.py:278-292)
   const int arena0 = blockIdx.x * kScanArenas;
   const int t = threadIdx.x;
   if (t < kScanArenas && arena0 + t < N) {
@@ -484,40 +489,110 @@ __global__ __launch_bounds__(256) void height_scan_kernel(DevConsts K, DevBuffer
     nrm = fmaxf(nrm, 1e-9f);
     rec[t] = make_float4(pwx, pwy, qu.x / nrm, qu.w / nrm);
   }
+  if (t >= 64 && t < 64 + OIS_HEIGHT_POINTS) {
+    const int pt = t - 64;
+    const int a = pt / 10, b = pt - a * 10;
+    const int gx = a < 7 ? a - 8 : a - 5;   // -8..-2, 2..8   (KAMMA.py:283-285)
+    const int gy = b < 5 ? b - 5 : b - 4;   // -5..-1, 1..5   (KAMMA.py:280-282)
+    tab[pt] = make_float2(0.1f * (float)gx, 0.1f * (float)gy);
+  }
   __syncthreads();
   const int narenas = min(kScanArenas, N - arena0);
   const int npts = narenas * OIS_HEIGHT_POINTS;
   float* o = out + (size_t)arena0 * OIS_HEIGHT_POINTS;
-  for (int p = t; p < npts; p += 256) {
-    const int la = p / OIS_HEIGHT_POINTS, pt = p - la * OIS_HEIGHT_POINTS;
-    const int a = pt / 10, b = pt - a * 10;
-    const int gx = a < 7 ? a - 8 : a - 5;   // -8..-2, 2..8   (KAMMA.py:283-285)
-    const int gy = b < 5 ? b - 5 : b - 4;   // -5..-1, 1..5   (KAMMA.py:280-282)
-    const float4 r = rec[la];
+  const float hs = B.ter.hs, border = B.ter.border, vs = B.ter.vs;
+  const float xmax = (float)(B.ter.rows - 2), ymax = (float)(B.ter.cols - 2);
+  const unsigned tpr = (unsigned)B.ter.tiles_per_row;
+  const char* __restrict__ m8 = reinterpret_cast<const char*>(B.ter.m8);
+  const char* __restrict__ mb = reinterpret_cast<const char*>(B.ter.mb);
+  const char* __restrict__ m16 = reinterpret_cast<const char*>(B.ter.m);
+  // point p of the workgroup = arena la, scan point pt; a lane's next point is p + 256 = one arena + 116 points on
+  int la = t >= OIS_HEIGHT_POINTS ? 1 : 0, pt = t - la * OIS_HEIGHT_POINTS;
+  struct Cell { unsigned px, py; };
+  auto cell = [&]() -> Cell {
+    const float4 r = rec[la & (kScanArenas - 1)];  // lanes past npts read some record: their cell is clamped, never stored
+    const float2 bb = tab[pt];
     const float qw = r.z, qz = r.w;
-    const float bx = 0.1f * (float)gx, by = 0.1f * (float)gy;
+    const float bx = bb.x, by = bb.y;
     const float tx = -(qz * by) * 2.0f, ty = (qz * bx) * 2.0f;
     const float cx = -(qz * ty), cy = qz * tx;
     float X = (bx + qw * tx) + cx, Y = (by + qw * ty) + cy;
     X += r.x; Y += r.y;                       // :878
-    X += B.ter.border; Y += B.ter.border;     // :882
-    float fx = X / B.ter.hs, fy = Y / B.ter.hs;  // :883
-    fx = fminf(fmaxf(fx, 0.0f), (float)(B.ter.rows - 2));  // :886-887
-    fy = fminf(fmaxf(fy, 0.0f), (float)(B.ter.cols - 2));
-    o[p] = terrain_cell_height(B.ter, (int)fx, (int)fy);  // :889-893, the min of the two samples is in the min-field
+    X += border; Y += border;                 // :882
+    float fx = X / hs, fy = Y / hs;           // :883
+    fx = fminf(fmaxf(fx, 0.0f), xmax);        // :886-887
+    fy = fminf(fmaxf(fy, 0.0f), ymax);
+    pt += 256 - OIS_HEIGHT_POINTS; la += 1;
+    if (pt >= OIS_HEIGHT_POINTS) { pt -= OIS_HEIGHT_POINTS; la += 1; }
+    return {(unsigned)(int)fx, (unsigned)(int)fy};
+  };
+  // :889-893: the minimum of the two samples is in the min-field; 8-bit tile + base, the 16-bit field for a wide tile
+  // (32-bit byte offsets: ois_terrain_attach refuses a field of 2^31 bytes)
+  auto tile_of = [&](Cell c) -> unsigned { return (c.px >> 4) * tpr + (c.py >> 3); };
+  auto load_base = [&](Cell c) -> int { return *reinterpret_cast<const int16_t*>(mb + (base_index(c.px >> 4, c.py >> 3, tpr) << 1)); };
+  auto load_off = [&](unsigned tl, Cell c) -> int {
+    return *reinterpret_cast<const uint8_t*>(m8 + ((tl << 7) + (((c.px & 15u) << 3) | (c.py & 7u))));
+  };
+  auto finish = [&](Cell c, int base, int off) -> float {
+    int hq = base + off;
+    if (__builtin_expect(base == kWideTile, 0))
+      hq = *reinterpret_cast<const int16_t*>(m16 + ((((c.px >> 3) * tpr + (c.py >> 3)) << 7) + (((c.px & 7u) << 4) | ((c.py & 7u) << 1))));
+    return (float)hq * vs;
+  };
+  int p = t;
+  const int chunks = npts / (256 * kScanUnroll);  // whole chunks: every lane has a point in each of the rows
+  for (int c = 0; c < chunks; ++c, p += 256 * kScanUnroll) {
+    Cell ce[kScanUnroll];
+    int base[kScanUnroll], off[kScanUnroll];
+#pragma unroll
+    for (int u = 0; u < kScanUnroll; ++u) ce[u] = cell();
+#pragma unroll
+    for (int u = 0; u < kScanUnroll; ++u) { const unsigned tl = tile_of(ce[u]); base[u] = load_base(ce[u]); off[u] = load_off(tl, ce[u]); }
+#pragma unroll
+    for (int u = 0; u < kScanUnroll; ++u) __builtin_nontemporal_store(finish(ce[u], base[u], off[u]), o + p + 256 * u);
+  }
+  for (; p < npts; p += 256) {
+    const Cell c1 = cell();
+    const unsigned tl = tile_of(c1);
+    __builtin_nontemporal_store(finish(c1, load_base(c1), load_off(tl, c1)), o + p);
   }
 }
 
 // m[x][y] = min(h[x][y], h[x+1][y+1]) (last row / column: h itself; never read, see ois.h)
+OIS_DEV int16_t minfield_value(const int16_t* __restrict__ h, int x, int y, int rows, int cols) {
+  const int16_t a = h[(size_t)x * cols + y];
+  int16_t b = a;
+  if (x + 1 < rows && y + 1 < cols) b = h[(size_t)(x + 1) * cols + y + 1];
+  return a < b ? a : b;
+}
 __global__ __launch_bounds__(256) void minfield_kernel(const int16_t* __restrict__ h, int16_t* __restrict__ m, int rows, int cols) {
   const size_t t = (size_t)blockIdx.x * 256 + threadIdx.x;
   if (t >= (size_t)rows * cols) return;
   const int x = (int)(t / cols), y = (int)(t % cols);
-  const int16_t a = h[t];
-  int16_t b = a;
-  if (x + 1 < rows && y + 1 < cols) b = h[t + cols + 1];
   const size_t o = ((size_t)((x >> 3) * ((cols + 7) >> 3) + (y >> 3)) << 6) + (size_t)(((x & 7) << 3) | (y & 7));  // 8 x 8 tiles
-  m[o] = a < b ? a : b;
+  m[o] = minfield_value(h, x, y, rows, cols);
+}
+// the same field for the height scan: tiles of 16 x 8 cells as 8-bit offsets from the tile's minimum (one 128-byte
+// line holds twice the cells: the scan is bound by the lines it pulls through L2). A tile whose
+// heights span more than 254 units gets the base kWideTile and is read from the 16-bit field. One thread per tile.
+__global__ __launch_bounds__(64) void minfield8_kernel(const int16_t* __restrict__ h, uint8_t* __restrict__ m8, int16_t* __restrict__ mb,
+                                                        int rows, int cols) {
+  const int tpr = (cols + 7) >> 3, ntiles = ((rows + 15) >> 4) * tpr;
+  const int tl = blockIdx.x * 64 + threadIdx.x;
+  if (tl >= ntiles) return;
+  const int x0 = (tl / tpr) << 4, y0 = (tl % tpr) << 3;
+  int lo = 32767, hi = -32768;
+  for (int i = 0; i < 128; ++i) {
+    const int x = x0 + (i >> 3), y = y0 + (i & 7);
+    if (x < rows && y < cols) { const int v = minfield_value(h, x, y, rows, cols); lo = v < lo ? v : lo; hi = v > hi ? v : hi; }
+  }
+  const bool wide = hi - lo > 254 || lo == kWideTile;
+  mb[base_index(tl / tpr, tl % tpr, tpr)] = (int16_t)(wide ? kWideTile : lo);
+  for (int i = 0; i < 128; ++i) {
+    const int x = x0 + (i >> 3), y = y0 + (i & 7);
+    const int v = (!wide && x < rows && y < cols) ? minfield_value(h, x, y, rows, cols) - lo : 0;
+    m8[((size_t)tl << 7) + i] = (uint8_t)v;
+  }
 }
 
 // ------------------------------------------------------------------ post_reset --------
@@ -960,6 +1035,17 @@ static void pick_lpa(ois_env* e) {
 }
 
 namespace {
+// scratch of ois_terrain_attach: the 16-bit min-field in 8 x 8 tiles | the 8-bit one in 16 x 8 tiles | its tile bases
+size_t minfield_layout(int rows, int cols, size_t off[3]) {
+  const size_t tpr = (size_t)((cols + 7) >> 3);
+  const size_t t8 = (size_t)((rows + 7) >> 3) * tpr, t16 = (size_t)((rows + 15) >> 4) * tpr;
+  off[0] = 0;
+  off[1] = align256(t8 * 128);
+  off[2] = off[1] + align256(t16 * 128);
+  // the bases in blocks of 8 x 8 tiles (one line): the tiles under one robot's scan are 1-4 blocks
+  const size_t blocks = (size_t)((((rows + 15) >> 4) + 7) >> 3) * ((tpr + 7) >> 3);
+  return off[2] + align256(blocks * 64 * sizeof(int16_t));
+}
 size_t replay_layout(int N, int M, size_t off[OIS_RP_COUNT_], size_t bytes[OIS_RP_COUNT_]) {
   const size_t rows = (size_t)M * (size_t)N;
   const size_t sz[OIS_RP_COUNT_] = {rows * 6 * sizeof(float), rows * 4 * sizeof(float), rows * sizeof(float),
@@ -1308,6 +1394,9 @@ int ois_terrain_attach(ois_env* e, const ois_terrain* t, const int16_t* heights_
       !levels_types_host)
     return fail(OIS_EINVAL, "bad terrain description");
   if (e->lpa_forced == 2) return fail(OIS_EINVAL, "the terrain contact needs one lane per arena (unset OIS_LANES_PER_ARENA)");
+  size_t mf[3];
+  if (minfield_layout(t->rows, t->cols, mf) >= ((size_t)1 << 31)) return fail(OIS_EINVAL, "height field too large (the kernels address it with 32-bit byte offsets)");
+  if (((uintptr_t)minfield_device & 255u) != 0) return fail(OIS_EINVAL, "the min-field scratch must be 256-byte aligned");
   // per-arena origin = terrain_origins[level, type] (KAMMA.py:397): built on the host from the
   // caller's table, so the table is read back once
   const size_t no = (size_t)t->num_levels * t->num_types * 3;
@@ -1329,10 +1418,16 @@ int ois_terrain_attach(ois_env* e, const ois_terrain* t, const int16_t* heights_
     e->B.ter.tiles_per_row = (t->cols + 7) >> 3;
     hipLaunchKernelGGL(minfield_kernel, dim3((unsigned)((cells + 255) / 256)), dim3(256), 0, s, heights_device, minfield_device,
                        t->rows, t->cols);
+    const unsigned ntiles = (unsigned)(((t->rows + 15) >> 4) * ((t->cols + 7) >> 3));
+    hipLaunchKernelGGL(minfield8_kernel, dim3((ntiles + 63) / 64), dim3(64), 0, s, heights_device,
+                       reinterpret_cast<uint8_t*>(minfield_device) + mf[1], reinterpret_cast<int16_t*>(reinterpret_cast<char*>(minfield_device) + mf[2]),
+                       t->rows, t->cols);
     HIP_TRY(hipGetLastError());
   }
   DevTerrain& T = e->B.ter;
   T.h = heights_device; T.m = minfield_device; T.origins = terrain_origins_device;
+  T.m8 = reinterpret_cast<const uint8_t*>(minfield_device) + mf[1];
+  T.mb = reinterpret_cast<const int16_t*>(reinterpret_cast<const char*>(minfield_device) + mf[2]);
   T.rows = t->rows; T.cols = t->cols; T.ntypes = t->num_types; T.max_level = t->max_level;
   T.curriculum = t->curriculum; T.on = 1;
   T.hs = t->horizontal_scale; T.inv_hs = 1.0f / t->horizontal_scale; T.vs = t->vertical_scale; T.border = t->border_size;
@@ -1492,7 +1587,8 @@ int ois_replay_sample(ois_env* e, const int64_t* indexes_device, int count, floa
 
 size_t ois_minfield_bytes(int rows, int cols) {
   if (rows < 1 || cols < 1) return 0;
-  return (size_t)((rows + 7) >> 3) * (size_t)((cols + 7) >> 3) * 64 * sizeof(int16_t);
+  size_t off[3];
+  return minfield_layout(rows, cols, off);
 }
 
 size_t ois_state_bytes(const ois_env* e) { return e ? sizeof(StateHeader) + e->L.total : 0; }

@@ -300,6 +300,45 @@ def test_height_scan_kernel_matches_fixture_through_the_env():
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("amplitude", [20, 300, 30000], ids=["narrow", "mixed", "wide"])
+def test_height_scan_tile_formats(amplitude):
+    """The scan reads the min-field as 8-bit offsets from a per-tile base and falls back to the 16-bit field
+    for a tile that spans more than 254 units: random fields whose tiles are all narrow, partly wide, all wide
+    (plus a block of -32768, the base value that marks a wide tile), odd sizes, robots all over the field -
+    against the oracle's two-sample minimum, bit for bit; the wheel contact reads the 16-bit field: a few steps."""
+    from options_in_simulation_amd.vecenv import NativeEnv
+    rng = np.random.default_rng(amplitude)
+    rows, cols, n = 1237, 1011, 3000
+    coarse = rng.integers(-amplitude, amplitude, (rows // 9 + 1, cols // 9 + 1))
+    f = np.repeat(np.repeat(coarse, 9, 0), 9, 1)[:rows, :cols] + rng.integers(-8, 8, (rows, cols))
+    f = np.clip(f, -32768, 32767).astype(np.int16)
+    f[400:420, 300:330] = -32768
+    cfg = build_config(variant="KAMMA_medium", num_envs=n, seed=3)
+    dev, orc = NativeEnv(cfg, "cuda:0"), OracleEnv(cfg)
+
+    class T:
+        heightsamples = f
+        env_origins = np.array([[[10.0, 8.0, 0.0]]], np.float32)
+        horizontal_scale, vertical_scale, border_size = 0.02, 0.0005, 2.0
+        cfg = {"curriculum": False}
+    lt = np.zeros((n, 2), np.int32)
+    dev.attach_terrain(T, lt); orc.attach_terrain(T, lt)
+    dev.reset(3); orc.reset(3)
+    pose = orc.buffer(_abi.BUF_POSE)
+    pose[:, 0] = rng.uniform(-13.0, 13.5, n)  # beyond both edges of the 24.7 m x 20.2 m field: the clamp
+    pose[:, 1] = rng.uniform(-11.0, 11.5, n)
+    dev.buffer(_abi.BUF_POSE).copy_(torch.from_numpy(pose))
+    got, ref = dev.height_scan().cpu().numpy(), orc.height_scan()
+    assert np.array_equal(got, ref)
+    assert len(np.unique(ref)) > 40
+    a = rng.uniform(0, 1, (n, 4)).astype(np.float32)
+    for _ in range(3):
+        dev.step(torch.from_numpy(a).cuda()); orc.step(a)
+    same_state(dev, orc, "steps on the random field")
+    assert np.array_equal(dev.height_scan().cpu().numpy(), orc.height_scan())
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("env_vars", [{"OIS_PACKED": "0"}, {"OIS_PACKED": "1"}], ids=["scalar", "packed"])
 def test_terrain_step_parity(env_vars, monkeypatch):
     from options_in_simulation_amd.vecenv import NativeEnv

@@ -10,7 +10,10 @@ N = int(sys.argv[1]) if len(sys.argv) > 1 else 65536
 reps = int(sys.argv[2]) if len(sys.argv) > 2 else 20
 T = tg.Terrain({"numLevels": 6, "numTerrains": 2, "mapLength": 10.0, "mapWidth": 10.0}, N, seed=0)
 env = NativeEnv(build_config(variant="KAMMA_eval", num_envs=N, seed=1), "cuda:0")
-env.attach_terrain(T, T.sample_levels_types(N, rng=np.random.RandomState(0)))
+lt = T.sample_levels_types(N, rng=np.random.RandomState(0))
+if "--one-tile" in sys.argv:  # every robot on the same tile: the field the scans touch fits each L2
+    lt[:] = 0
+env.attach_terrain(T, lt)
 env.reset(1)
 env.rollout(60, _abi.POLICY_RANDOM)
 scan = torch.empty((N, 140), device="cuda")
