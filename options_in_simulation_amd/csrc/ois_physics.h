@@ -77,8 +77,10 @@ OIS_DEV float terrain_cell_height(const DevTerrain& T, int px, int py) {
   // tiles of 8 x 8 cells = 128 B (one cache line): the 140 scan points of a robot are 5 cells apart and rotated
   // by its yaw, so in a row-major field nearly every point is on a line of its own whatever the heading; a
   // tile holds 2-3 of them (height scan at 65 536 arenas 53.9 -> 41.8 us, tools/height_scan_probe.py)
-  const size_t idx = ((size_t)((px >> 3) * T.tiles_per_row + (py >> 3)) << 6) + (size_t)(((px & 7) << 3) | (py & 7));
-  return (float)T.m[idx] * T.vs;
+  // 32-bit byte offset (ois_terrain_attach refuses a field of 2^31 bytes): the gather takes the base from SGPRs
+  const unsigned ux = (unsigned)px, uy = (unsigned)py;
+  const unsigned off = (((ux >> 3) * (unsigned)T.tiles_per_row + (uy >> 3)) << 7) + (((ux & 7u) << 4) | ((uy & 7u) << 1));
+  return (float)*reinterpret_cast<const int16_t*>(reinterpret_cast<const char*>(T.m) + off) * T.vs;
 }
 // footprints of the 4 wheels at the current pose: world xy under the wheel centres and the field
 // height there (4 gathers of the min-field, issued here, consumed one substep later). A wheel moves at most ~2 cm

@@ -8,14 +8,9 @@ R=${1:-r2}
 OUT=$PWD/gpurun_out
 mkdir -p $OUT
 export TMPDIR=/tmp
-python bench.py > $OUT/${R}_bench.json 2> $OUT/${R}_bench.err
-echo "bench done" && tail -c 300 $OUT/${R}_bench.json
-python bench.py --no-actor --no-cpu-baseline --steps 400 --warmup 40 > $OUT/${R}_bench_envonly.json 2>> $OUT/${R}_bench.err
 P=/tmp/ois_prof_$$
 rm -rf $P && mkdir -p $P
-(cd /tmp && rocprofv3 --kernel-trace --stats --output-format csv -d $P/kt -- python3 $OLDPWD/bench.py --steps 100 --warmup 10 --no-cpu-baseline --no-extras > $OUT/${R}_bench_under_rocprof.json 2> $P/kt.err) || { tail -5 $P/kt.err; exit 1; }
-cp $(find $P/kt -name '*kernel_stats.csv' | head -1) $OUT/${R}_bench_kernel_stats.csv
-echo "kernel trace done"
+# the traffic counters first: bench.py quotes `traffic` from profiles/${R}_pmc_traffic.json when its source hash is this checkout's
 for C in FETCH_SIZE WRITE_SIZE; do
   (cd /tmp && rocprofv3 --pmc $C --kernel-trace --output-format csv -d $P/$C -- python3 $OLDPWD/bench.py --steps 60 --warmup 10 --no-actor --no-cpu-baseline --no-extras > /dev/null 2> $P/$C.err) || { tail -5 $P/$C.err; exit 1; }
   cp $(find $P/$C -name '*counter_collection.csv' | head -1) $P/$C.csv
@@ -51,6 +46,13 @@ out = {"FETCH_SIZE_KB_per_launch_mean": fm, "FETCH_SIZE_launches": len(f), "WRIT
 json.dump(out, open(f"{OUT}/{R}_pmc_traffic.json", "w"), indent=1)
 print(json.dumps(out))
 PY
+cp $OUT/${R}_pmc_traffic.json profiles/${R}_pmc_traffic.json
+python bench.py > $OUT/${R}_bench.json 2> $OUT/${R}_bench.err
+echo "bench done" && tail -c 300 $OUT/${R}_bench.json
+python bench.py --no-actor --no-cpu-baseline --steps 400 --warmup 40 > $OUT/${R}_bench_envonly.json 2>> $OUT/${R}_bench.err
+(cd /tmp && rocprofv3 --kernel-trace --stats --output-format csv -d $P/kt -- python3 $OLDPWD/bench.py --steps 100 --warmup 10 --no-cpu-baseline --no-extras > $OUT/${R}_bench_under_rocprof.json 2> $P/kt.err) || { tail -5 $P/kt.err; exit 1; }
+cp $(find $P/kt -name '*kernel_stats.csv' | head -1) $OUT/${R}_bench_kernel_stats.csv
+echo "kernel trace done"
 grep step_kernel $OUT/${R}_bench_kernel_stats.csv | cut -c1-200
 # the multi-process path on this 1-GPU box: two gloo ranks sharing the card, launched by bench.py itself
 OIS_DIST_BACKEND=gloo python bench.py --gpus 2 --steps 120 --warmup 10 > $OUT/${R}_bench_gloo2.json 2>> $OUT/${R}_bench.err
