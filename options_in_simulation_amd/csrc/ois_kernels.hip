@@ -144,6 +144,10 @@ OIS_DEV void step_body(const DevConsts& K, const DevBuffers& B, const float* __r
   policy &= 0xff;
   float rsum = (rsum_continue && reward_sum != nullptr) ? reward_sum[la] : 0.0f;
   bool cmd_dirty = false;
+  // KAMMA_eval.py:470: a reset_idx call zeroes old_torques of EVERY arena. Did any arena reset in the step before
+  // this launch? (the stamp slot of this parity was written by that step or by an older one; launches of the
+  // eval variants are single steps, launch_steps())
+  const bool old_zeroed = K.eval_sums && B.reset_stamp[S.sim_steps & 1] == S.sim_steps;
   // terrain tile of this arena (origin xyz; level / type for the curriculum)
   float tor[3] = {0.0f, 0.0f, 0.0f};
   int tlevel = 0, ttype = 0;
@@ -229,7 +233,7 @@ OIS_DEV void step_body(const DevConsts& K, const DevBuffers& B, const float* __r
       float e2[W];
 #pragma unroll
       for (int k = 0; k < W; ++k) {
-        const float old = S.sc[3] != 0.0f ? S.wt[k] : 0.0f;
+        const float old = (S.sc[3] != 0.0f && !(s == 0 && old_zeroed)) ? S.wt[k] : 0.0f;
         const float df = old - wt[k];
         e2[k] = df * df;
       }
@@ -412,7 +416,9 @@ OIS_DEV void step_body(const DevConsts& K, const DevBuffers& B, const float* __r
     if (m != 0ull) {
       group_record<LPA>(B, arena / kGroup, lane, group_any<LPA>(m, lane), rc, S.sim_steps, true);
       // any reset_idx call re-snapshots `fraction` of every arena (KAMMA.py:498): tell level_command_kernel
-      if (K.cmd_sampler == OIS_CMD_LEVEL && lane == 0) *B.reset_stamp = S.sim_steps;
+      // and zeroes old_torques of every arena (KAMMA_eval.py:470): tell the next step. Two slots by the parity of
+      // the step count: a wave of the NEXT parity's launch never reads the slot this launch writes
+      if ((K.cmd_sampler == OIS_CMD_LEVEL || K.eval_sums) && lane == 0) B.reset_stamp[S.sim_steps & 1] = S.sim_steps;
     }
   }
   if (valid) {
@@ -639,7 +645,7 @@ __global__ __launch_bounds__(kBlock) void reset_kernel(DevConsts K, DevBuffers B
   }
   if (arena < OIS_ENV0_DIAG_LEN) { B.env0_diag[arena] = 0.0f; B.episode_info[arena] = 0.0f; }
   if (valid) B.cmd_fraction[arena] = 0.0f;  // KAMMA.py:498 at post_reset: the sums are zero
-  if (arena == 0) *B.reset_stamp = -1;
+  if (arena == 0) { B.reset_stamp[0] = -1; B.reset_stamp[1] = -1; }
 }
 
 // Tail of post_physics_step with terrain.curriculum (KAMMA.py:719-725): the command of EVERY arena is
@@ -651,7 +657,7 @@ __global__ __launch_bounds__(256) void level_command_kernel(DevConsts K, DevBuff
   if (i >= N) return;
   const int sim = B.counters[i].y;  // == episode_step_counter: policy steps since post_reset
   float fr = B.cmd_fraction[i];
-  if (*B.reset_stamp == sim) {
+  if (B.reset_stamp[sim & 1] == sim) {
     fr = B.sums_a[i].x / K.cmd_thr_high;
     B.cmd_fraction[i] = fr;
   }
@@ -907,7 +913,7 @@ Layout make_layout(int N) {
   L.red_cmax = o; o = align256(o + (size_t)L.nchunks * sizeof(int));
   L.red_lvl = o; o = align256(o + (size_t)L.nchunks * sizeof(long long));
   L.red_part8 = o; o = align256(o + (size_t)L.nchunks * 8 * sizeof(double));
-  L.reset_stamp = o; o = align256(o + sizeof(int32_t));
+  L.reset_stamp = o; o = align256(o + 2 * sizeof(int32_t));
   L.total = o;
   return L;
 }
@@ -1316,16 +1322,21 @@ static int launch_kernel(ois_env* e, int k, int policy, const float* actions, fl
 }
 
 static int launch_steps(ois_env* e, int k, int policy, const float* actions, float* reward_sum, void* stream) {
-  if (e->K.cmd_sampler != OIS_CMD_LEVEL) return launch_kernel(e, k, policy, actions, reward_sum, stream);
+  const bool level = e->K.cmd_sampler == OIS_CMD_LEVEL;
+  if (!level && !(e->K.eval_sums && k > 1)) return launch_kernel(e, k, policy, actions, reward_sum, stream);
   // per-level command curriculum: the commands of all arenas are re-drawn between two policy steps
   // from a quantity that depends on every arena of the step before (level_command_kernel), so a
-  // rollout is k launches of one step, each followed by the command launch
+  // rollout is k launches of one step, each followed by the command launch. The eval variants' Smoothness
+  // sum has the same kind of dependence (old_torques of all arenas zeroed by any reset, KAMMA_eval.py:470):
+  // k launches of one step
   for (int s = 0; s < k; ++s) {
     const float* a = (policy == OIS_POLICY_EXTERNAL) ? actions + (size_t)s * e->N * e->K.action_dim : actions;
     int rc = launch_kernel(e, 1, policy | (s > 0 ? 0x100 : 0), a, reward_sum, stream);
     if (rc != OIS_OK) return rc;
-    hipLaunchKernelGGL(level_command_kernel, dim3((e->N + 255) / 256), dim3(256), 0, (hipStream_t)stream, e->K, e->B, e->N);
-    HIP_TRY(hipGetLastError());
+    if (level) {
+      hipLaunchKernelGGL(level_command_kernel, dim3((e->N + 255) / 256), dim3(256), 0, (hipStream_t)stream, e->K, e->B, e->N);
+      HIP_TRY(hipGetLastError());
+    }
   }
   return OIS_OK;
 }

@@ -774,6 +774,7 @@ struct orc_env {
   int N, G;
   int threads;
   int reset_done;
+  int old_torques_zeroed; /* KAMMA_eval.py:470: the last step's reset_idx zeroed old_torques of EVERY arena */
   uint64_t seed;
   double steps_done;
   /* buffers, same ids/shapes as the product */
@@ -949,7 +950,7 @@ static void reset_arena(orc_env* e, int i, uint32_t step_ctr, float gamma2, rese
   /* :485 zero the sums of the reset arena */
   for (int k = 0; k < 4; ++k) { sa[k] = 0.0f; sb[k] = 0.0f; }
   sc[0] = sc[1] = sc[2] = 0.0f;
-  sc[3] = 0.0f; /* old_torques scratch (KAMMA_eval.py:470) — per-arena here, see SPEC */
+  sc[3] = 0.0f; /* old_torques of this arena are zero (KAMMA_eval.py:470; the other arenas': step_all) */
 
   float u[8];
   int64_t gid = c->arena_offset + i;
@@ -1102,12 +1103,28 @@ int orc_reset(orc_env* e, uint64_t seed) {
   for (int i = 0; i < N; ++i) reset_arena(e, i, 0u, g2, &rc[i]);
   for (int g = 0; g < e->G; ++g) group_reduce(e, g, rs, rc, 0, g1, g2, 0);
   free(rc); free(rs);
+  e->old_torques_zeroed = 1;
   e->reset_done = 1;
   return OIS_OK;
 }
 
 /* one policy step of arena i: pre_physics_step + substeps + post_physics_step.
  * Returns reward. rs/rc: reset flag and contribution (for the group reduction). */
+/* KAMMA_eval.py:677-683 (pre_physics_step): Smoothness += sum((old_torques - wheel_torqs)^2) / 10, Desired velocity +=
+ * desired_v / 10; :840 (calculate_metrics): Tracking error += |v_delta| / 10 (skipped when v_delta == NULL).
+ * sums_c4 = [Smoothness, Tracking error, Desired velocity, -] per arena. The wheel sum in the SPEC order. */
+void orc_eval_sums(int n, const float* old4, const float* wt4, const float* desired_v, const float* v_delta, float* sums_c4) {
+  for (int i = 0; i < n; ++i) {
+    const float* o = &old4[4 * i];
+    const float* w = &wt4[4 * i];
+    float* sc = &sums_c4[4 * i];
+    float d0 = o[0] - w[0], d1 = o[1] - w[1], d2 = o[2] - w[2], d3 = o[3] - w[3];
+    sc[0] += ((d0 * d0 + d1 * d1) + (d2 * d2 + d3 * d3)) / 10.0f;
+    sc[2] += desired_v[i] / 10.0f;
+    if (v_delta) sc[1] += fabsf(v_delta[i]) / 10.0f;
+  }
+}
+
 static float step_arena(orc_env* e, int i, const float* act /*[A]*/, uint8_t* rs, reset_contrib* rc, float* g1_out, float* g2_out) {
   const ois_config* c = &e->cfg;
   const derived* D = &e->D;
@@ -1148,17 +1165,15 @@ static float step_arena(orc_env* e, int i, const float* act /*[A]*/, uint8_t* rs
   mix1(c->mix_mode, c->guiding_mode, a4, ac_left, ac_right, gamma1, rnd, c->action_scale, c->torque_clip,
        torques, wt, &guiding);
   if (c->eval_sums) {
-    /* KAMMA_eval.py:677-685. old_torques = the previous step's clipped torques, which
-     * still sit in the wheel_torqs buffer; sums_c[3] != 0 marks them valid (the reference
-     * zeroes old_torques in reset_idx, KAMMA_eval.py:470 — for ALL arenas at once, which
-     * only ever ran with numEnvs = 1; here the zeroing is per arena, docs/SPEC.md §2.9) */
+    /* KAMMA_eval.py:677-685. old_torques = the previous step's clipped torques, which still sit in the
+     * wheel_torqs buffer — or zeros when a reset_idx call came in between: it zeroes old_torques of ALL
+     * arenas (KAMMA_eval.py:470), whichever arena reset (sums_c[3] == 0: before this arena's first step) */
     const float* old = &e->wheel_torqs[4 * i];
-    float o0 = sc[3] != 0.0f ? old[0] : 0.0f, o1 = sc[3] != 0.0f ? old[1] : 0.0f;
-    float o2 = sc[3] != 0.0f ? old[2] : 0.0f, o3 = sc[3] != 0.0f ? old[3] : 0.0f;
-    float d0 = o0 - wt[0], d1 = o1 - wt[1], d2 = o2 - wt[2], d3 = o3 - wt[3];
-    sc[0] += ((d0 * d0 + d1 * d1) + (d2 * d2 + d3 * d3)) / 10.0f;
-    sc[2] += desired_v / 10.0f;
-    sc[3] = 1.0f; /* old_torques valid */
+    float o4[4];
+    const int zeroed = sc[3] == 0.0f || e->old_torques_zeroed;
+    for (int k = 0; k < 4; ++k) o4[k] = zeroed ? 0.0f : old[k];
+    orc_eval_sums(1, o4, wt, &desired_v, NULL, sc);
+    sc[3] = 1.0f; /* this arena has stepped since its reset */
   }
   for (int k = 0; k < 4; ++k) e->wheel_torqs[4 * i + k] = wt[k];
 
@@ -1301,6 +1316,11 @@ static int step_all(orc_env* e, int policy, const float* actions, float* reward_
       orc_level_command(level, e->cmd_fraction[i], stamp, normal_det(u[0], u[1]), (double)e->cfg.decimation * (double)e->cfg.sim_dt,
                         (double)e->cfg.episode_length_s, &e->commands[4 * i], &e->commands[4 * i + 2]);
     }
+  }
+  if (e->cfg.eval_sums) { /* KAMMA_eval.py:470: a reset_idx call zeroes old_torques of all arenas */
+    int any = 0;
+    for (int i = 0; i < N; ++i) any |= rs[i];
+    e->old_torques_zeroed = any;
   }
   e->steps_done += (double)N;
   if (e->rp_size > 0) {

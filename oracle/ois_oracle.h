@@ -103,6 +103,8 @@ void orc_metrics(int n, const float* v_fwd_prev, const float* omega_z, float* pr
                  float w3, float sparse_bonus, float sparse_thr, float terminal_reward,
                  float* lin_acc, float* ang_acc, float* rew, float* sums8);
 /* a11: forward-velocity projection, KAMMA.py:701-710 */
+void orc_eval_sums(int n, const float* old4, const float* wt4, const float* desired_v, const float* v_delta,
+                   float* sums_c4); /* KAMMA_eval.py:677-683, :840 */
 void orc_forward_projection(int n, const float* quat4, const float* linvel3, float* v_fwd);
 /* quat helpers as used by the reference (omni.isaac.core.utils.torch.rotations, wxyz) */
 void orc_quat_apply(const float q[4], const float v[3], float out[3]);

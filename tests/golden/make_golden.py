@@ -360,6 +360,51 @@ def refmath_curriculum(seed=6, n=384):
 
 
 # ----------------------------------------------------------------------------------------
+def evalsums_sequence(wheel_torqs, desired_v, v_delta, reset):
+    """KAMMA_eval.py bookkeeping of its three extra episode sums over T steps of N arenas (also in KA_DDPG_1D/2D_eval):
+    pre_physics_step :677-685 (Smoothness against old_torques, Desired velocity, then old_torques = the step's clipped
+    torques), calculate_metrics :840 (Tracking error), reset_idx :470 (old_torques = zeros for ALL arenas, whichever
+    arenas reset), :480-485 (rew_<key> = mean over the resetting arenas / max_episode_length_s, their sums zeroed).
+    Inputs are [T, N(, 4)] tensors; returns the sums after every step [T, N, 3] (Smoothness, Tracking error, Desired
+    velocity), old_torques after every step, and the extras means (NaN where no arena reset)."""
+    T, n = desired_v.shape
+    zeros = lambda: torch.zeros(n, dtype=F)  # noqa: E731
+    sums = {"Smoothness": zeros(), "Tracking error": zeros(), "Desired velocity": zeros()}
+    old_torques = torch.zeros(n, 4, dtype=F)                                      # :205
+    max_episode_length_s = 10.0
+    out_sums, out_old, out_rew = [], [], []
+    for t in range(T):
+        wt = wheel_torqs[t]
+        diff = old_torques - wt                                                   # :677
+        sums["Smoothness"] += torch.sum(diff ** 2, dim=1) / 10.0                  # :681
+        sums["Desired velocity"] += desired_v[t] / 10.0                           # :683
+        old_torques = wt.clone()                                                  # :685
+        sums["Tracking error"] += torch.abs(v_delta[t]) / 10.0                    # :840
+        env_ids = reset[t].nonzero(as_tuple=False).flatten()
+        rew = torch.full((3,), float("nan"), dtype=F)
+        if len(env_ids) > 0:                                                      # post_physics_step :691-693
+            old_torques = torch.zeros(n, 4, dtype=F)                              # :470 (every arena)
+            for k, key in enumerate(("Smoothness", "Tracking error", "Desired velocity")):
+                rew[k] = torch.mean(sums[key][env_ids]) / max_episode_length_s    # :482-484
+                sums[key][env_ids] = 0.0                                          # :485
+        out_sums.append(torch.stack([sums["Smoothness"], sums["Tracking error"], sums["Desired velocity"]], 1).clone())
+        out_old.append(old_torques.clone())
+        out_rew.append(rew)
+    return torch.stack(out_sums), torch.stack(out_old), torch.stack(out_rew)
+
+
+def refmath_evalsums(seed=7, n=9, T=48):
+    g = torch.Generator().manual_seed(seed)
+    r = lambda *s, lo=-1.0, hi=1.0: (hi - lo) * torch.rand(*s, generator=g, dtype=F) + lo  # noqa: E731
+    wheel_torqs = torch.clip(r(T, n, 4, lo=-5.0, hi=5.0), -4.0, 4.0)
+    desired_v, v_delta = r(T, n, lo=0.0, hi=2.0), r(T, n, lo=-0.8, hi=0.8)
+    reset = torch.zeros(T, n, dtype=torch.bool)
+    reset[5, 2] = True; reset[6, 2] = True; reset[17, [0, 4, 8]] = True; reset[30] = True; reset[31, 7] = True; reset[44, 3] = True
+    sums, old, rew = evalsums_sequence(wheel_torqs, desired_v, v_delta, reset)
+    return {"wheel_torqs": wheel_torqs.numpy(), "desired_v": desired_v.numpy(), "v_delta": v_delta.numpy(),
+            "reset": reset.numpy().astype(np.uint8), "sums": sums.numpy(), "old_torques": old.numpy(), "rew": rew.numpy()}
+
+
 def trajectories():
     from oracle.binding import OracleEnv
     from tests.golden_replay import TRAJ_SPECS, run_spec
@@ -370,6 +415,7 @@ def main():
     np.savez_compressed(os.path.join(HERE, "refmath_gae.npz"), **refmath_gae())
     np.savez_compressed(os.path.join(HERE, "refmath_heights.npz"), **refmath_heights())
     np.savez_compressed(os.path.join(HERE, "refmath_curriculum.npz"), **refmath_curriculum())
+    np.savez_compressed(os.path.join(HERE, "refmath_evalsums.npz"), **refmath_evalsums())
     if "--gae-only" in sys.argv or "--unit-only" in sys.argv:
         return
     np.savez_compressed(os.path.join(HERE, "refmath_step.npz"), **refmath_step())

@@ -28,7 +28,7 @@ def lanes_per_arena(request, monkeypatch):
 
 
 STATE_BUFS = [_abi.BUF_POSE, _abi.BUF_QUAT, _abi.BUF_LINVEL, _abi.BUF_ANGVEL, _abi.BUF_WHEEL_VEL,
-              _abi.BUF_COMMANDS, _abi.BUF_SUMS_A, _abi.BUF_SUMS_B, _abi.BUF_LAMBDA_N, _abi.BUF_LAMBDA_L,
+              _abi.BUF_COMMANDS, _abi.BUF_SUMS_A, _abi.BUF_SUMS_B, _abi.BUF_SUMS_C, _abi.BUF_LAMBDA_N, _abi.BUF_LAMBDA_L,
               _abi.BUF_LAMBDA_T, _abi.BUF_WHEEL_TORQS, _abi.BUF_OBS, _abi.BUF_REW]
 EXACT_BUFS = [_abi.BUF_COUNTERS, _abi.BUF_DONE, _abi.BUF_TIMEOUT]
 RTOL, ATOL = 1e-5, 1e-6
@@ -71,6 +71,40 @@ def test_step_parity_variants(variant):
         a = rng.uniform(lo, 1.0, size=(N, cfg.action_dim)).astype(np.float32)
         dev.step(torch.from_numpy(a).cuda()); orc.step(a)
         compare(dev, orc, f"{variant} step {t}", exact_float=True)
+
+
+@pytest.mark.parametrize("variant,N", [("KAMMA_eval", 300), ("KA_DDPG_2D_eval", 300), ("KAMMA_eval", 140000)],
+                         ids=["KAMMA_eval", "KA_DDPG_2D_eval", "KAMMA_eval-140000"])
+def test_eval_variants_zero_old_torques_of_every_arena_on_any_reset(variant, N):
+    """KAMMA_eval.py:470: reset_idx sets old_torques = zeros(num_envs, 4), so ONE robot falling changes the next
+    step's Smoothness of every arena. The step kernel learns it through a stamp the resetting wave leaves for the
+    next launch (two slots by step parity; a rollout of these variants is k single-step launches). Falls of single
+    arenas, two in consecutive steps, the synchronous timeout, a fused rollout; at 140 000 arenas the waves of a
+    launch run in several rounds (the stamp must not be read from the launch that writes it). Bit for bit."""
+    cfg, dev, orc = make_pair(variant=variant, num_envs=N, seed=21)
+    dev.reset(21); orc.reset(21)
+    rng = np.random.default_rng(2)
+    steps = 103 if N < 1000 else 9
+    falls = {4: 7, 5: N - 1, 40: 123} if N < 1000 else {3: N // 2, 4: 5}
+    up = np.array([0.0, 1.0, 0.0, 0.0], np.float32)
+    for t in range(steps):
+        if t in falls:
+            orc.buffer(_abi.BUF_QUAT)[falls[t]] = up
+            dev.buffer(_abi.BUF_QUAT)[falls[t]] = torch.from_numpy(up).cuda()
+        a = rng.uniform(-1, 1, size=(N, cfg.action_dim)).astype(np.float32)
+        dev.step(torch.from_numpy(a).cuda()); orc.step(a)
+        if t in falls or t - 1 in falls or t >= 97 or t == steps - 1:
+            compare(dev, orc, f"{variant} step {t}", exact_float=True)
+            if orc.done.any():
+                np.testing.assert_array_equal(dev.episode_info().cpu().numpy(), orc.episode_info())
+    acts = rng.uniform(-1, 1, size=(6, N, cfg.action_dim)).astype(np.float32)
+    orc.buffer(_abi.BUF_QUAT)[11] = up
+    dev.buffer(_abi.BUF_QUAT)[11] = torch.from_numpy(up).cuda()
+    rs = torch.zeros(N, device="cuda")
+    dev.rollout(6, _abi.POLICY_EXTERNAL, torch.from_numpy(acts).cuda(), reward_sum=rs)
+    ro = orc.rollout(6, _abi.POLICY_EXTERNAL, acts, want_reward_sum=True)
+    compare(dev, orc, f"{variant} fused rollout with a fall in its first step", exact_float=True)
+    assert np.array_equal(rs.cpu().numpy(), ro)
 
 
 def test_long_rollout_with_resets_and_extras():

@@ -184,3 +184,62 @@ def test_extras_means_follow_reference():
         np.testing.assert_allclose(ei[slot], d[f"mean_{key}_over_final"], rtol=2e-3, atol=2e-3)
     assert ei[16] == np.float32(0.375) and ei[17] == np.float32(0.375) and ei[18] == 0.0
     del before, added_a, added_b
+
+
+def test_eval_sums_follow_the_fixture(oracle_lib):
+    """KAMMA_eval.py:677-685 / :840 on the fixture's sequence: orc_eval_sums step by step, old_torques kept as the
+    reference keeps them (the step's clipped torques; zeros for EVERY arena after a step in which any arena reset)."""
+    d = np.load(os.path.join(G, "refmath_evalsums.npz"))
+    T, n = d["desired_v"].shape
+    sums = np.zeros((n, 4), np.float32)
+    old = np.zeros((n, 4), np.float32)
+    for t in range(T):
+        oracle_lib.orc_eval_sums(n, fptr(old), fptr(f32(d["wheel_torqs"][t])), fptr(f32(d["desired_v"][t])),
+                                 fptr(f32(d["v_delta"][t])), fptr(sums))
+        old = f32(d["wheel_torqs"][t]).copy()
+        ids = d["reset"][t].astype(bool)
+        if ids.any():
+            np.testing.assert_allclose(sums[ids, :3].mean(0) / 10.0, d["rew"][t], rtol=2e-6)  # :482-484
+            sums[ids] = 0.0
+            old[:] = 0.0  # :470, all arenas
+        else:
+            assert np.isnan(d["rew"][t]).all()
+        assert np.array_equal(old, d["old_torques"][t])
+        np.testing.assert_allclose(sums[:, :3], d["sums"][t], rtol=2e-6, atol=1e-6)  # torch.sum over the wheels: order
+    assert d["reset"].sum(1).max() == n and ((d["reset"].sum(1) > 0) & (d["reset"].sum(1) < n)).any()
+
+
+@pytest.mark.parametrize("variant", ["KAMMA_eval", "KA_DDPG_1D_eval"])
+def test_eval_sums_through_the_env_with_partial_resets(variant):
+    """The whole oracle env against the transcription (tests/golden/make_golden.py evalsums_sequence) on the env's own
+    per-step torques, commands and resets: a robot that falls alone zeroes old_torques of every arena (the reference's
+    reset_idx, KAMMA_eval.py:470), so the next step's Smoothness of the OTHER arenas is the square of their torques."""
+    import torch
+    from oracle.binding import OracleEnv
+    from tests.golden.make_golden import evalsums_sequence
+    n, T = 7, 130
+    cfg = build_config(variant=variant, num_envs=n, seed=5)
+    env = OracleEnv(cfg)
+    env.reset(5)
+    rng = np.random.default_rng(0)
+    wt, dv, vd, rs, sc, info = [], [], [], [], [], []
+    for t in range(T):
+        if t in (20, 21, 60):  # arena 3 falls alone (twice in a row), later arena 5
+            env.buffer(_abi.BUF_QUAT)[3 if t < 60 else 5] = np.array([0.0, 1.0, 0.0, 0.0], np.float32)
+        dv.append(env.buffer(_abi.BUF_COMMANDS)[:, 0].copy())  # desired_v is a view of commands: pre-reset value
+        env.step(rng.uniform(-1, 1, (n, cfg.action_dim)).astype(np.float32))
+        wt.append(env.buffer(_abi.BUF_WHEEL_TORQS).copy()); vd.append(env.buffer(_abi.BUF_OBS)[:, 2].copy())
+        rs.append(env.done.astype(bool).copy()); sc.append(env.buffer(_abi.BUF_SUMS_C)[:, :3].copy())
+        info.append(env.episode_info().copy() if env.done.any() else None)
+    rs = np.array(rs)
+    assert rs[20, 3] and rs[20].sum() == 1 and rs[21].sum() == 1 and rs[60, 5] and rs[60].sum() == 1 and rs[98].sum() == n - 2
+    sums, old, rew = evalsums_sequence(torch.from_numpy(np.array(wt)), torch.from_numpy(np.array(dv)),
+                                       torch.from_numpy(np.array(vd)), torch.from_numpy(rs))
+    np.testing.assert_allclose(np.array(sc), sums.numpy(), rtol=3e-6, atol=1e-6)
+    for t in range(T):
+        if info[t] is not None:
+            np.testing.assert_allclose(info[t][20:23], rew[t].numpy(), rtol=3e-6, atol=1e-7)
+    # the global zeroing is visible: at step 21 the arenas that did not reset at step 20 add sum(wt^2) / 10
+    others = [i for i in range(n) if i != 3]
+    step21 = np.array(sc)[21, others, 0] - np.array(sc)[20, others, 0]
+    np.testing.assert_allclose(step21, (np.array(wt)[21, others] ** 2).sum(1) / 10.0, rtol=1e-4)  # a difference of running sums

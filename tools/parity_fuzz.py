@@ -21,7 +21,7 @@ from oracle.binding import OracleEnv  # noqa: E402
 N = int(sys.argv[1]) if len(sys.argv) > 1 else 2048
 STEPS = int(sys.argv[2]) if len(sys.argv) > 2 else 230
 FLOATS = [_abi.BUF_POSE, _abi.BUF_QUAT, _abi.BUF_LINVEL, _abi.BUF_ANGVEL, _abi.BUF_WHEEL_VEL, _abi.BUF_COMMANDS, _abi.BUF_SUMS_A,
-          _abi.BUF_SUMS_B, _abi.BUF_LAMBDA_N, _abi.BUF_LAMBDA_L, _abi.BUF_LAMBDA_T, _abi.BUF_WHEEL_TORQS, _abi.BUF_OBS, _abi.BUF_REW]
+          _abi.BUF_SUMS_B, _abi.BUF_SUMS_C, _abi.BUF_LAMBDA_N, _abi.BUF_LAMBDA_L, _abi.BUF_LAMBDA_T, _abi.BUF_WHEEL_TORQS, _abi.BUF_OBS, _abi.BUF_REW]
 EXACT = [_abi.BUF_COUNTERS, _abi.BUF_DONE, _abi.BUF_TIMEOUT, _abi.BUF_TERRAIN_IDX, _abi.BUF_CMD_FRACTION]
 
 
