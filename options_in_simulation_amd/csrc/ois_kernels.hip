@@ -467,11 +467,14 @@ __global__ __launch_bounds__(kBlock) void step_kernel_terrain(DevConsts K, DevBu
 // ------------------------------------------------------------------ get_heights -------
 // KAMMA.py:872-893. A workgroup takes kScanArenas consecutive arenas: their per-arena part (base-link
 // position in the field's frame, the normalised yaw quaternion of quat_apply_yaw :895-899) is computed once by
-// one lane per arena and parked in LDS; then the workgroup's 140 * kScanArenas points are dealt to the lanes
-// in output order, so the rows of measured_heights are written coalesced and a wave's lanes read the
-// same one or two LDS records. (One thread per point recomputing the arena part: 154 VALU instructions
-// per point, ~24 us of issue at 65 536 arenas; here ~45.) Same float operations per point as the oracle's
-// orc_get_heights: bit-identical to tests/golden/refmath_heights.npz.
+// one lane per arena and parked in LDS beside the table of the 140 lattice points; then the workgroup's
+// 140 * kScanArenas points are dealt to the lanes in output order, so the rows of measured_heights are written
+// coalesced (non-temporal: 37 MB nobody in this kernel reads again) and a wave's lanes read the same one or two
+// LDS records. The kernel is bound by the 128-byte lines its gathers pull through L2 (neither fewer instructions
+// nor more gathers in flight moved it), so it reads the min-field in its 8-bit form: tiles of
+// 16 x 8 cells, one int16 base per tile (in blocks of 8 x 8 tiles), the 16-bit tiles for a tile marked wide.
+// Same float operations per point as the oracle's orc_get_heights and the same int16 under every point:
+// bit-identical to tests/golden/refmath_heights.npz.
 OIS_DEV unsigned base_index(unsigned trow, unsigned tcol, unsigned tpr) {  // 8 x 8-tile blocks of the base table
   return ((((trow >> 3) * ((tpr + 7u) >> 3) + (tcol >> 3)) << 6) | ((trow & 7u) << 3) | (tcol & 7u));
 }
