@@ -30,7 +30,7 @@ T = tg.Terrain({"numLevels": 6, "numTerrains": 2, "mapLength": 10.0, "mapWidth":
 lt = T.sample_levels_types(N, rng=np.random.RandomState(0))
 for packed in ("1", "0"):
     os.environ["OIS_PACKED"] = packed
-    cfg = build_config(variant="KAMMA_eval", num_envs=N, seed=1)
+    cfg = build_config(variant="KAMMA_eval", num_envs=N, seed=1, eval_sums=0)  # gamma = 0 (random torques executed); without the eval sums, whose rollouts are single-step launches
     env = NativeEnv(cfg, "cuda:0")
     env.reset(1)
     flat = timed(env)
