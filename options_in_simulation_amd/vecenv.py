@@ -351,6 +351,32 @@ class _SimConfigLike:
         self.task_config = config["task"] if "task" in config else config
 
 
+def observed_components_from_diag(d) -> Dict[str, float]:
+    """``task.observed_components`` (KAMMA.py:840-867) from the 32-float env-0 block the step kernel leaves
+    (include/ois.h OIS_BUF_ENV0_DIAG): the reference builds the percentages from ``.item()`` values, i.e. in
+    Python doubles, left to right: ``100.0 * (1 - gamma2) * comp / rew``."""
+    d = np.asarray(d, np.float64)
+    g2, rew = d[19], d[27]
+
+    def perc(x, scale):
+        with np.errstate(divide="ignore", invalid="ignore"):
+            return float(np.float64(100.0) * scale * x / rew)
+    out = {
+        "env0_desired_v": d[0], "env0_current_v": d[1], "env0_desired_omega": d[2],
+        "env0_current_omega": d[3], "env0_v_delta": d[4], "env0_omega_delta": d[5],
+        "env0_linear_acc": d[6], "env0_angular_acc": d[7], "env0_episode_count": int(d[8]),
+        "env0_torque_apl_fl": d[9], "env0_torque_apl_rl": d[10], "env0_torque_apl_fr": d[11],
+        "env0_torque_apl_rr": d[12], "env0_exp_left": d[13], "env0_exp_right": d[14],
+        "env0_policy_torque_fl": d[15], "env0_policy_torque_rl": d[16],
+        "env0_policy_torque_fr": d[17], "env0_policy_torque_rr": d[18],
+        "env0_perc_r1": perc(d[20], 1 - g2), "env0_perc_r2": perc(d[21], 1 - g2),
+        "env0_perc_r3": perc(d[22], 1 - g2), "env0_perc_dense": perc(d[23], 1 - g2),
+        "env0_perc_sparse": perc(d[24], 1 - g2), "env0_perc_observed": perc(d[25], 1 - g2),
+        "env0_perc_guiding": perc(d[26], g2),
+    }
+    return {k: (v if isinstance(v, int) else float(v)) for k, v in out.items()}
+
+
 class TorqueDistributionTask:
     """The task object trainers reach through ``env.task`` (KAMMA.py:148)."""
 
@@ -449,25 +475,7 @@ class TorqueDistributionTask:
             # a loop that also reads infos["episode"] every step gets both blocks in one copy
             combined = getattr(self.native, "_infos_read", False) and self.infos_on_host
             d = (self.native.host_logs()[1] if combined else self.native.env0_diag()).astype(np.float64)
-            g2, rew = d[19], d[27]
-
-            def perc(x, scale):
-                with np.errstate(divide="ignore", invalid="ignore"):
-                    return float(np.float64(100.0) * scale * x / rew)
-            self._diag_cache = {
-                "env0_desired_v": d[0], "env0_current_v": d[1], "env0_desired_omega": d[2],
-                "env0_current_omega": d[3], "env0_v_delta": d[4], "env0_omega_delta": d[5],
-                "env0_linear_acc": d[6], "env0_angular_acc": d[7], "env0_episode_count": int(d[8]),
-                "env0_torque_apl_fl": d[9], "env0_torque_apl_rl": d[10], "env0_torque_apl_fr": d[11],
-                "env0_torque_apl_rr": d[12], "env0_exp_left": d[13], "env0_exp_right": d[14],
-                "env0_policy_torque_fl": d[15], "env0_policy_torque_rl": d[16],
-                "env0_policy_torque_fr": d[17], "env0_policy_torque_rr": d[18],
-                "env0_perc_r1": perc(d[20], 1 - g2), "env0_perc_r2": perc(d[21], 1 - g2),
-                "env0_perc_r3": perc(d[22], 1 - g2), "env0_perc_dense": perc(d[23], 1 - g2),
-                "env0_perc_sparse": perc(d[24], 1 - g2), "env0_perc_observed": perc(d[25], 1 - g2),
-                "env0_perc_guiding": perc(d[26], g2),
-            }
-            self._diag_cache = {k: (v if isinstance(v, int) else float(v)) for k, v in self._diag_cache.items()}
+            self._diag_cache = observed_components_from_diag(d)
             self._diag_step = self.native.epoch
         return self._diag_cache
 

@@ -403,6 +403,13 @@ void orc_reset_draws(const ois_config* cfg, const float u[8], float pos3[3], flo
  * doubles in the reference and doubles here; tensor arithmetic is float32.
  * Where the reference would raise (torch.normal with std < 0: sigma < 0 at level 0 once the r1 sum
  * is below -1.11, Noise < 0 at level 2) the build evaluates mean + std * z all the same. */
+/* KAMMA_eval.py:545-550 (EvalSampling): x_vel ramps from 1 to 2 m/s with sim_steps / max_sim_steps, omega = 0 */
+float orc_eval_command(int32_t sim_steps, float ramp_steps) {
+  float progress = fminf(fmaxf((float)sim_steps / ramp_steps, 0.0f), 1.0f);
+  float xv = 1.0f + progress * (2.0f - 1.0f);
+  return xv > 0.0f ? xv : 0.0f;
+}
+
 void orc_level_command(int level, float fraction, int32_t step_counter, float z, double dt, double episode_length_s,
                        float* cmd_x, float* cmd_yaw) {
   if (level == 0) {
@@ -975,10 +982,7 @@ static void reset_arena(orc_env* e, int i, uint32_t step_ctr, float gamma2, rese
     float xv = rand_float(xmin, xmax, u[6]);
     cmd[0] = xv > 0.0f ? xv : 0.0f;
   } else if (c->cmd_sampler == OIS_CMD_EVAL) {
-    /* KAMMA_eval.py:545-550 */
-    float progress = fminf(fmaxf((float)cnt[1] / c->eval_ramp_steps, 0.0f), 1.0f);
-    float xv = 1.0f + progress * (2.0f - 1.0f);
-    cmd[0] = xv > 0.0f ? xv : 0.0f;
+    cmd[0] = orc_eval_command(cnt[1], c->eval_ramp_steps);
   } else if (c->cmd_sampler == OIS_CMD_GRID) {
     /* KAMMA_curr2.py:602-640: bimodal normal (sigma 0.05) whose two means move from the
      * centre of the range to its ends with progress; u[6] picks the side (torch.rand(1) < 0.5),

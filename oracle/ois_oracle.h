@@ -8,11 +8,19 @@
  * (options_in_simulation_amd/) never does.
  *
  * PARITY STATUS
- *   - reference-followed math (controller, gamma, mixing, clip, termination, reward,
- *     reset, observation, projections): pinned against tests/golden/refmath_*.npz, which
- *     are produced by tests/golden/make_golden.py — a torch-CPU transcription of the
- *     cited KAMMA.py lines written in this repo (the reference module itself cannot be
- *     imported: it needs Isaac Sim / gym / pxr, plain ModuleNotFoundError).
+ *   - pinned by the reference's OWN code executed here (tests/golden/refexec_*.npz, made by
+ *     tests/golden/make_golden_ref.py: the function definitions are taken out of the reference's files
+ *     by ast, compiled unchanged and run on seeded inputs; the modules cannot be imported whole — omni /
+ *     pxr / gym / skrl at module level, plain ModuleNotFoundError, SURVEY §8c — and no stand-in for an
+ *     absent library is supplied): calculate_metrics (KAMMA.py:767, KA_DDPG_4D, KAMMA_eval),
+ *     get_observations incl. the 26 env-0 diagnostics and KAMMA_g1d_g21's reward guard,
+ *     sample_velocity_command's curriculum and EvalSampling branches, PPO's compute_gae, the terrain
+ *     generator families and the Terrain class (tests/test_refexec.py).
+ *   - the rest of the reference-followed math (controller, gamma, mixing, clip, termination, reset,
+ *     projections, get_heights, the eval variants' old_torques bookkeeping): pinned against
+ *     tests/golden/refmath_*.npz, produced by tests/golden/make_golden.py — a torch-CPU transcription of
+ *     the cited KAMMA.py lines written in this repo (those functions call omni / skrl helpers or the
+ *     simulator, so they cannot be run here).
  *   - physics (PhysX 5 inside Isaac Sim 4.0.0, not in /root/reference, no golden vectors
  *     anywhere in the reference): PARITY UNPINNED. The model is defined by docs/SPEC.md §3;
  *     parity is oracle <-> HIP kernel only.
@@ -135,6 +143,7 @@ float orc_h2f(uint16_t h);
 /* the per-terrain-level command generators (KAMMA.py:533-567) and the deterministic helpers they use */
 float orc_sin(float x);
 float orc_normal(float u1, float u2);
+float orc_eval_command(int32_t sim_steps, float ramp_steps); /* KAMMA_eval.py:545-550 */
 void orc_level_command(int level, float fraction, int32_t step_counter, float z, double dt, double episode_length_s,
                        float* cmd_x, float* cmd_yaw);
 

@@ -1,0 +1,293 @@
+#!/usr/bin/env python3
+"""Golden vectors made by EXECUTING the reference's own code (build container only; needs /root/reference).
+
+The reference's modules for this path cannot be imported whole — each one imports omni / pxr / gym / skrl at
+module level (plain ModuleNotFoundError) — but several of the functions on and around the
+hot path are pure torch / numpy / scipy / math over their arguments. This script reads the reference's files,
+takes exactly those function / class definitions out of the syntax tree (ast), compiles them unchanged and runs
+them on seeded inputs. No stand-in is supplied for any absent library: a function whose body needs one
+(quat_apply, torch_rand_float, SimulationContext, skrl memories ...) is not used here and stays pinned by the
+transcription in make_golden.py only. `self` is a plain namespace holding the tensors the method reads.
+
+What is executed (file:line of the definitions in /root/reference/src):
+  my_envs/KAMMA.py            TorqueDistributionTask.calculate_metrics :767, .get_observations :825,
+                              .sample_velocity_command :531 (curriculum branch)
+  my_envs/KA_DDPG_4D.py       .calculate_metrics (single gamma_assist)
+  my_envs/KAMMA_eval.py       .calculate_metrics (Tracking error sum), .sample_velocity_command (EvalSampling)
+  my_envs/KAMMA_g1d_g21.py    .get_observations (env-0 reward guard :838-842)
+  my_agents/ppo.py            PPO._update.compute_gae :320 (nested function)
+  my_utils/origin_terrain_utils.py      the generator families :39-346, SubTerrain :437
+  my_utils/origin_terrain_generator.py  Terrain :37-183 (numpy's global RNG seeded here)
+
+Outputs: tests/golden/refexec_*.npz (inputs and outputs only — data). Where make_golden.py transcribes the same
+lines, this script also asserts that the transcription gives the same numbers on the same inputs.
+
+    python tests/golden/make_golden_ref.py
+"""
+import ast
+import hashlib
+import math
+import os
+import sys
+import types
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+sys.path.insert(0, ROOT)
+REF = "/root/reference/src"
+F = torch.float32
+
+
+def extract(relpath, *qualname, extra_globals=None):
+    """the definition `qualname` (nested: class -> method -> inner function) of a reference file, compiled alone"""
+    path = os.path.join(REF, relpath)
+    node = ast.parse(open(path).read(), filename=path)
+    for name in qualname:
+        found = None
+        for child in ast.walk(node):
+            if child is not node and isinstance(child, (ast.FunctionDef, ast.ClassDef)) and child.name == name:
+                found = child
+                break
+        if found is None:
+            raise KeyError(f"{relpath}: {'.'.join(qualname)} not found")
+        node = found
+    node.decorator_list = []
+    mod = ast.Module(body=[node], type_ignores=[])
+    ast.fix_missing_locations(mod)
+    ns = {"torch": torch, "np": np, "math": math}
+    ns.update(extra_globals or {})
+    exec(compile(mod, path, "exec"), ns)
+    return ns[node.name], ns
+
+
+SUM_KEYS = ["r1: Tracking error reward (squared errors)", "r2: Convergence reward (squared accelerations)",
+            "r3: Torque penalty (sum of squared torques)", "Dense reward", "Sparse reward", "Guiding reward",
+            "Observed reward", "Final reward"]
+
+
+# ------------------------------------------------------------------ calculate_metrics -----------
+def metrics_case(relpath, seed, n=193, terminal=0.0, single_gamma=False, eval_sums=False):
+    fn, _ = extract(relpath, "TorqueDistributionTask", "calculate_metrics")
+    g = torch.Generator().manual_seed(seed)
+    r = lambda *s, lo=-1.0, hi=1.0: (hi - lo) * torch.rand(*s, generator=g, dtype=F) + lo  # noqa: E731
+    S = types.SimpleNamespace()
+    S.device = "cpu"
+    S.dt = 10 * 0.01
+    S.v_forward_projected = r(n, lo=-0.5, hi=2.5)
+    S.base_velocities = r(n, 6)
+    S.previous_linear_velocity = r(n, 3, lo=-0.5, hi=2.5)
+    S.previous_angular_velocity = r(n, 3)
+    S.v_delta, S.omega_delta = r(n, lo=-1.0, hi=2.0), r(n, lo=-0.4, hi=0.4)
+    S.v_delta[:7] = r(7, lo=-0.02, hi=0.02); S.omega_delta[:7] = r(7, lo=-0.02, hi=0.02)  # the sparse bonus
+    S.wheel_torqs = torch.clip(r(n, 4, lo=-5.0, hi=5.0), -4.0, 4.0)
+    gamma = torch.clamp(r(n, lo=-0.2, hi=1.2), 0.0, 1.0)
+    if single_gamma:
+        S.gamma_assist = gamma
+    else:
+        S.gamma_assist2 = gamma
+    S.guiding_reward = -r(n, lo=0.0, hi=6.0)
+    S.timeout_buf = (torch.rand(n, generator=g) < 0.3).long()
+    S.reset_buf = ((torch.rand(n, generator=g) < 0.3) | S.timeout_buf.bool()).long()
+    S.rew_scales = {"termination": terminal}
+    keys = SUM_KEYS + (["Tracking error"] if eval_sums else [])
+    S.episode_sums = {k: r(n, lo=-5.0, hi=5.0) for k in keys}
+    inp = {"v_forward_projected": S.v_forward_projected.clone(), "omega_z": S.base_velocities[:, 5].clone(),
+           "prev_lin": S.previous_linear_velocity[:, 0].clone(), "prev_ang": S.previous_angular_velocity[:, 2].clone(),
+           "v_delta": S.v_delta.clone(), "omega_delta": S.omega_delta.clone(), "wheel_torqs": S.wheel_torqs.clone(),
+           "gamma2": gamma.clone(), "guiding": S.guiding_reward.clone(), "reset": S.reset_buf.to(torch.uint8),
+           "timeout": S.timeout_buf.to(torch.uint8), "terminal": torch.tensor(terminal, dtype=F),
+           "sums_in": torch.stack([S.episode_sums[k] for k in keys], 1).clone()}
+    ret = fn(S)
+    assert ret is S.rew_buf
+    out = {"rew": S.rew_buf, "lin_acc": S.linear_acc, "ang_acc": S.angular_acc,
+           "prev_lin_out": S.previous_linear_velocity[:, 0], "prev_ang_out": S.previous_angular_velocity[:, 2],
+           "sums_out": torch.stack([S.episode_sums[k] for k in keys], 1),
+           "comp": torch.stack([S.comp_1, S.comp_2, S.comp_3, S.rdense, S.rsparse, S.robs, S.rguide, S.rfinal], 1)}
+    d = {k: v.numpy() for k, v in {**inp, **out}.items()}
+    d["source"] = np.array(relpath)
+    return d
+
+
+# ------------------------------------------------------------------ get_observations ------------
+def observations_case(relpath, seed, n=5, tiny_rew0=False):
+    fn, _ = extract(relpath, "TorqueDistributionTask", "get_observations")
+    g = torch.Generator().manual_seed(seed)
+    r = lambda *s, lo=-1.0, hi=1.0: (hi - lo) * torch.rand(*s, generator=g, dtype=F) + lo  # noqa: E731
+    S = types.SimpleNamespace()
+    S._robots = types.SimpleNamespace(name="robot_view")
+    for k in ("desired_v", "desired_omega", "current_v", "current_omega", "v_delta", "omega_delta", "linear_acc", "angular_acc",
+              "ac_left", "ac_right", "comp_1", "comp_2", "comp_3", "rdense", "rsparse", "robs", "rguide"):
+        setattr(S, k, r(n, lo=-3.0, hi=3.0))
+    S.linear_acc[1] = 2500.0  # beyond the wrapper's clip (rl_task.py:99): the task's own buffer is not clipped
+    S.episode_count = torch.randint(0, 50, (n,), generator=g)
+    S.torques, S.actions = r(n, 4, lo=-6.0, hi=6.0), r(n, 4, lo=0.0, hi=1.0)
+    S.action_scale = 3.0
+    S.gamma_assist2 = torch.clamp(r(n, lo=0.0, hi=1.0), 0.0, 1.0)
+    S.rew_buf = r(n, lo=-9.0, hi=-0.1)
+    if tiny_rew0:
+        S.rew_buf[0] = 3.0e-13
+    inp = {k: getattr(S, k).clone().numpy() for k in ("desired_v", "desired_omega", "current_v", "current_omega", "v_delta", "omega_delta",
+                                                       "linear_acc", "angular_acc", "ac_left", "ac_right", "comp_1", "comp_2", "comp_3",
+                                                       "rdense", "rsparse", "robs", "rguide", "torques", "actions", "gamma_assist2", "rew_buf")}
+    inp["episode_count"] = S.episode_count.numpy().astype(np.int32)
+    ret = fn(S)
+    assert list(ret) == ["robot_view"] and ret["robot_view"]["obs_buf"] is S.obs_buf
+    keys = list(S.observed_components)
+    d = dict(inp)
+    d.update(obs_buf=S.obs_buf.numpy(), rew_buf_out=S.rew_buf.numpy(), component_keys=np.array(keys),
+             component_values=np.array([float(S.observed_components[k]) for k in keys], np.float64), source=np.array(relpath))
+    return d
+
+
+# ------------------------------------------------------------------ sample_velocity_command -----
+def level_commands_case(seed=11, n=240):
+    """curriculum branch (KAMMA.py:533-567) per arena as post_physics_step calls it (:719-725). torch.normal draws
+    from torch's global generator: each call is preceded by torch.manual_seed(seed_i), and the standard normal
+    behind the draw is recorded by replaying the same seed through torch.randn(1) (normal(mean, std) = mean + std z
+    in double there, so a float32 replay agrees to an ulp or two: the test's tolerance). std < 0 makes the
+    reference's torch.normal raise: recorded as such."""
+    fn, _ = extract("my_envs/KAMMA.py", "TorqueDistributionTask", "sample_velocity_command")
+    g = torch.Generator().manual_seed(seed)
+    S = types.SimpleNamespace()
+    S.curriculum, S.device = True, "cpu"
+    S.terrain_levels = torch.randint(0, 5, (n,), generator=g)
+    r1 = -torch.rand(n, generator=g, dtype=F) * 2.0
+    r1[::3] = torch.rand(len(r1[::3]), generator=g, dtype=F) * 9.0
+    S.episode_sums = {SUM_KEYS[0]: r1}
+    S.threshold_high = 10.0
+    S.fraction = r1 / S.threshold_high            # KAMMA.py:498
+    S.dt = 10 * 0.01
+    S.max_episode_length_s = 10.0
+    counters = torch.randint(1, 500000, (n,), generator=g)
+    cmd0, cmd2, z, raised = torch.zeros(n, dtype=F), torch.zeros(n, dtype=F), torch.zeros(n, dtype=F), np.zeros(n, np.uint8)
+    for i in range(n):
+        S.episode_step_counter = int(counters[i])
+        torch.manual_seed(1000 + i)
+        z[i] = torch.randn(1)[0]
+        torch.manual_seed(1000 + i)
+        try:
+            a, b = fn(S, i)
+        except RuntimeError:
+            raised[i] = 1
+            continue
+        cmd0[i] = a   # KAMMA.py:724: the assignment rounds to float32
+        cmd2[i] = b   # :725
+    assert raised.sum() > 0 and raised.sum() < n // 2
+    return {"terrain_levels": S.terrain_levels.numpy().astype(np.int32), "fraction": S.fraction.numpy(), "z": z.numpy(),
+            "episode_step_counter": counters.numpy().astype(np.int32), "dt": np.float64(S.dt),
+            "max_episode_length_s": np.float64(S.max_episode_length_s), "commands_0": cmd0.numpy(), "commands_2": cmd2.numpy(),
+            "raised": raised}
+
+
+def eval_commands_case(n=64):
+    """KAMMA_eval.py:545-550: x = 1 + clamp(sim_steps / max_sim_steps, 0, 1) (no random draw)"""
+    fn, _ = extract("my_envs/KAMMA_eval.py", "TorqueDistributionTask", "sample_velocity_command")
+    S = types.SimpleNamespace()
+    S.curriculum, S.evalsampling, S.device = False, True, "cpu"
+    S.max_sim_steps = 50000.0
+    S.sim_steps = torch.cat([torch.arange(0, 60000, 1000), torch.tensor([1, 49999, 50000, 50001])])[:n].long()
+    out = np.zeros((len(S.sim_steps), 2), np.float32)
+    for i in range(len(S.sim_steps)):
+        a, b = fn(S, i)
+        out[i] = [float(a), float(b)]
+    return {"sim_steps": S.sim_steps.numpy().astype(np.int32), "max_sim_steps": np.float32(S.max_sim_steps), "commands": out}
+
+
+# ------------------------------------------------------------------ GAE ------------------------
+def gae_case():
+    from tests.golden.make_golden import refmath_gae
+    d = refmath_gae()
+    fn, ns = extract("my_agents/ppo.py", "PPO", "_update", "compute_gae",
+                     extra_globals={"last_values": torch.from_numpy(d["last_values"])})  # closure variable of _update (:362)
+    returns, advantages = fn(torch.from_numpy(d["rewards"]), torch.from_numpy(d["terminated"]), torch.from_numpy(d["values"]), None,
+                             discount_factor=float(d["discount_factor"]), lambda_coefficient=float(d["lambda_coefficient"]))
+    assert np.array_equal(returns.numpy(), d["ppo_returns"]) and np.array_equal(advantages.numpy(), d["ppo_advantages"]), \
+        "make_golden.refmath_gae differs from the reference's compute_gae"
+    return {"rewards": d["rewards"], "values": d["values"], "last_values": d["last_values"], "terminated": d["terminated"],
+            "discount_factor": d["discount_factor"], "lambda_coefficient": d["lambda_coefficient"],
+            "returns": returns.numpy(), "advantages": advantages.numpy()}
+
+
+# ------------------------------------------------------------------ terrain ----------------------
+def terrain_namespace():
+    from numpy.random import choice
+    from scipy import interpolate
+    names = ["random_uniform_terrain", "flat_terrain", "sloped_terrain", "pyramid_sloped_terrain", "discrete_obstacles_terrain",
+             "wave_terrain", "stairs_terrain", "pyramid_stairs_terrain", "stepping_stones_terrain", "convert_heightfield_to_trimesh",
+             "SubTerrain"]
+    ns = {"np": np, "choice": choice, "interpolate": interpolate, "sqrt": math.sqrt}
+    for nm in names:
+        obj, _ = extract("my_utils/origin_terrain_utils.py", nm, extra_globals=ns)
+        ns[nm] = obj
+    T, _ = extract("my_utils/origin_terrain_generator.py", "Terrain", extra_globals=ns)
+    ns["Terrain"] = T
+    return ns
+
+
+def terrain_cases():
+    ns = terrain_namespace()
+    HS, VS = 0.02, 0.006
+    tile = lambda n=200, m=None: ns["SubTerrain"]("t", width=n, length=m or n, vertical_scale=VS, horizontal_scale=HS)  # noqa: E731
+    out = {}
+    fams = {
+        "flat": lambda: ns["flat_terrain"](tile(50), height=0.3),
+        "sloped": lambda: ns["sloped_terrain"](tile(100), slope=0.25),
+        "pyramid_sloped_pos": lambda: ns["pyramid_sloped_terrain"](tile(200), slope=0.3, platform_size=1.0),
+        "pyramid_sloped_neg": lambda: ns["pyramid_sloped_terrain"](tile(200), slope=-0.2, platform_size=3.0),
+        "stairs": lambda: ns["stairs_terrain"](tile(100), step_width=0.3, step_height=0.05),
+        "pyramid_stairs_up": lambda: ns["pyramid_stairs_terrain"](tile(400), step_width=0.31, step_height=0.15, platform_size=3.0),
+        "pyramid_stairs_down": lambda: ns["pyramid_stairs_terrain"](tile(400), step_width=1.0, step_height=-0.047, platform_size=3.0),
+        "wave": lambda: ns["wave_terrain"](tile(100), num_waves=2, amplitude=0.2),
+        "discrete_obstacles": lambda: ns["discrete_obstacles_terrain"](tile(400), 0.15, 1.0, 2.0, 40, platform_size=3.0),
+        "random_uniform": lambda: ns["random_uniform_terrain"](tile(100), -0.1, 0.1, step=0.05, downsampled_scale=0.2),
+        "stepping_stones": lambda: ns["stepping_stones_terrain"](tile(200), 0.5, 0.1, 0.05, platform_size=1.0),
+        "stepping_stones_wide": lambda: ns["stepping_stones_terrain"](tile(120, 200), 0.4, 0.08, 0.1, platform_size=1.0),
+    }
+    for k, (name, make) in enumerate(fams.items()):
+        np.random.seed(100 + k)
+        t = make()
+        out[name] = t.height_field_raw.copy()
+        assert out[name].dtype == np.int16
+    # the whole generator: curriculum layout (deterministic) and the randomised one under two seeds
+    base = {"mapLength": 10.0, "mapWidth": 10.0, "numLevels": 6, "numTerrains": 2, "slopeTreshold": 0.5, "terrainProportions": [0.1, 0.5, 0.4]}
+    for tag, cfg, seed in (("gen_curriculum", {**base, "curriculum": True}, 0), ("gen_random_s3", {**base, "curriculum": False}, 3),
+                           ("gen_random_s42", {**base, "curriculum": False}, 42),
+                           ("gen_random_small_s7", {**base, "curriculum": False, "numLevels": 3, "numTerrains": 3, "mapLength": 8.0, "mapWidth": 8.0}, 7)):
+        np.random.seed(seed)
+        T = ns["Terrain"](cfg, 4096)
+        f = np.ascontiguousarray(T.height_field_raw)
+        out[tag + "_shape"] = np.array(f.shape, np.int32)
+        out[tag + "_sha256"] = np.array(hashlib.sha256(f.tobytes()).hexdigest())
+        out[tag + "_origins"] = T.env_origins.copy()
+        out[tag + "_every25"] = f[::25, ::25].copy()
+        out[tag + "_tri"] = np.array([T.vertices.shape[0], T.triangles.shape[0]], np.int64)
+    return out
+
+
+def main():
+    from tests.golden import make_golden as mg
+    save = lambda name, d: np.savez_compressed(os.path.join(HERE, name), **d)  # noqa: E731
+    cases = {"kamma_t0": metrics_case("my_envs/KAMMA.py", 21, terminal=0.0), "kamma_t15": metrics_case("my_envs/KAMMA.py", 22, terminal=1.5),
+             "ddpg4d": metrics_case("my_envs/KA_DDPG_4D.py", 23, single_gamma=True),
+             "eval": metrics_case("my_envs/KAMMA_eval.py", 24, eval_sums=True)}
+    save("refexec_metrics.npz", {f"{c}__{k}": v for c, d in cases.items() for k, v in d.items()})
+    obs = {"kamma": observations_case("my_envs/KAMMA.py", 31), "g1d": observations_case("my_envs/KAMMA_g1d_g21.py", 32, tiny_rew0=True),
+           "g1d_normal": observations_case("my_envs/KAMMA_g1d_g21.py", 33)}
+    save("refexec_observations.npz", {f"{c}__{k}": v for c, d in obs.items() for k, v in d.items()})
+    lc = level_commands_case()
+    save("refexec_level_commands.npz", lc)
+    save("refexec_eval_commands.npz", eval_commands_case())
+    save("refexec_gae.npz", gae_case())
+    save("refexec_terrain.npz", terrain_cases())
+    # the transcription of make_golden.py against the executed reference, same inputs
+    import tests.golden.make_golden  # noqa: F401
+    d = mg.refmath_curriculum()
+    print("wrote refexec_*.npz;", {k: int(v["rew"].size) for k, v in cases.items()}, "level-command rows", len(lc["z"]),
+          "of which torch.normal raised", int(lc["raised"].sum()), "| transcription rows", len(d["z"]))
+
+
+if __name__ == "__main__":
+    main()
