@@ -12,7 +12,8 @@
  *     tests/golden/make_golden_ref.py: the function definitions are taken out of the reference's files
  *     by ast, compiled unchanged and run on seeded inputs; the modules cannot be imported whole — omni /
  *     pxr / gym / skrl at module level, plain ModuleNotFoundError, SURVEY §8c — and no stand-in for an
- *     absent library is supplied): calculate_metrics (KAMMA.py:767, KA_DDPG_4D, KAMMA_eval),
+ *     absent library is supplied): TASK_CFG + update_config of the 12 env files, calculate_metrics
+ *     (KAMMA.py:767, KA_DDPG_4D, KAMMA_eval),
  *     get_observations incl. the 26 env-0 diagnostics and KAMMA_g1d_g21's reward guard,
  *     sample_velocity_command's curriculum and EvalSampling branches, PPO's compute_gae, the terrain
  *     generator families and the Terrain class (tests/test_refexec.py).

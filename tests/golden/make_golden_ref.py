@@ -10,6 +10,7 @@ them on seeded inputs. No stand-in is supplied for any absent library: a functio
 transcription in make_golden.py only. `self` is a plain namespace holding the tensors the method reads.
 
 What is executed (file:line of the definitions in /root/reference/src):
+  my_envs/*.py (12 files)     the TASK_CFG literal :29-128 (ast.literal_eval), TorqueDistributionTask.update_config :231
   my_envs/KAMMA.py            TorqueDistributionTask.calculate_metrics :767, .get_observations :825,
                               .sample_velocity_command :531 (curriculum branch)
   my_envs/KA_DDPG_4D.py       .calculate_metrics (single gamma_assist)
@@ -66,6 +67,49 @@ def extract(relpath, *qualname, extra_globals=None):
 SUM_KEYS = ["r1: Tracking error reward (squared errors)", "r2: Convergence reward (squared accelerations)",
             "r3: Torque penalty (sum of squared torques)", "Dense reward", "Sparse reward", "Guiding reward",
             "Observed reward", "Final reward"]
+
+
+# ------------------------------------------------------------------ TASK_CFG / update_config ----
+VARIANT_FILES = ["KAMMA", "KAMMA_medium", "KAMMA_g11_g21", "KAMMA_g1d_g21", "KAMMA_curr1", "KAMMA_curr2", "KAMMA_eval",
+                 "KA_DDPG_4D", "KA_DDPG_2D", "KA_DDPG_1D", "KA_DDPG_2D_eval", "KA_DDPG_1D_eval"]
+# what every train / eval script writes into TASK_CFG before it builds the task (argparse defaults,
+# train/train_kamma_4d_nofifo_random_RLIL.py:62-68, 79-91)
+SCRIPT_OVERRIDES = {"stiffness": 0.035, "damping": 0.005, "static_friction": 0.85, "dynamic_friction": 0.85,
+                    "yaw_constant": 0.5, "linear_x": [1.0, 2.0], "numEnvs": 1}
+
+
+def config_cases():
+    """the module-level TASK_CFG literal of every env file (ast.literal_eval) and what update_config (KAMMA.py:231-275)
+    derives from it once the scripts' overrides are in"""
+    import copy
+    import json
+    out = {}
+    for name in VARIANT_FILES:
+        rel = f"my_envs/{name}.py"
+        tree = ast.parse(open(os.path.join(REF, rel)).read())
+        node = next(n for n in tree.body if isinstance(n, ast.Assign) and getattr(n.targets[0], "id", None) == "TASK_CFG")
+        cfg = ast.literal_eval(node.value)
+        out[name + "__task_cfg_json"] = np.array(json.dumps(cfg, sort_keys=True))
+        run = copy.deepcopy(cfg)
+        o = SCRIPT_OVERRIDES
+        run["task"]["env"]["numEnvs"] = o["numEnvs"]
+        run["task"]["env"]["control"]["stiffness"], run["task"]["env"]["control"]["damping"] = o["stiffness"], o["damping"]
+        run["task"]["sim"]["default_physics_material"]["static_friction"] = o["static_friction"]
+        run["task"]["sim"]["default_physics_material"]["dynamic_friction"] = o["dynamic_friction"]
+        run["task"]["env"]["randomCommandVelocityRanges"]["yaw_constant"] = o["yaw_constant"]
+        run["task"]["env"]["randomCommandVelocityRanges"]["linear_x"] = o["linear_x"]
+        fn, _ = extract(rel, "TorqueDistributionTask", "update_config")
+        S = types.SimpleNamespace()
+        fn(S, types.SimpleNamespace(config=run, task_config=run["task"]))
+        derived = {k: getattr(S, k) for k in ("action_scale", "command_x_range", "command_y_range", "command_yaw_range", "yaw_constant",
+                                              "base_init_state", "decimation", "sim_dt", "dt", "max_episode_length_s",
+                                              "max_episode_length", "Kp", "Kd", "curriculum", "randsampling", "boxsampling",
+                                              "gridsampling", "threshold_high", "_num_envs", "dof_init_state")}
+        derived["termination"] = S.rew_scales["termination"]
+        derived["evalsampling"] = bool(getattr(S, "evalsampling", False))
+        out[name + "__derived_json"] = np.array(json.dumps(derived, sort_keys=True))
+    out["script_overrides_json"] = np.array(json.dumps(SCRIPT_OVERRIDES, sort_keys=True))
+    return out
 
 
 # ------------------------------------------------------------------ calculate_metrics -----------
@@ -282,6 +326,7 @@ def main():
     save("refexec_eval_commands.npz", eval_commands_case())
     save("refexec_gae.npz", gae_case())
     save("refexec_terrain.npz", terrain_cases())
+    save("refexec_config.npz", config_cases())
     # the transcription of make_golden.py against the executed reference, same inputs
     import tests.golden.make_golden  # noqa: F401
     d = mg.refmath_curriculum()

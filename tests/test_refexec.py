@@ -183,3 +183,77 @@ def test_terrain_generator_equals_the_executed_reference(tag, over, seed):
     assert np.array_equal(f[::25, ::25], d[tag + "_every25"])
     assert hashlib.sha256(f.tobytes()).hexdigest() == str(d[tag + "_sha256"])
     assert np.array_equal(T.env_origins, d[tag + "_origins"])
+
+
+VARIANT_FILES = ["KAMMA", "KAMMA_medium", "KAMMA_g11_g21", "KAMMA_g1d_g21", "KAMMA_curr1", "KAMMA_curr2", "KAMMA_eval",
+                 "KA_DDPG_4D", "KA_DDPG_2D", "KA_DDPG_1D", "KA_DDPG_2D_eval", "KA_DDPG_1D_eval"]
+
+
+def _with_script_overrides(cfg, o):
+    """what the train / eval scripts write into TASK_CFG before building the task (train_kamma_4d_nofifo_random_RLIL.py:79-91)"""
+    import copy
+    run = copy.deepcopy(cfg)
+    run["task"]["env"]["numEnvs"] = o["numEnvs"]
+    run["task"]["env"]["control"]["stiffness"], run["task"]["env"]["control"]["damping"] = o["stiffness"], o["damping"]
+    run["task"]["sim"]["default_physics_material"]["static_friction"] = o["static_friction"]
+    run["task"]["sim"]["default_physics_material"]["dynamic_friction"] = o["dynamic_friction"]
+    run["task"]["env"]["randomCommandVelocityRanges"]["yaw_constant"] = o["yaw_constant"]
+    run["task"]["env"]["randomCommandVelocityRanges"]["linear_x"] = o["linear_x"]
+    return run
+
+
+def test_default_task_cfg_is_the_reference_literal_with_the_scripts_overrides():
+    """default_task_cfg() against the TASK_CFG literal of KAMMA.py:29-128 (ast.literal_eval of the reference's file) after
+    the scripts' argparse defaults are written into it; PhysX GPU buffer sizes are the only keys not carried."""
+    import json
+    from options_in_simulation_amd import default_task_cfg
+    d = np.load(os.path.join(G, "refexec_config.npz"))
+    lit = json.loads(str(d["KAMMA__task_cfg_json"]))
+    ref = _with_script_overrides(lit, json.loads(str(d["script_overrides_json"])))
+    ref["task"]["env"]["numEnvs"] = lit["task"]["env"]["numEnvs"]  # the literal's; every script then forces 1
+    mine = default_task_cfg()
+    dropped = []
+
+    def walk(a, b, path):
+        assert isinstance(a, dict) == isinstance(b, dict), path
+        if not isinstance(a, dict):
+            assert a == b, (path, a, b)
+            return
+        for k in a:
+            if k not in b:
+                dropped.append(path + "/" + k)
+            else:
+                walk(a[k], b[k], path + "/" + k)
+        assert not (set(b) - set(a)), (path, set(b) - set(a))  # nothing invented
+    walk(ref, mine, "")
+    assert dropped and all(p.startswith("/task/sim/physx/gpu_") for p in dropped), dropped
+
+
+@pytest.mark.parametrize("name", VARIANT_FILES)
+def test_build_config_derives_what_update_config_derives(name):
+    """update_config (KAMMA.py:231-275 and the same method of the 11 other env files) EXECUTED on each file's own TASK_CFG:
+    dt, max_episode_length = int(10 / 0.1 + 0.5), Kp, ranges, init state, sampler flags — against build_config(variant)."""
+    import json
+    from options_in_simulation_amd import build_config
+    d = np.load(os.path.join(G, "refexec_config.npz"))
+    cfg = _with_script_overrides(json.loads(str(d[name + "__task_cfg_json"])), json.loads(str(d["script_overrides_json"])))
+    r = json.loads(str(d[name + "__derived_json"]))
+    c = build_config(task_cfg=cfg, variant=name)
+    assert c.num_envs == r["_num_envs"] == 1
+    assert c.decimation == r["decimation"] and c.sim_dt == np.float32(r["sim_dt"])
+    assert c.policy_dt == np.float32(r["dt"]) and c.max_episode_length == r["max_episode_length"] == 100
+    assert c.episode_length_s == np.float32(r["max_episode_length_s"])
+    assert c.Kp == np.float32(r["Kp"]) and c.action_scale == np.float32(r["action_scale"])
+    assert c.terminal_reward == np.float32(r["termination"])
+    assert [c.cmd_x_lo, c.cmd_x_hi] == [np.float32(v) for v in r["command_x_range"]]
+    assert [c.cmd_y_lo, c.cmd_y_hi] == [np.float32(v) for v in r["command_y_range"]]
+    assert [c.cmd_yaw_lo, c.cmd_yaw_hi] == [np.float32(v) for v in r["command_yaw_range"]]
+    assert c.curriculum_threshold_high == np.float32(r["threshold_high"])
+    init = r["base_init_state"]
+    assert [c.init_pos[k] for k in range(3)] == [np.float32(v) for v in init[:3]]
+    assert [c.init_quat[k] for k in range(4)] == [np.float32(v) for v in init[3:7]]
+    assert [c.init_lin_vel[k] for k in range(3)] + [c.init_ang_vel[k] for k in range(3)] == [np.float32(v) for v in init[7:13]]
+    assert [c.init_dof_vel[k] for k in range(4)] == [np.float32(v) for v in r["dof_init_state"][4:8]]
+    sampler = (_abi.CMD_LEVEL if r["curriculum"] else _abi.CMD_EVAL if r["evalsampling"] else _abi.CMD_RAND if r["randsampling"]
+               else _abi.CMD_BOX if r["boxsampling"] else _abi.CMD_GRID if r["gridsampling"] else None)
+    assert c.cmd_sampler == sampler, (name, r)
