@@ -235,11 +235,32 @@ class Env0Tracker:
             row[k] = val
         self.tracking_data.clear()
         self.writer.flush()
+        # the CLI builds this file from the event file, whose simple_value is a float32: the same rounding here
         with open(self.csv_path, "a", newline="") as f:
-            csv.writer(f).writerow([timestep] + [row.get(f"Reward_comp_env0 / {c}", float("nan")) for c in CSV_COLUMNS])
+            csv.writer(f).writerow([timestep] + [_as_f32(row.get(f"Reward_comp_env0 / {c}", float("nan"))) for c in CSV_COLUMNS])
 
     def close(self) -> None:
         self.writer.close()
+
+
+def _as_f32(v: float) -> float:
+    """the value an event file holds for v (Summary.Value.simple_value is a float32)"""
+    return struct.unpack("<f", struct.pack("<f", v))[0]
+
+
+def write_timeseries_csv(event_path: str, out_csv: Optional[str] = None) -> str:
+    """``reward_components_env0_timeseries.csv`` rebuilt from an event file, as the reference's CLI does it
+    (src/options_sim/cli/artifacts.py:68-108: _collect_timeseries + _write_csv): one row per step that carries any
+    of the six tags, NaN where a tag has no value at that step."""
+    steps, data = timeseries_from_events(event_path)
+    if out_csv is None:
+        out_csv = os.path.join(os.path.dirname(event_path), "reward_components_env0_timeseries.csv")
+    with open(out_csv, "w", newline="") as f:
+        w = csv.writer(f)
+        w.writerow(("step",) + CSV_COLUMNS)
+        for i, s_ in enumerate(steps):
+            w.writerow([s_] + [data[c][i] for c in CSV_COLUMNS])
+    return out_csv
 
 
 def timeseries_from_events(path: str) -> Tuple[List[int], Dict[str, List[float]]]:

@@ -17,6 +17,8 @@ What is executed (file:line of the definitions in /root/reference/src):
   my_envs/KAMMA_eval.py       .calculate_metrics (Tracking error sum), .sample_velocity_command (EvalSampling)
   my_envs/KAMMA_g1d_g21.py    .get_observations (env-0 reward guard :838-842)
   my_agents/ppo.py            PPO._update.compute_gae :320 (nested function)
+  options_sim/cli/artifacts.py          _collect_timeseries :68, _write_csv :96 (over the build's event files)
+  options_sim/cli/eval_artifacts.py     _get_series :62, _align_by_step :76, _moving_average :90
   my_utils/origin_terrain_utils.py      the generator families :39-346, SubTerrain :437
   my_utils/origin_terrain_generator.py  Terrain :37-183 (numpy's global RNG seeded here)
 
@@ -311,6 +313,77 @@ def terrain_cases():
     return out
 
 
+# ------------------------------------------------------------------ artefact CLIs ---------------
+def artifacts_case(seed=41):
+    """src/options_sim/cli/artifacts.py _collect_timeseries :68 + _write_csv :96 and eval_artifacts.py _get_series :62,
+    _align_by_step :76, _moving_average :90, run over an event file written by options_in_simulation_amd.tracking
+    (TensorBoard's EventAccumulator is absent: the accumulator handed to the reference's functions is the build's own
+    reader behind the two calls they make, Scalars(tag) -> events with .step / .value, KeyError for an unknown tag)."""
+    import collections
+    import tempfile
+    from options_in_simulation_amd import tracking
+    rng = np.random.default_rng(seed)
+    steps = [800 * (i + 1) for i in range(12)]
+    cols = ["v_delta", "desired_v", "current_v", "omega_delta", "desired_omega", "current_omega"]
+    values = {c: rng.normal(size=len(steps)) * (1e-5 if "omega" in c else 1.0) for c in cols}
+    te, dv = np.abs(rng.normal(size=len(steps))) * 0.4, np.linspace(1.0, 2.0, len(steps)) + rng.normal(size=len(steps)) * 1e-3
+    Ev = collections.namedtuple("Ev", "wall_time step value")
+
+    class EA:
+        def __init__(self, path):
+            self.s = collections.defaultdict(list)
+            for step, wall, scalars in tracking.read_events(path):
+                for tag, v in scalars.items():
+                    self.s[tag].append(Ev(wall, step, v))
+
+        def Scalars(self, tag):
+            if tag not in self.s:
+                raise KeyError(tag)
+            return self.s[tag]
+
+    tag_node = next(n for n in ast.parse(open(os.path.join(REF, "options_sim/cli/artifacts.py")).read()).body
+                    if isinstance(n, ast.Assign) and getattr(n.targets[0], "id", None) == "TAG_CANDIDATES")
+    import csv as _csv
+    from pathlib import Path
+    g = {"TAG_CANDIDATES": ast.literal_eval(tag_node.value), "csv": _csv, "Path": Path, "EventAccumulator": object}
+    collect, _ = extract("options_sim/cli/artifacts.py", "_collect_timeseries", extra_globals=g)
+    write_csv, _ = extract("options_sim/cli/artifacts.py", "_write_csv", extra_globals=g)
+    cand = {}
+    for nm in ("TRACKING_ERR_CANDS", "DESIRED_VEL_CANDS"):
+        node = next(n for n in ast.parse(open(os.path.join(REF, "options_sim/cli/eval_artifacts.py")).read()).body
+                    if isinstance(n, ast.Assign) and getattr(n.targets[0], "id", None) == nm)
+        cand[nm] = ast.literal_eval(node.value)
+    from typing import Dict, List, Optional, Tuple
+    g2 = {"List": List, "Tuple": Tuple, "Dict": Dict, "Optional": Optional, "EventAccumulator": object}
+    get_series, _ = extract("options_sim/cli/eval_artifacts.py", "_get_series", extra_globals=g2)
+    align, _ = extract("options_sim/cli/eval_artifacts.py", "_align_by_step", extra_globals=g2)
+    mavg, _ = extract("options_sim/cli/eval_artifacts.py", "_moving_average", extra_globals=g2)
+    with tempfile.TemporaryDirectory() as tmp:
+        w = tracking.EventFileWriter(tmp)
+        for i, st in enumerate(steps):
+            sc = {f"Reward_comp_env0 / {c}": float(values[c][i]) for c in cols if not (c == "current_v" and i == 4)}  # one gap -> NaN
+            if i != 7:                                                           # an unmatched step on the eval side
+                sc["Info / rew_Tracking error"] = float(te[i])
+            sc["Info / rew_Desired velocity"] = float(dv[i])
+            w.add_scalars(sc, st)
+        w.close()
+        path = [os.path.join(tmp, f) for f in os.listdir(tmp) if "tfevents" in f][0]
+        ea = EA(path)
+        st_out, data, matched = collect(ea)
+        csv_path = write_csv(Path(tmp), st_out, data)
+        csv_text = open(csv_path).read()
+        te_tag, te_series = get_series(ea, cand["TRACKING_ERR_CANDS"])
+        dv_tag, dv_series = get_series(ea, cand["DESIRED_VEL_CANDS"])
+        xs, ys = align(dv_series, te_series)
+        ys_s = mavg(list(ys), 4)
+    assert matched["v_delta"] == "Reward_comp_env0 / v_delta" and te_tag == "Info / rew_Tracking error"
+    out = {"steps": np.array(steps, np.int64), "tracking_error": te, "desired_velocity": dv, "timeseries_csv": np.array(csv_text),
+           "speed": np.array(xs, np.float64), "tracking_error_aligned": np.array(ys, np.float64),
+           "tracking_error_smooth4": np.array(ys_s, np.float64)}
+    out.update({"value_" + c: values[c] for c in cols})
+    return out
+
+
 def main():
     from tests.golden import make_golden as mg
     save = lambda name, d: np.savez_compressed(os.path.join(HERE, name), **d)  # noqa: E731
@@ -327,6 +400,7 @@ def main():
     save("refexec_gae.npz", gae_case())
     save("refexec_terrain.npz", terrain_cases())
     save("refexec_config.npz", config_cases())
+    save("refexec_artifacts.npz", artifacts_case())
     # the transcription of make_golden.py against the executed reference, same inputs
     import tests.golden.make_golden  # noqa: F401
     d = mg.refmath_curriculum()

@@ -257,3 +257,35 @@ def test_build_config_derives_what_update_config_derives(name):
     sampler = (_abi.CMD_LEVEL if r["curriculum"] else _abi.CMD_EVAL if r["evalsampling"] else _abi.CMD_RAND if r["randsampling"]
                else _abi.CMD_BOX if r["boxsampling"] else _abi.CMD_GRID if r["gridsampling"] else None)
     assert c.cmd_sampler == sampler, (name, r)
+
+
+def test_artefact_files_equal_what_the_reference_cli_functions_write(tmp_path):
+    """The reference's own artefact helpers (artifacts.py _collect_timeseries / _write_csv, eval_artifacts.py _get_series /
+    _align_by_step / _moving_average) were run over an event file of the build (fixture). Here the same scalars go through
+    EventFileWriter again and the build's writers must produce the same CSV text and series: a gap in one tag becomes
+    `nan`, a step missing on the tracking-error side is dropped by the left join, values are the event file's float32s."""
+    import csv
+    from options_in_simulation_amd import tracking
+    d = np.load(os.path.join(G, "refexec_artifacts.npz"))
+    cols = tracking.CSV_COLUMNS
+    w = tracking.EventFileWriter(str(tmp_path))
+    for i, st in enumerate(d["steps"]):
+        sc = {f"Reward_comp_env0 / {c}": float(d["value_" + c][i]) for c in cols if not (c == "current_v" and i == 4)}
+        if i != 7:
+            sc["Info / rew_Tracking error"] = float(d["tracking_error"][i])
+        sc["Info / rew_Desired velocity"] = float(d["desired_velocity"][i])
+        w.add_scalars(sc, int(st))
+    w.close()
+    ev = [str(p) for p in tmp_path.iterdir() if "tfevents" in p.name][0]
+    out = tracking.write_timeseries_csv(ev)
+    assert open(out).read() == str(d["timeseries_csv"])
+    assert "nan" in str(d["timeseries_csv"]).splitlines()[5]
+    xs, ys = tracking.write_tracking_error_vs_speed(ev)
+    assert np.array_equal(np.array(xs), d["speed"]) and np.array_equal(np.array(ys), d["tracking_error_aligned"])
+    assert len(xs) == len(d["steps"]) - 1
+    xs, ys = tracking.write_tracking_error_vs_speed(ev, smooth=4)
+    assert np.array_equal(np.array(ys), d["tracking_error_smooth4"])
+    rows = list(csv.reader(open(os.path.join(str(tmp_path), "tracking_error_vs_speed.csv"))))
+    assert rows[0] == ["speed_m_s", "tracking_error_m_s"] and [float(r[1]) for r in rows[1:]] == list(d["tracking_error_smooth4"])
+    # the tracker's live CSV rows carry the same float32 values the CLI would read back
+    assert tracking._as_f32(0.1) == float(np.float32(0.1))
