@@ -289,3 +289,61 @@ def test_artefact_files_equal_what_the_reference_cli_functions_write(tmp_path):
     assert rows[0] == ["speed_m_s", "tracking_error_m_s"] and [float(r[1]) for r in rows[1:]] == list(d["tracking_error_smooth4"])
     # the tracker's live CSV rows carry the same float32 values the CLI would read back
     assert tracking._as_f32(0.1) == float(np.float32(0.1))
+
+
+RETURNS_SPEC = dict(variant="KAMMA_medium", n=24, steps=210, seed=13)
+
+
+def _returns_run(env, to_numpy):
+    sp = RETURNS_SPEC
+    rng = np.random.default_rng(sp["seed"])
+    rew, done = [], []
+    for _ in range(sp["steps"]):
+        env.step(rng.uniform(0, 1, (sp["n"], 4)).astype(np.float32))
+        rew.append(to_numpy(env.buffer(_abi.BUF_REW)).copy()); done.append(to_numpy(env.buffer(_abi.BUF_DONE)).astype(np.uint8).copy())
+    return np.array(rew), np.array(done), env.stats()
+
+
+def _check_returns(rew, done, st):
+    """the finished-episode statistics of the environment against Agent.record_transition (src/my_agents/base.py:270-341)
+    EXECUTED on the same run (fixture): number of episodes, their total rewards (max / min / mean of the deque), lengths"""
+    d = np.load(os.path.join(G, "refexec_returns.npz"))
+    assert np.array_equal(rew, d["rewards"]) and np.array_equal(done, d["done"])  # the run the fixture was made from
+    tr, tt = d["track_rewards"], d["track_timesteps"]
+    assert st.episodes == len(tr) == 2 * RETURNS_SPEC["n"]
+    assert st.return_max == np.float32(tr.max()) and st.return_min == np.float32(tr.min())        # torch float32 sums there
+    assert st.return_sum / st.episodes == pytest.approx(d["td__Reward / Total reward (mean)"][-1], rel=1e-6)
+    assert st.return_sum / st.episodes == pytest.approx(tr.mean(), rel=1e-6)
+    assert st.length_sum / st.episodes == d["td__Episode / Total timesteps (mean)"][-1] == tt.mean() == 99.0
+    var = st.return_sqsum / st.episodes - (st.return_sum / st.episodes) ** 2
+    assert var == pytest.approx(tr.var(), rel=1e-5)
+    # per-step instantaneous rewards: what the agent logs is torch.max / min / mean over the arenas of rew_buf
+    assert np.array_equal(d["td__Reward / Instantaneous reward (max)"], rew.max(1).astype(np.float64))
+    assert np.array_equal(d["td__Reward / Instantaneous reward (min)"], rew.min(1).astype(np.float64))
+
+
+def test_episode_statistics_against_the_executed_agent_bookkeeping():
+    from options_in_simulation_amd import build_config
+    from oracle.binding import OracleEnv
+    sp = RETURNS_SPEC
+    env = OracleEnv(build_config(variant=sp["variant"], num_envs=sp["n"], seed=sp["seed"]))
+    env.reset(sp["seed"])
+    _check_returns(*_returns_run(env, np.asarray))
+
+
+@pytest.mark.gpu
+def test_episode_statistics_of_the_hip_path_against_the_executed_agent_bookkeeping():
+    import torch
+    from options_in_simulation_amd import build_config
+    from options_in_simulation_amd.vecenv import NativeEnv
+    sp = RETURNS_SPEC
+    env = NativeEnv(build_config(variant=sp["variant"], num_envs=sp["n"], seed=sp["seed"]), "cuda:0")
+    env.reset(sp["seed"])
+
+    class Adapter:  # numpy actions in, as the oracle env takes them
+        buffer, stats = env.buffer, env.stats
+
+        @staticmethod
+        def step(a):
+            env.step(torch.from_numpy(a).cuda())
+    _check_returns(*_returns_run(Adapter, lambda t: t.cpu().numpy()))
