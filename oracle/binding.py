@@ -67,6 +67,8 @@ def lib() -> C.CDLL:
         L.orc_metrics.argtypes = ([C.c_int, fp, fp, fp, fp, fp, fp, fp, fp, fp, u8p, u8p] + [C.c_float] * 7
                                   + [fp, fp, fp, fp])
         L.orc_metrics.restype = None
+        L.orc_grid_command.argtypes = [C.c_int32, C.c_float, C.c_float, C.c_float, C.c_float, C.c_float]
+        L.orc_grid_command.restype = C.c_float
         L.orc_eval_command.argtypes = [C.c_int32, C.c_float]
         L.orc_eval_command.restype = C.c_float
         L.orc_eval_sums.argtypes = [C.c_int, fp, fp, fp, fp, fp]

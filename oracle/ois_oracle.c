@@ -403,6 +403,19 @@ void orc_reset_draws(const ois_config* cfg, const float u[8], float pos3[3], flo
  * doubles in the reference and doubles here; tensor arithmetic is float32.
  * Where the reference would raise (torch.normal with std < 0: sigma < 0 at level 0 once the r1 sum
  * is below -1.11, Noise < 0 at level 2) the build evaluates mean + std * z all the same. */
+/* KAMMA_curr2.py:602-626 (GridSampling): a bimodal normal (sigma 0.05) whose two means move from the centre of the
+ * command range to its ends with progress = min(1, sim_steps / max_sim_steps); u_side < 0.5 picks the left mode;
+ * torch.normal(mean=Tensor, std=Tensor) = z * std + mean in float32 */
+float orc_grid_command(int32_t sim_steps, float max_sim_steps, float lo, float hi, float u_side, float z) {
+  float progress = fminf(1.0f, (float)sim_steps / max_sim_steps);
+  float xc = (lo + hi) / 2.0f;
+  float left = xc - progress * (xc - lo);
+  float right = xc + progress * (hi - xc);
+  float mean = u_side < 0.5f ? left : right;
+  float xv = mean + 0.05f * z;
+  return xv > 0.0f ? xv : 0.0f;
+}
+
 /* KAMMA_eval.py:545-550 (EvalSampling): x_vel ramps from 1 to 2 m/s with sim_steps / max_sim_steps, omega = 0 */
 float orc_eval_command(int32_t sim_steps, float ramp_steps) {
   float progress = fminf(fmaxf((float)sim_steps / ramp_steps, 0.0f), 1.0f);
@@ -984,18 +997,11 @@ static void reset_arena(orc_env* e, int i, uint32_t step_ctr, float gamma2, rese
   } else if (c->cmd_sampler == OIS_CMD_EVAL) {
     cmd[0] = orc_eval_command(cnt[1], c->eval_ramp_steps);
   } else if (c->cmd_sampler == OIS_CMD_GRID) {
-    /* KAMMA_curr2.py:602-640: bimodal normal (sigma 0.05) whose two means move from the
-     * centre of the range to its ends with progress; u[6] picks the side (torch.rand(1) < 0.5),
-     * a third Philox block feeds the normal draw (the omega draw of :631-636 is discarded) */
-    float progress = fminf(1.0f, (float)cnt[1] / c->max_sim_steps);
-    float xc = (c->cmd_x_lo + c->cmd_x_hi) / 2.0f;
-    float left = xc - progress * (xc - c->cmd_x_lo);
-    float right = xc + progress * (c->cmd_x_hi - xc);
+    /* KAMMA_curr2.py:602-640; u[6] picks the side (torch.rand(1) < 0.5), a third Philox block feeds the normal
+     * draw (the omega draw of :631-636 is discarded) */
     float uc[4];
     draw4(e->seed, gid, step_ctr, PURPOSE_RESET_C, uc);
-    float mean = u[6] < 0.5f ? left : right;
-    float xv = mean + 0.05f * normal_det(uc[0], uc[1]);
-    cmd[0] = xv > 0.0f ? xv : 0.0f;
+    cmd[0] = orc_grid_command(cnt[1], c->max_sim_steps, c->cmd_x_lo, c->cmd_x_hi, u[6], normal_det(uc[0], uc[1]));
   }
   /* pose: the reference sets the base-link pose (:441-443); the state stores the COM */
   float* P = &e->pose[4 * i];

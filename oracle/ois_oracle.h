@@ -144,6 +144,7 @@ float orc_h2f(uint16_t h);
 /* the per-terrain-level command generators (KAMMA.py:533-567) and the deterministic helpers they use */
 float orc_sin(float x);
 float orc_normal(float u1, float u2);
+float orc_grid_command(int32_t sim_steps, float max_sim_steps, float lo, float hi, float u_side, float z); /* KAMMA_curr2.py:602-626 */
 float orc_eval_command(int32_t sim_steps, float ramp_steps); /* KAMMA_eval.py:545-550 */
 void orc_level_command(int level, float fraction, int32_t step_counter, float z, double dt, double episode_length_s,
                        float* cmd_x, float* cmd_yaw);

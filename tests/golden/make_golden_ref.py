@@ -15,6 +15,7 @@ What is executed (file:line of the definitions in /root/reference/src):
                               .sample_velocity_command :531 (curriculum branch)
   my_envs/KA_DDPG_4D.py       .calculate_metrics (single gamma_assist)
   my_envs/KAMMA_eval.py       .calculate_metrics (Tracking error sum), .sample_velocity_command (EvalSampling)
+  my_envs/KAMMA_curr2.py      .sample_velocity_command (GridSampling :600-640)
   my_envs/KAMMA_g1d_g21.py    .get_observations (env-0 reward guard :838-842)
   my_agents/ppo.py            PPO._update.compute_gae :320 (nested function)
   my_agents/base.py           Agent.record_transition :270 (episode return / length bookkeeping)
@@ -243,6 +244,32 @@ def eval_commands_case(n=64):
     return {"sim_steps": S.sim_steps.numpy().astype(np.int32), "max_sim_steps": np.float32(S.max_sim_steps), "commands": out}
 
 
+def grid_commands_case(n=96):
+    """KAMMA_curr2.py:600-640 (GridSampling), one arena (the branch's min(1.0, tensor) only works with one): the side
+    pick torch.rand(1) < 0.5 and torch.normal(mean=Tensor, std=Tensor) = randn * std + mean in float32 — both replayed
+    from the same seed, so the draw behind each output is in the fixture (u, z) and the formula can be checked exactly."""
+    import warnings
+    fn, _ = extract("my_envs/KAMMA_curr2.py", "TorqueDistributionTask", "sample_velocity_command")
+    S = types.SimpleNamespace()
+    S.curriculum, S.randsampling, S.boxsampling, S.gridsampling, S.device = False, False, False, True, "cpu"
+    S.max_sim_steps = 500000.0
+    S.command_x_range, S.command_yaw_range = [1.0, 2.0], [1.0, 1.1]
+    steps = np.concatenate([np.linspace(0, 620000, n - 4).astype(np.int64), [1, 499999, 500000, 500001]])
+    out = np.zeros((n, 2), np.float32)
+    u, z = np.zeros(n, np.float32), np.zeros(n, np.float32)
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")  # torch.tensor(tensor) copy-construct warning of :611
+        for i, st in enumerate(steps):
+            S.sim_steps = torch.tensor([int(st)])
+            torch.manual_seed(5000 + i)
+            u[i] = torch.rand(1)[0]; z[i] = torch.randn(1)[0]
+            torch.manual_seed(5000 + i)
+            a, b = fn(S, 0)
+            out[i] = [float(a), float(b)]
+    return {"sim_steps": steps.astype(np.int32), "max_sim_steps": np.float32(S.max_sim_steps), "x_range": np.array(S.command_x_range, np.float32),
+            "u_side": u, "z": z, "commands": out}
+
+
 # ------------------------------------------------------------------ GAE ------------------------
 def gae_case():
     from tests.golden.make_golden import refmath_gae
@@ -440,6 +467,7 @@ def main():
     lc = level_commands_case()
     save("refexec_level_commands.npz", lc)
     save("refexec_eval_commands.npz", eval_commands_case())
+    save("refexec_grid_commands.npz", grid_commands_case())
     save("refexec_gae.npz", gae_case())
     save("refexec_terrain.npz", terrain_cases())
     save("refexec_config.npz", config_cases())

@@ -347,3 +347,16 @@ def test_episode_statistics_of_the_hip_path_against_the_executed_agent_bookkeepi
         def step(a):
             env.step(torch.from_numpy(a).cuda())
     _check_returns(*_returns_run(Adapter, lambda t: t.cpu().numpy()))
+
+
+def test_grid_sampler_against_the_executed_reference(oracle_lib):
+    """KAMMA_curr2.py:600-640 executed; the fixture holds the uniform and the standard normal behind every draw (same
+    seed replayed), so the bimodal formula is compared exactly: float32 progress, means, z * 0.05 + mean, max(., 0)."""
+    d = np.load(os.path.join(G, "refexec_grid_commands.npz"))
+    lo, hi = (float(v) for v in d["x_range"])
+    got = np.array([oracle_lib.orc_grid_command(int(s), float(d["max_sim_steps"]), lo, hi, float(u), float(z))
+                    for s, u, z in zip(d["sim_steps"], d["u_side"], d["z"])], np.float32)
+    assert np.array_equal(got, d["commands"][:, 0]) and not d["commands"][:, 1].any()
+    late = d["sim_steps"] >= 500000                      # progress clamps at 1: the modes sit on the range ends
+    assert (np.abs(got[late] - np.where(d["u_side"][late] < 0.5, lo, hi)) < 0.3).all()
+    assert (d["u_side"] < 0.5).sum() > 20 and (d["u_side"] >= 0.5).sum() > 20
