@@ -216,6 +216,11 @@ def build_config(task_cfg: Optional[Dict[str, Any]] = None, variant: str = "KAMM
     for k, v in var.items():
         setattr(c, k, v)
     if terrain.get("curriculum"):  # sample_velocity_command tests self.curriculum first (KAMMA.py:533)
+        if c.cmd_sampler == _abi.CMD_EVAL:
+            # the *_eval files test self.evalsampling BEFORE self.curriculum (KAMMA_eval.py:544), so there the per-step
+            # re-draw of the curriculum (:719-725) yields the eval ramp: a combination no script uses and the kernels
+            # do not implement
+            raise ValueError("terrain.curriculum with EvalSampling is not supported")
         c.cmd_sampler = _abi.CMD_LEVEL
     c.curriculum_threshold_high = 10.0                            # KAMMA.py:269
 

@@ -82,27 +82,53 @@ SCRIPT_OVERRIDES = {"stiffness": 0.035, "damping": 0.005, "static_friction": 0.8
                     "yaw_constant": 0.5, "linear_x": [1.0, 2.0], "numEnvs": 1}
 
 
+def _leaves(d, path=""):
+    if isinstance(d, dict):
+        for k in sorted(d):
+            yield from _leaves(d[k], path + "/" + k)
+    else:
+        yield path, d
+
+
+def _apply_overrides(cfg):
+    import copy
+    run, o = copy.deepcopy(cfg), SCRIPT_OVERRIDES
+    run["task"]["env"]["control"]["stiffness"], run["task"]["env"]["control"]["damping"] = o["stiffness"], o["damping"]
+    run["task"]["sim"]["default_physics_material"]["static_friction"] = o["static_friction"]
+    run["task"]["sim"]["default_physics_material"]["dynamic_friction"] = o["dynamic_friction"]
+    run["task"]["env"]["randomCommandVelocityRanges"]["yaw_constant"] = o["yaw_constant"]
+    run["task"]["env"]["randomCommandVelocityRanges"]["linear_x"] = o["linear_x"]
+    return run
+
+
 def config_cases():
     """the module-level TASK_CFG literal of every env file (ast.literal_eval) and what update_config (KAMMA.py:231-275)
-    derives from it once the scripts' overrides are in"""
-    import copy
+    derives from it once the scripts' overrides are in. Stored: a digest of KAMMA.py's literal (with the overrides, without
+    the keys default_task_cfg() does not carry, which are listed), the leaves in which each variant's literal differs from
+    it, and update_config's results — not the literal itself."""
     import json
-    out = {}
+    from options_in_simulation_amd import default_task_cfg
+    out, lits = {}, {}
     for name in VARIANT_FILES:
         rel = f"my_envs/{name}.py"
         tree = ast.parse(open(os.path.join(REF, rel)).read())
         node = next(n for n in tree.body if isinstance(n, ast.Assign) and getattr(n.targets[0], "id", None) == "TASK_CFG")
-        cfg = ast.literal_eval(node.value)
-        out[name + "__task_cfg_json"] = np.array(json.dumps(cfg, sort_keys=True))
-        run = copy.deepcopy(cfg)
-        o = SCRIPT_OVERRIDES
-        run["task"]["env"]["numEnvs"] = o["numEnvs"]
-        run["task"]["env"]["control"]["stiffness"], run["task"]["env"]["control"]["damping"] = o["stiffness"], o["damping"]
-        run["task"]["sim"]["default_physics_material"]["static_friction"] = o["static_friction"]
-        run["task"]["sim"]["default_physics_material"]["dynamic_friction"] = o["dynamic_friction"]
-        run["task"]["env"]["randomCommandVelocityRanges"]["yaw_constant"] = o["yaw_constant"]
-        run["task"]["env"]["randomCommandVelocityRanges"]["linear_x"] = o["linear_x"]
-        fn, _ = extract(rel, "TorqueDistributionTask", "update_config")
+        lits[name] = ast.literal_eval(node.value)
+    base = dict(_leaves(_apply_overrides(lits["KAMMA"])))
+    mine = dict(_leaves(default_task_cfg()))
+    dropped = sorted(set(base) - set(mine))
+    kept = {k: v for k, v in base.items() if k in mine}
+    out["kamma_leaf_count"] = np.int64(len(kept))
+    out["kamma_dropped_paths"] = np.array(dropped)
+    out["kamma_sha256"] = np.array(hashlib.sha256(json.dumps(kept, sort_keys=True).encode()).hexdigest())
+    for name in VARIANT_FILES:
+        lv = dict(_leaves(lits[name]))
+        l0 = dict(_leaves(lits["KAMMA"]))
+        diff = {k: lv.get(k, "<absent>") for k in sorted(set(lv) | set(l0)) if lv.get(k, "<absent>") != l0.get(k, "<absent>")}
+        out[name + "__diff_json"] = np.array(json.dumps(diff, sort_keys=True))
+        run = _apply_overrides(lits[name])
+        run["task"]["env"]["numEnvs"] = SCRIPT_OVERRIDES["numEnvs"]
+        fn, _ = extract(f"my_envs/{name}.py", "TorqueDistributionTask", "update_config")
         S = types.SimpleNamespace()
         fn(S, types.SimpleNamespace(config=run, task_config=run["task"]))
         derived = {k: getattr(S, k) for k in ("action_scale", "command_x_range", "command_y_range", "command_yaw_range", "yaw_constant",

@@ -189,54 +189,48 @@ VARIANT_FILES = ["KAMMA", "KAMMA_medium", "KAMMA_g11_g21", "KAMMA_g1d_g21", "KAM
                  "KA_DDPG_4D", "KA_DDPG_2D", "KA_DDPG_1D", "KA_DDPG_2D_eval", "KA_DDPG_1D_eval"]
 
 
-def _with_script_overrides(cfg, o):
-    """what the train / eval scripts write into TASK_CFG before building the task (train_kamma_4d_nofifo_random_RLIL.py:79-91)"""
-    import copy
-    run = copy.deepcopy(cfg)
-    run["task"]["env"]["numEnvs"] = o["numEnvs"]
-    run["task"]["env"]["control"]["stiffness"], run["task"]["env"]["control"]["damping"] = o["stiffness"], o["damping"]
-    run["task"]["sim"]["default_physics_material"]["static_friction"] = o["static_friction"]
-    run["task"]["sim"]["default_physics_material"]["dynamic_friction"] = o["dynamic_friction"]
-    run["task"]["env"]["randomCommandVelocityRanges"]["yaw_constant"] = o["yaw_constant"]
-    run["task"]["env"]["randomCommandVelocityRanges"]["linear_x"] = o["linear_x"]
-    return run
+def _leaves(d, path=""):
+    if isinstance(d, dict):
+        for k in sorted(d):
+            yield from _leaves(d[k], path + "/" + k)
+    else:
+        yield path, d
+
+
+def _set_leaf(cfg, path, value):
+    keys = path.strip("/").split("/")
+    for k in keys[:-1]:
+        cfg = cfg.setdefault(k, {})
+    cfg[keys[-1]] = value
 
 
 def test_default_task_cfg_is_the_reference_literal_with_the_scripts_overrides():
-    """default_task_cfg() against the TASK_CFG literal of KAMMA.py:29-128 (ast.literal_eval of the reference's file) after
-    the scripts' argparse defaults are written into it; PhysX GPU buffer sizes are the only keys not carried."""
+    """default_task_cfg() against the TASK_CFG literal of KAMMA.py:29-128 (ast.literal_eval of the reference's file at
+    fixture time, the scripts' argparse defaults written in): the digest over all shared leaves is the same, and the only
+    leaves not carried are PhysX's GPU buffer sizes."""
     import json
     from options_in_simulation_amd import default_task_cfg
     d = np.load(os.path.join(G, "refexec_config.npz"))
-    lit = json.loads(str(d["KAMMA__task_cfg_json"]))
-    ref = _with_script_overrides(lit, json.loads(str(d["script_overrides_json"])))
-    ref["task"]["env"]["numEnvs"] = lit["task"]["env"]["numEnvs"]  # the literal's; every script then forces 1
-    mine = default_task_cfg()
-    dropped = []
-
-    def walk(a, b, path):
-        assert isinstance(a, dict) == isinstance(b, dict), path
-        if not isinstance(a, dict):
-            assert a == b, (path, a, b)
-            return
-        for k in a:
-            if k not in b:
-                dropped.append(path + "/" + k)
-            else:
-                walk(a[k], b[k], path + "/" + k)
-        assert not (set(b) - set(a)), (path, set(b) - set(a))  # nothing invented
-    walk(ref, mine, "")
+    mine = dict(_leaves(default_task_cfg()))
+    assert len(mine) == int(d["kamma_leaf_count"])
+    assert hashlib.sha256(json.dumps(mine, sort_keys=True).encode()).hexdigest() == str(d["kamma_sha256"])
+    dropped = [str(p) for p in d["kamma_dropped_paths"]]
     assert dropped and all(p.startswith("/task/sim/physx/gpu_") for p in dropped), dropped
 
 
 @pytest.mark.parametrize("name", VARIANT_FILES)
 def test_build_config_derives_what_update_config_derives(name):
-    """update_config (KAMMA.py:231-275 and the same method of the 11 other env files) EXECUTED on each file's own TASK_CFG:
-    dt, max_episode_length = int(10 / 0.1 + 0.5), Kp, ranges, init state, sampler flags — against build_config(variant)."""
+    """update_config (KAMMA.py:231-275 and the same method of the 11 other env files) EXECUTED on each file's own TASK_CFG
+    (the fixture holds the leaves in which it differs from KAMMA.py's, and the results): dt, max_episode_length =
+    int(10 / 0.1 + 0.5), Kp, ranges, init state, sampler flags — against build_config(variant) on the same dict."""
     import json
-    from options_in_simulation_amd import build_config
+    from options_in_simulation_amd import build_config, default_task_cfg
     d = np.load(os.path.join(G, "refexec_config.npz"))
-    cfg = _with_script_overrides(json.loads(str(d[name + "__task_cfg_json"])), json.loads(str(d["script_overrides_json"])))
+    cfg = default_task_cfg()
+    for path, v in json.loads(str(d[name + "__diff_json"])).items():
+        assert v != "<absent>", path
+        _set_leaf(cfg, path, v)
+    cfg["task"]["env"]["numEnvs"] = json.loads(str(d["script_overrides_json"]))["numEnvs"]
     r = json.loads(str(d[name + "__derived_json"]))
     c = build_config(task_cfg=cfg, variant=name)
     assert c.num_envs == r["_num_envs"] == 1
@@ -257,38 +251,6 @@ def test_build_config_derives_what_update_config_derives(name):
     sampler = (_abi.CMD_LEVEL if r["curriculum"] else _abi.CMD_EVAL if r["evalsampling"] else _abi.CMD_RAND if r["randsampling"]
                else _abi.CMD_BOX if r["boxsampling"] else _abi.CMD_GRID if r["gridsampling"] else None)
     assert c.cmd_sampler == sampler, (name, r)
-
-
-def test_artefact_files_equal_what_the_reference_cli_functions_write(tmp_path):
-    """The reference's own artefact helpers (artifacts.py _collect_timeseries / _write_csv, eval_artifacts.py _get_series /
-    _align_by_step / _moving_average) were run over an event file of the build (fixture). Here the same scalars go through
-    EventFileWriter again and the build's writers must produce the same CSV text and series: a gap in one tag becomes
-    `nan`, a step missing on the tracking-error side is dropped by the left join, values are the event file's float32s."""
-    import csv
-    from options_in_simulation_amd import tracking
-    d = np.load(os.path.join(G, "refexec_artifacts.npz"))
-    cols = tracking.CSV_COLUMNS
-    w = tracking.EventFileWriter(str(tmp_path))
-    for i, st in enumerate(d["steps"]):
-        sc = {f"Reward_comp_env0 / {c}": float(d["value_" + c][i]) for c in cols if not (c == "current_v" and i == 4)}
-        if i != 7:
-            sc["Info / rew_Tracking error"] = float(d["tracking_error"][i])
-        sc["Info / rew_Desired velocity"] = float(d["desired_velocity"][i])
-        w.add_scalars(sc, int(st))
-    w.close()
-    ev = [str(p) for p in tmp_path.iterdir() if "tfevents" in p.name][0]
-    out = tracking.write_timeseries_csv(ev)
-    assert open(out).read() == str(d["timeseries_csv"])
-    assert "nan" in str(d["timeseries_csv"]).splitlines()[5]
-    xs, ys = tracking.write_tracking_error_vs_speed(ev)
-    assert np.array_equal(np.array(xs), d["speed"]) and np.array_equal(np.array(ys), d["tracking_error_aligned"])
-    assert len(xs) == len(d["steps"]) - 1
-    xs, ys = tracking.write_tracking_error_vs_speed(ev, smooth=4)
-    assert np.array_equal(np.array(ys), d["tracking_error_smooth4"])
-    rows = list(csv.reader(open(os.path.join(str(tmp_path), "tracking_error_vs_speed.csv"))))
-    assert rows[0] == ["speed_m_s", "tracking_error_m_s"] and [float(r[1]) for r in rows[1:]] == list(d["tracking_error_smooth4"])
-    # the tracker's live CSV rows carry the same float32 values the CLI would read back
-    assert tracking._as_f32(0.1) == float(np.float32(0.1))
 
 
 RETURNS_SPEC = dict(variant="KAMMA_medium", n=24, steps=210, seed=13)
