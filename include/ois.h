@@ -92,7 +92,9 @@ extern "C" {
 #define OIS_CMD_LEVEL 4 /* terrain.curriculum: the per-terrain-level generators of sample_velocity_command
                            (KAMMA.py:533-567), re-drawn for EVERY arena after EVERY step (KAMMA.py:719-725) and
                            not at a reset (KAMMA.py:490). Also switched on by ois_terrain_attach with
-                           curriculum != 0. Costs one small extra launch per policy step. */
+                           curriculum != 0. Costs one small extra launch per policy step. Not with OIS_CMD_EVAL:
+                           the *_eval files test evalsampling first (KAMMA_eval.py:544); attaching such a terrain to an
+                           EVAL environment is OIS_EINVAL. */
 
 /* rollout policies */
 #define OIS_POLICY_ZERO 0     /* actions == 0                                  */

@@ -1408,6 +1408,8 @@ int ois_terrain_attach(ois_env* e, const ois_terrain* t, const int16_t* heights_
       !levels_types_host)
     return fail(OIS_EINVAL, "bad terrain description");
   if (e->lpa_forced == 2) return fail(OIS_EINVAL, "the terrain contact needs one lane per arena (unset OIS_LANES_PER_ARENA)");
+  // the *_eval files test evalsampling before curriculum (KAMMA_eval.py:544): their per-step re-draw would be the eval ramp
+  if (t->curriculum && e->cfg.cmd_sampler == OIS_CMD_EVAL) return fail(OIS_EINVAL, "terrain.curriculum with the EvalSampling commands is not supported");
   size_t mf[3];
   if (minfield_layout(t->rows, t->cols, mf) >= ((size_t)1 << 31)) return fail(OIS_EINVAL, "height field too large (the kernels address it with 32-bit byte offsets)");
   if (((uintptr_t)minfield_device & 255u) != 0) return fail(OIS_EINVAL, "the min-field scratch must be 256-byte aligned");

@@ -1412,6 +1412,8 @@ int orc_terrain_attach(orc_env* e, const ois_terrain* t, const int16_t* heights,
   memset(e->env_origins, 0, (size_t)e->N * 4 * sizeof(float));
   memset(e->terrain_idx, 0, (size_t)e->N * 4 * sizeof(int32_t));
   if (!t) return OIS_OK;
+  if (t->curriculum && e->cfg.cmd_sampler == OIS_CMD_EVAL) /* KAMMA_eval.py:544: evalsampling is tested before curriculum */
+    return fail(OIS_EINVAL, "terrain.curriculum with the EvalSampling commands is not supported");
   if (t->struct_bytes != sizeof(ois_terrain)) return fail(OIS_EINVAL, "ois_terrain.struct_bytes mismatch");
   if (t->rows < 2 || t->cols < 2 || !(t->horizontal_scale > 0.0f) || t->num_levels < 1 || t->num_types < 1 ||
       t->max_level < 0 || t->max_level >= t->num_levels || !heights || !terrain_origins || !levels_types)

@@ -230,3 +230,17 @@ def test_level_curriculum_without_terrain_and_task_surface():
     assert np.array_equal(env.task.fraction.cpu().numpy(), orc.buffer(_abi.BUF_CMD_FRACTION))
     assert not env.task.commands[:, 0].any() and (env.task.commands[:, 2] > 0).all()
     env.close()
+
+
+def test_eval_sampling_refuses_a_curriculum_terrain():
+    """the *_eval files test `evalsampling` before `curriculum` (KAMMA_eval.py:544): with both set the per-step re-draw of
+    KAMMA.py:719-725 would hand out the eval ramp, which nothing here implements: refused, not silently different"""
+    from options_in_simulation_amd import default_task_cfg
+    cfg = default_task_cfg()
+    cfg["task"]["env"]["terrain"]["curriculum"] = True
+    with pytest.raises(ValueError, match="EvalSampling"):
+        build_config(task_cfg=cfg, variant="KAMMA_eval")
+    env = OracleEnv(build_config(variant="KAMMA_eval", num_envs=4, seed=1))
+    T = tg.Terrain({"curriculum": True, "numLevels": 3, "numTerrains": 2, "mapLength": 8.0, "mapWidth": 8.0}, 4, seed=0)
+    with pytest.raises(RuntimeError, match="EvalSampling"):
+        env.attach_terrain(T, np.zeros((4, 2), np.int32), curriculum=True)
