@@ -132,6 +132,38 @@ def test_full_size_properties(N):
     assert float(a.episode_info()[_abi.EI_COUNT]) == N
 
 
+def test_config5_partition_at_full_size_on_one_gpu():
+    """BASELINE.json configs[4]: 524 288 arenas as 8 shards of 65 536 (arena_offset = rank * 65 536). One GPU here, so:
+    the whole range as ONE environment (two waves per SIMD: the 256-register shell) against shards 0, 3 and 7 as
+    environments of their own (one lane per arena, default registers) — every buffer of a shard bit-identical to its
+    slice of the whole, across the synchronous timeout; and the shards' statistics merge (dist.merge_stats) to the whole's."""
+    from options_in_simulation_amd.dist import merge_stats
+    from options_in_simulation_amd.vecenv import NativeEnv
+    per, world = 65536, 8
+    kw = dict(variant="KAMMA_medium", seed=19, max_sim_steps=200.0)
+    whole = NativeEnv(build_config(num_envs=per * world, **kw), "cuda:0")
+    whole.reset(19)
+    K = 100
+    whole.rollout(K, _abi.POLICY_RANDOM)
+    parts = []
+    for r in range(world):
+        sh = NativeEnv(build_config(num_envs=per, arena_offset=r * per, **kw), "cuda:0")
+        sh.reset(19)
+        sh.rollout(K, _abi.POLICY_RANDOM)
+        torch.cuda.synchronize()
+        if r in (0, 3, 7):
+            for bid in (_abi.BUF_POSE, _abi.BUF_QUAT, _abi.BUF_LINVEL, _abi.BUF_ANGVEL, _abi.BUF_WHEEL_VEL, _abi.BUF_COMMANDS,
+                        _abi.BUF_COUNTERS, _abi.BUF_SUMS_A, _abi.BUF_SUMS_B, _abi.BUF_OBS, _abi.BUF_REW, _abi.BUF_DONE):
+                assert torch.equal(sh.buffer(bid), whole.buffer(bid)[r * per:(r + 1) * per]), (r, bid)
+        parts.append(sh.stats())
+        sh.close()
+    m, w = merge_stats(parts), whole.stats()
+    assert m["episodes"] == w.episodes == per * world and m["steps"] == w.steps
+    assert m["return_min"] == w.return_min and m["return_max"] == w.return_max
+    assert m["return_mean"] == pytest.approx(w.return_sum / w.episodes, rel=1e-12)
+    assert m["return_std"] == pytest.approx((w.return_sqsum / w.episodes - (w.return_sum / w.episodes) ** 2) ** 0.5, rel=1e-9)
+
+
 def test_capture_with_a_transition_memory_attached_is_refused():
     """graph replays do not advance the host-side replay cursor — so such a capture is refused
     instead of silently writing one memory row over and over"""
