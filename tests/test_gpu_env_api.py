@@ -132,6 +132,40 @@ def test_full_size_properties(N):
     assert float(a.episode_info()[_abi.EI_COUNT]) == N
 
 
+def test_config2_in_kernel_random_policy_equals_host_generated_actions():
+    """BASELINE.json configs[1]: 4 096 arenas, gamma = 0, actions ~ U[0,1)^4 from Philox(seed, arena,
+    step) generated in the kernel (policy = RANDOM) — and the same values generated on the host, handed over as EXTERNAL
+    actions: identical runs. The host side is the published Philox4x32-10 (the oracle's, pinned by Random123's known
+    answers): counter (arena lo, arena hi, step, purpose 3), key = seed, u = (x >> 8) * 2^-24."""
+    import ctypes as C
+    from options_in_simulation_amd.vecenv import NativeEnv
+    from oracle.binding import lib
+    N, K, seed = 4096, 24, 42
+    kw = dict(variant="KAMMA_medium", num_envs=N, seed=seed, gamma1_mode=_abi.GAMMA_CONST, gamma1_const=0.0,
+              gamma2_mode=_abi.GAMMA_CONST, gamma2_const=0.0)
+    a, b = NativeEnv(build_config(**kw), "cuda:0"), NativeEnv(build_config(**kw), "cuda:0")
+    a.reset(seed); b.reset(seed)
+    L = lib()
+    acts = np.zeros((K, N, 4), np.float32)
+    ctr, key, out = (C.c_uint32 * 4)(), (C.c_uint32 * 2)(seed & 0xffffffff, seed >> 32), (C.c_uint32 * 4)()
+    for s in range(K):
+        for i in range(N):
+            ctr[0], ctr[1], ctr[2], ctr[3] = i, 0, s, 3
+            L.orc_philox4x32_10(ctr, key, out)
+            acts[s, i] = [(x >> 8) * 2.0 ** -24 for x in out]
+    assert 0.0 <= acts.min() and acts.max() < 1.0 and abs(acts.mean() - 0.5) < 0.01
+    ra, rb = torch.zeros(N, device="cuda"), torch.zeros(N, device="cuda")
+    a.rollout(K, _abi.POLICY_RANDOM, reward_sum=ra)
+    b.rollout(K, _abi.POLICY_EXTERNAL, torch.from_numpy(acts).cuda(), reward_sum=rb)
+    torch.cuda.synchronize()
+    for bid in (_abi.BUF_POSE, _abi.BUF_QUAT, _abi.BUF_LINVEL, _abi.BUF_ANGVEL, _abi.BUF_WHEEL_VEL, _abi.BUF_WHEEL_TORQS,
+                _abi.BUF_SUMS_A, _abi.BUF_SUMS_B, _abi.BUF_OBS, _abi.BUF_REW, _abi.BUF_COUNTERS):
+        assert torch.equal(a.buffer(bid), b.buffer(bid)), bid
+    assert torch.equal(ra, rb)
+    wt = a.buffer(_abi.BUF_WHEEL_TORQS).cpu().numpy()     # gamma = 0: the executed torques ARE the policy's, a * 3 (clip at 4 idle)
+    assert np.array_equal(wt, acts[K - 1] * np.float32(3.0))
+
+
 def test_config5_partition_at_full_size_on_one_gpu():
     """BASELINE.json configs[4]: 524 288 arenas as 8 shards of 65 536 (arena_offset = rank * 65 536). One GPU here, so:
     the whole range as ONE environment (two waves per SIMD: the 256-register shell) against shards 0, 3 and 7 as
