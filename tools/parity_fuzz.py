@@ -46,6 +46,8 @@ for variant in sorted(VARIANTS):
             os.environ["OIS_LANES_PER_ARENA"] = "2" if shell == "pair" else "1"  # by size it would be the pair at this N
             if ground.startswith("field") and shell != "1":
                 continue  # the terrain kernels have one shell
+            if ground.endswith("curriculum") and VARIANTS[variant].get("cmd_sampler") == _abi.CMD_EVAL:
+                continue  # EvalSampling with a curriculum terrain is refused (KAMMA_eval.py:544 tests evalsampling first)
             seed = 100 + cases
             cfg = build_config(variant=variant, num_envs=N, seed=seed, max_sim_steps=float(STEPS))
             dev, orc = NativeEnv(cfg, "cuda:0"), OracleEnv(cfg, threads=16)
