@@ -55,6 +55,26 @@ EPISODE_INFO_ZERO_KEYS = (
 )
 
 
+# the KA-DDPG files keep ONE assist factor and log it under one key (KA_DDPG_4D.py:487; 1D / 2D and their eval twins alike)
+EPISODE_INFO_SINGLE_GAMMA_KEY = "gamma assist"
+
+
+def episode_info_items(vec, eval_keys: bool, single_gamma: bool):
+    """(key, value) pairs of extras["episode"] (KAMMA.py:480-488) from the 32-slot vector of OIS_BUF_EPISODE_INFO, in the
+    key set of the reference file the variant stands for: `vec` is anything indexable (numpy row, 1-D tensor)."""
+    for slot, key in EPISODE_INFO_KEYS.items():
+        if single_gamma and slot in (16, 17):
+            continue
+        yield key, vec[slot]
+    if single_gamma:
+        yield EPISODE_INFO_SINGLE_GAMMA_KEY, vec[16]
+    for key in EPISODE_INFO_ZERO_KEYS:
+        yield key, vec[31]  # never written by the reference: 0
+    if eval_keys:
+        for slot, key in EPISODE_INFO_EVAL_KEYS.items():
+            yield key, vec[slot]
+
+
 class OisConfig(C.Structure):
     _fields_ = [
         ("struct_bytes", C.c_uint32),

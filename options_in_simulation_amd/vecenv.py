@@ -306,9 +306,10 @@ class _LazyEpisodeInfo(dict):
     tensors); with ``on_host`` (default) the 32-float vector comes over in ONE copy and the
     values are 0-dim CPU tensors, whose ``.item()`` is free."""
 
-    def __init__(self, native: NativeEnv, eval_keys: bool, on_host: bool = True):
+    def __init__(self, native: NativeEnv, eval_keys: bool, on_host: bool = True, single_gamma: bool = False):
         super().__init__()
         self._native, self._eval, self._done, self._on_host = native, eval_keys, False, on_host
+        self._single_gamma = single_gamma
         self._epoch = native.epoch  # the step this dict belongs to
 
     def _materialize(self):
@@ -324,13 +325,8 @@ class _LazyEpisodeInfo(dict):
             self._native._infos_read = True  # tells observed_components to fetch both blocks at once from now on
         else:
             vec = self._native.episode_info().clone()
-        for slot, key in _abi.EPISODE_INFO_KEYS.items():
-            dict.__setitem__(self, key, vec[slot])
-        for key in _abi.EPISODE_INFO_ZERO_KEYS:
-            dict.__setitem__(self, key, vec[31])  # never written by the reference: 0
-        if self._eval:
-            for slot, key in _abi.EPISODE_INFO_EVAL_KEYS.items():
-                dict.__setitem__(self, key, vec[slot])
+        for key, value in _abi.episode_info_items(vec, self._eval, self._single_gamma):
+            dict.__setitem__(self, key, value)
 
     def __getitem__(self, k): self._materialize(); return dict.__getitem__(self, k)
     def __iter__(self): self._materialize(); return dict.__iter__(self)
@@ -547,12 +543,14 @@ class TorqueDistributionTask:
     def post_reset(self, seed: Optional[int] = None):
         """KAMMA.py:366-414"""
         self.native.reset(seed)
-        self.extras = {"episode": _LazyEpisodeInfo(self.native, bool(self.cfg_native.eval_sums), self.infos_on_host)}
+        self.extras = {"episode": _LazyEpisodeInfo(self.native, bool(self.cfg_native.eval_sums), self.infos_on_host,
+                                                    single_gamma=self.cfg_native.mix_mode == _abi.MIX_BLEND)}
 
     def step(self, actions: torch.Tensor):
         """pre_physics_step + substeps + post_physics_step (KAMMA.py:596-727) in one launch"""
         self.native.step(actions)
-        self.extras = {"episode": _LazyEpisodeInfo(self.native, bool(self.cfg_native.eval_sums), self.infos_on_host)}
+        self.extras = {"episode": _LazyEpisodeInfo(self.native, bool(self.cfg_native.eval_sums), self.infos_on_host,
+                                                    single_gamma=self.cfg_native.mix_mode == _abi.MIX_BLEND)}
         return self.obs_buf, self.rew_buf, self.reset_buf, self.extras
 
     def close(self):

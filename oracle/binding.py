@@ -26,6 +26,15 @@ def build(force: bool = False) -> str:
 
 _lib = None
 
+RESET_U_STRIDE = 12   # ORC_RESET_U_STRIDE
+PHYSICS_STRIDE = 20   # ORC_PHYSICS_STRIDE
+
+
+class ReplayHooks(C.Structure):
+    """orc_test_hooks (oracle/ois_oracle.h): fixture replay of the reference's draws and of the simulator's outcome"""
+    _fields_ = [("switch_u", C.POINTER(C.c_float)), ("reset_u", C.POINTER(C.c_float)), ("physics_in", C.POINTER(C.c_float)),
+                ("physics_out", C.POINTER(C.c_float))]
+
 
 def lib() -> C.CDLL:
     global _lib
@@ -69,6 +78,9 @@ def lib() -> C.CDLL:
         L.orc_metrics.restype = None
         L.orc_grid_command.argtypes = [C.c_int32, C.c_float, C.c_float, C.c_float, C.c_float, C.c_float]
         L.orc_grid_command.restype = C.c_float
+        L.orc_box_bounds.argtypes = [C.c_int32, C.c_float, C.c_float, C.c_float, fp, fp]
+        L.orc_box_bounds.restype = None
+        L.orc_test_set_hooks.argtypes = [C.c_void_p, C.POINTER(ReplayHooks)]
         L.orc_eval_command.argtypes = [C.c_int32, C.c_float]
         L.orc_eval_command.restype = C.c_float
         L.orc_eval_sums.argtypes = [C.c_int, fp, fp, fp, fp, fp]
@@ -216,6 +228,20 @@ class OracleEnv:
 
     def push_robots(self):
         self._check(self.L.orc_push_robots(self.h))
+
+    def set_hooks(self, switch_u=None, reset_u=None, physics_in=None, physics_out=None):
+        """orc_test_set_hooks: float32 arrays [N], [N, 12], [N, 20], [N, 20] that the env reads (writes: physics_out) at
+        every reset / step until replaced; the arrays are kept alive here. No argument clears the hooks."""
+        shapes = {"switch_u": (self.N,), "reset_u": (self.N, RESET_U_STRIDE), "physics_in": (self.N, PHYSICS_STRIDE),
+                  "physics_out": (self.N, PHYSICS_STRIDE)}
+        given = {"switch_u": switch_u, "reset_u": reset_u, "physics_in": physics_in, "physics_out": physics_out}
+        h = ReplayHooks()
+        for k, a in given.items():
+            if a is not None:
+                assert a.dtype == np.float32 and a.flags.c_contiguous and a.shape == shapes[k], (k, a.shape, a.dtype)
+                setattr(h, k, fptr(a))
+        self._hooks = (h, given)
+        self._check(self.L.orc_test_set_hooks(self.h, C.byref(h) if any(a is not None for a in given.values()) else None))
 
     def randomize_params(self, mu_lo, mu_hi, slopes=()):
         s = np.asarray(slopes, np.float32)

@@ -406,6 +406,15 @@ void orc_reset_draws(const ois_config* cfg, const float u[8], float pos3[3], flo
 /* KAMMA_curr2.py:602-626 (GridSampling): a bimodal normal (sigma 0.05) whose two means move from the centre of the
  * command range to its ends with progress = min(1, sim_steps / max_sim_steps); u_side < 0.5 picks the left mode;
  * torch.normal(mean=Tensor, std=Tensor) = z * std + mean in float32 */
+/* BoxSampling bounds (KAMMA_curr1.py:579-591): the range opens from 10 % to all of [lo, hi] around its centre */
+void orc_box_bounds(int32_t sim_steps, float max_sim_steps, float lo, float hi, float* xmin, float* xmax) {
+  float progress = fminf(1.0f, (float)sim_steps / max_sim_steps);
+  float factor = 0.1f + (1.0f - 0.1f) * progress;
+  float xc = (lo + hi) / 2.0f;
+  *xmin = xc - (xc - lo) * factor;
+  *xmax = xc + (hi - xc) * factor;
+}
+
 float orc_grid_command(int32_t sim_steps, float max_sim_steps, float lo, float hi, float u_side, float z) {
   float progress = fminf(1.0f, (float)sim_steps / max_sim_steps);
   float xc = (lo + hi) / 2.0f;
@@ -820,6 +829,7 @@ struct orc_env {
   float *rp_states, *rp_actions, *rp_rewards, *rp_next;
   uint8_t* rp_done;
   int rp_size, rp_head, rp_filled;
+  orc_test_hooks hooks; /* fixture replay (orc_test_set_hooks); all NULL in normal use */
 };
 
 static void* zalloc(size_t n) { return calloc(n ? n : 1, 1); }
@@ -879,6 +889,12 @@ int orc_set_threads(orc_env* e, int threads) {
   if (threads != 1) return fail(OIS_EINVAL, "oracle built without OpenMP");
 #endif
   e->threads = threads;
+  return OIS_OK;
+}
+
+int orc_test_set_hooks(orc_env* e, const orc_test_hooks* h) {
+  if (!e) return fail(OIS_EINVAL, "null env");
+  if (h) e->hooks = *h; else memset(&e->hooks, 0, sizeof e->hooks);
   return OIS_OK;
 }
 
@@ -974,8 +990,12 @@ static void reset_arena(orc_env* e, int i, uint32_t step_ctr, float gamma2, rese
 
   float u[8];
   int64_t gid = c->arena_offset + i;
-  draw4(e->seed, gid, step_ctr, PURPOSE_RESET_A, &u[0]);
-  draw4(e->seed, gid, step_ctr, PURPOSE_RESET_B, &u[4]);
+  if (e->hooks.reset_u) {
+    memcpy(u, &e->hooks.reset_u[(size_t)ORC_RESET_U_STRIDE * i], sizeof u);
+  } else {
+    draw4(e->seed, gid, step_ctr, PURPOSE_RESET_A, &u[0]);
+    draw4(e->seed, gid, step_ctr, PURPOSE_RESET_B, &u[4]);
+  }
   float pos[3], q[4], cmd[4];
   orc_reset_draws(c, u, pos, q, cmd);
   if (level_mode(e)) {
@@ -987,11 +1007,8 @@ static void reset_arena(orc_env* e, int i, uint32_t step_ctr, float gamma2, rese
     cmd[2] = e->commands[4 * i + 2] * keep;
   } else if (c->cmd_sampler == OIS_CMD_BOX) {
     /* KAMMA_curr1.py:577-598 */
-    float progress = fminf(1.0f, (float)cnt[1] / c->max_sim_steps);
-    float factor = 0.1f + (1.0f - 0.1f) * progress;
-    float xc = (c->cmd_x_lo + c->cmd_x_hi) / 2.0f;
-    float xmin = xc - (xc - c->cmd_x_lo) * factor;
-    float xmax = xc + (c->cmd_x_hi - xc) * factor;
+    float xmin, xmax;
+    orc_box_bounds(cnt[1], c->max_sim_steps, c->cmd_x_lo, c->cmd_x_hi, &xmin, &xmax);
     float xv = rand_float(xmin, xmax, u[6]);
     cmd[0] = xv > 0.0f ? xv : 0.0f;
   } else if (c->cmd_sampler == OIS_CMD_EVAL) {
@@ -999,9 +1016,14 @@ static void reset_arena(orc_env* e, int i, uint32_t step_ctr, float gamma2, rese
   } else if (c->cmd_sampler == OIS_CMD_GRID) {
     /* KAMMA_curr2.py:602-640; u[6] picks the side (torch.rand(1) < 0.5), a third Philox block feeds the normal
      * draw (the omega draw of :631-636 is discarded) */
-    float uc[4];
-    draw4(e->seed, gid, step_ctr, PURPOSE_RESET_C, uc);
-    cmd[0] = orc_grid_command(cnt[1], c->max_sim_steps, c->cmd_x_lo, c->cmd_x_hi, u[6], normal_det(uc[0], uc[1]));
+    float uc[4], z;
+    if (e->hooks.reset_u) {
+      z = e->hooks.reset_u[(size_t)ORC_RESET_U_STRIDE * i + 8];
+    } else {
+      draw4(e->seed, gid, step_ctr, PURPOSE_RESET_C, uc);
+      z = normal_det(uc[0], uc[1]);
+    }
+    cmd[0] = orc_grid_command(cnt[1], c->max_sim_steps, c->cmd_x_lo, c->cmd_x_hi, u[6], z);
   }
   /* pose: the reference sets the base-link pose (:441-443); the state stores the COM */
   float* P = &e->pose[4 * i];
@@ -1169,7 +1191,7 @@ static float step_arena(orc_env* e, int i, const float* act /*[A]*/, uint8_t* rs
   if (c->mix_mode == OIS_MIX_SWITCH) {
     float u[4];
     draw4(e->seed, gid, (uint32_t)cnt[1], PURPOSE_MASK, u); /* torch.rand(num_envs,1) :633 */
-    rnd = u[0];
+    rnd = e->hooks.switch_u ? e->hooks.switch_u[i] : u[0];
   }
   float torques[4], wt[4], guiding;
   mix1(c->mix_mode, c->guiding_mode, a4, ac_left, ac_right, gamma1, rnd, c->action_scale, c->torque_clip,
@@ -1224,6 +1246,18 @@ static float step_arena(orc_env* e, int i, const float* act /*[A]*/, uint8_t* rs
   if (blown) w[0] = w[1] = w[2] = 0.0f; /* R may itself be non-finite if the pose was corrupted from outside */
   float jv[4];
   for (int k = 0; k < 4; ++k) jv[k] = spin[k] - wb[1];
+  if (e->hooks.physics_in) { /* fixture replay: the simulator's outcome comes from the fixture */
+    const float* s = &e->hooks.physics_in[(size_t)ORC_PHYSICS_STRIDE * i];
+    for (int k = 0; k < 3; ++k) { p[k] = s[k]; v[k] = s[7 + k]; w[k] = s[10 + k]; }
+    for (int k = 0; k < 4; ++k) { q[k] = s[3 + k]; jv[k] = s[13 + k]; }
+    rotmat(q, R);
+  }
+  if (e->hooks.physics_out) {
+    float* s = &e->hooks.physics_out[(size_t)ORC_PHYSICS_STRIDE * i];
+    for (int k = 0; k < 3; ++k) { s[k] = p[k]; s[7 + k] = v[k]; s[10 + k] = w[k]; }
+    for (int k = 0; k < 4; ++k) { s[3 + k] = q[k]; s[13 + k] = jv[k]; }
+    s[17] = fmaf(-R[2], c->com_height, p[0]); s[18] = fmaf(-R[5], c->com_height, p[1]); s[19] = fmaf(-R[8], c->com_height, p[2]);
+  }
 
   /* ---- post_physics_step (:674-727) ---- */
   cnt[0] += 1; /* episode_buf :675 */

@@ -64,6 +64,23 @@ int orc_randomize_params(orc_env* env, float mu_lo, float mu_hi, const float* sl
 /* number of OpenMP threads used by orc_step/orc_rollout (1 = scalar). */
 int orc_set_threads(orc_env* env, int threads);
 
+/* Fixture replay (tests/golden/refexec_cosim_*.npz: the reference's own statements run in lock-step with this env).
+ * The reference draws from torch's generator and steps PhysX; to compare step by step the env takes those three
+ * things from the caller: the uniform of the stochastic switch (KAMMA.py:633), the draws of reset_idx (order of
+ * orc_reset_draws; slot 8 = the standard normal of GridSampling), and the simulator's outcome. Arrays stay the
+ * caller's and are read at every orc_reset / orc_step until cleared (NULL). physics rows: COM position 3,
+ * quaternion 4 (w,x,y,z), linear velocity 3, angular velocity 3 (world), joint velocities 4, base-link position 3
+ * (written only). */
+#define ORC_RESET_U_STRIDE 12
+#define ORC_PHYSICS_STRIDE 20
+typedef struct {
+  const float* switch_u;   /* [N] */
+  const float* reset_u;    /* [N, ORC_RESET_U_STRIDE] */
+  const float* physics_in; /* [N, ORC_PHYSICS_STRIDE]: replaces the outcome of the substeps */
+  float* physics_out;      /* [N, ORC_PHYSICS_STRIDE]: receives it (before is_done / reset) */
+} orc_test_hooks;
+int orc_test_set_hooks(orc_env* env, const orc_test_hooks* hooks);
+
 /* host pointer to a buffer with the SAME id / shape / dtype as ois_buffer() */
 int orc_buffer(orc_env* env, int id, void** ptr, size_t* bytes);
 int orc_episode_info(orc_env* env);               /* fills OIS_BUF_EPISODE_INFO */
@@ -144,6 +161,7 @@ float orc_h2f(uint16_t h);
 /* the per-terrain-level command generators (KAMMA.py:533-567) and the deterministic helpers they use */
 float orc_sin(float x);
 float orc_normal(float u1, float u2);
+void orc_box_bounds(int32_t sim_steps, float max_sim_steps, float lo, float hi, float* xmin, float* xmax); /* KAMMA_curr1.py:579-591 */
 float orc_grid_command(int32_t sim_steps, float max_sim_steps, float lo, float hi, float u_side, float z); /* KAMMA_curr2.py:602-626 */
 float orc_eval_command(int32_t sim_steps, float ramp_steps); /* KAMMA_eval.py:545-550 */
 void orc_level_command(int level, float fraction, int32_t step_counter, float z, double dt, double episode_length_s,

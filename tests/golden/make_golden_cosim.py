@@ -1,0 +1,323 @@
+#!/usr/bin/env python3
+"""Golden vectors made by running the reference's own task statements in lock-step with the CPU oracle (build
+container only; needs /root/reference). Writes
+
+  tests/golden/refexec_cosim.npz        per variant: T steps of n arenas — inputs (actions, the uniform draws, the
+                                        simulator's outcome per step) and what the REFERENCE's statements computed
+                                        from them (observations, rewards, masks, torques, sums, commands, counters,
+                                        extras, the 26 env-0 diagnostics)
+  tests/golden/refexec_blocks.npz       single methods on seeded random states (wider numeric ranges than a trajectory
+                                        reaches): pre_physics_step of the 12 env files, is_done, reset_idx's extras,
+                                        the projection tail, the box-sampler bounds
+  tests/golden/refexec_cosim_lines.json which source lines of each method ran and which were removed (refexec_task.py)
+
+How: refexec_task.build() compiles `TorqueDistributionTask` of a reference env file without the statements that need
+Isaac Sim (rule R1-R4 there; nothing is written in their place). What those statements would have delivered is DATA
+here: the post-physics state comes from the oracle's physics (orc_test_hooks.physics_out), the uniform draws of
+`torch_rand_float` from a numpy generator (the same numbers go to the oracle through orc_test_hooks.reset_u),
+`torch.rand` / `torch.normal` are the reference's own calls on torch's generator, re-seeded before each call so that
+the draw can be recorded and handed to the oracle (switch_u, the GridSampling normal), and the three rotated vectors
+of `quat_apply` come from the oracle's orc_quat_apply. tests/test_refexec_cosim.py replays the fixture through the
+oracle with physics_in = the recorded simulator outcome, so the fixture pins everything of the step EXCEPT the physics
+and does not move when the physics model is re-calibrated.
+
+    python tests/golden/make_golden_cosim.py
+"""
+import ast
+import json
+import os
+import sys
+import types
+import warnings
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, HERE)
+
+import refexec_task as rt  # noqa: E402
+from make_golden_ref import SCRIPT_OVERRIDES, SUM_KEYS, VARIANT_FILES, _apply_overrides  # noqa: E402
+
+F = torch.float32
+EVAL_KEYS = ["Smoothness", "Tracking error", "Desired velocity"]
+
+
+def task_cfg_literal(variant):
+    tree = ast.parse(open(os.path.join(rt.REF, "my_envs", variant + ".py")).read())
+    node = next(n for n in tree.body if isinstance(n, ast.Assign) and getattr(n.targets[0], "id", None) == "TASK_CFG")
+    run = _apply_overrides(ast.literal_eval(node.value))
+    return run
+
+
+def capture_locals(fn, *args):
+    """fn(*args) unchanged; returns (result, the locals of fn's own frame when it returned)"""
+    box = {}
+
+    def prof(frame, event, arg):
+        if event == "return" and frame.f_code is fn.__code__:
+            box.update(frame.f_locals)
+    sys.setprofile(prof)
+    try:
+        res = fn(*args)
+    finally:
+        sys.setprofile(None)
+    return res, box
+
+
+def rf(lo, hi, u):
+    """what the removed torch_rand_float(lo, hi, shape) statements deliver for the uniform draw u (published formula
+    of omni.isaac.core.utils.torch.maths: (upper - lower) * torch.rand(shape) + lower)"""
+    return (hi - lo) * u + lo
+
+
+class Cosim:
+    def __init__(self, variant, n, seed):
+        from options_in_simulation_amd import _abi, build_config
+        from oracle.binding import OracleEnv, PHYSICS_STRIDE, RESET_U_STRIDE, fptr, lib
+        self._abi, self.L, self.fptr = _abi, lib(), fptr
+        self.variant, self.n = variant, n
+        Ref, self.ns, self.lines = rt.build(variant)
+        run = task_cfg_literal(variant)
+        run["task"]["env"]["numEnvs"] = n
+        self.cfg = build_config(run, variant=variant, num_envs=n, seed=seed)   # from the reference's own TASK_CFG literal
+        assert bytes(self.cfg) == bytes(build_config(variant=variant, num_envs=n, seed=seed)), "default_task_cfg() differs from the literal"
+        self.orc = OracleEnv(self.cfg)
+        self.rng = np.random.default_rng(seed)
+        self.S = np.zeros((n, PHYSICS_STRIDE), np.float32)
+        self.reset_u = np.zeros((n, RESET_U_STRIDE), np.float32)
+        self.switch_u = np.zeros(n, np.float32)
+        self.grid_seed = None
+        co = self
+
+        class Glue(Ref):
+            """the caller's side of the removed statements (see the module docstring); no arithmetic of the step here"""
+
+            def reset_idx(self, env_ids):
+                ids = env_ids.long()
+                u = torch.from_numpy(co.reset_u[ids.numpy()][:, :8].copy())
+                # KAMMA.py:448-456 (removed: torch_rand_float) — the draws land where the kept line :458 reads them
+                self.commands[ids, 0] = rf(self.command_x_range[0], self.command_x_range[1], u[:, 3])
+                self.commands[ids, 1] = rf(self.command_y_range[0], self.command_y_range[1], u[:, 4])
+                self.commands[ids, 3] = rf(self.command_yaw_range[0], self.command_yaw_range[1], u[:, 5])
+                self._u6 = {int(i): u[k, 6] for k, i in enumerate(ids)}
+                super().reset_idx(env_ids)
+                # :424, :426-434 (removed: torch_rand_float, quat_mul): spawn offset and yaw quaternion, from the oracle
+                for k, i in enumerate(ids.tolist()):
+                    pos, quat, cmd = np.zeros(3, np.float32), np.zeros(4, np.float32), np.zeros(4, np.float32)
+                    uu = np.ascontiguousarray(co.reset_u[i, :8])
+                    co.L.orc_reset_draws(co.cfg, fptr(uu), fptr(pos), fptr(quat), fptr(cmd))
+                    assert float(self.base_pos[i, 2]) == float(pos[2]) and float(self.base_pos[i, 0]) == 0.0  # :422 ran
+                    self.base_pos[i, 0:2] = torch.from_numpy(pos[:2].copy())
+                    self.base_quat[i] = torch.from_numpy(quat.copy())
+                co.orientation_givens(self)
+
+            def refresh_dof_state_tensors(self):     # KAMMA.py:587-589 (removed): the attributes are re-bound, as there
+                S = torch.from_numpy(co.S.copy())
+                self.dof_vel = S[:, 13:17].clone()
+
+            def refresh_body_state_tensors(self):    # :591-593 (removed)
+                S = torch.from_numpy(co.S.copy())
+                self.base_pos, self.base_quat = S[:, 17:20].clone(), S[:, 3:7].clone()
+                self.base_velocities = torch.cat([S[:, 7:10], S[:, 10:13]], 1)
+                co.orientation_givens(self)
+
+            def sample_velocity_command(self, env_id):
+                i = int(env_id)
+                if getattr(self, "evalsampling", False) or self.curriculum:
+                    return super().sample_velocity_command(env_id)
+                if self.randsampling:       # :571 removed; :573-575 run on the draw
+                    co.ns["x_vel"] = rf(self.command_x_range[0], self.command_x_range[1], self._u6[i]).clone()
+                    return super().sample_velocity_command(env_id)
+                if self.boxsampling:        # KAMMA_curr1.py:579-591 run; :593 removed; :595-597 run on the draw
+                    co.ns["x_vel"] = torch.tensor(0.0)
+                    _, loc = capture_locals(super().sample_velocity_command.__func__, self, env_id)
+                    co.box_bounds = (loc["x_min"], loc["x_max"])
+                    co.ns["x_vel"] = rf(loc["x_min"], loc["x_max"], self._u6[i]).squeeze()
+                    return super().sample_velocity_command(env_id)
+                if self.gridsampling:       # KAMMA_curr2.py:602-640: torch.rand(1) / torch.normal are the reference's own
+                    torch.manual_seed(co.grid_seed)
+                    with warnings.catch_warnings():
+                        warnings.simplefilter("ignore")
+                        return super().sample_velocity_command(env_id)
+                raise AssertionError("no sampler")
+
+        t = Glue.__new__(Glue)
+        t._device = "cpu"                                                       # RLTask.__init__ (removed): rl_task.py:73
+        Glue.__init__(t, "TorqueDistributionTask", types.SimpleNamespace(config=run, task_config=run["task"]), None)
+        t.clip_obs = run["task"]["env"].get("clipObservations", np.inf)         # rl_task.py:96
+        t.cleanup()                                                             # rl_task.py:118
+        t.num_dof = 4                                                           # KAMMA.py:399 (removed: self._robots.num_dof)
+        self.task = t
+        self.gravity = np.array([0.0, 0.0, -1.0], np.float32)
+
+    # -- data the removed statements would have delivered ---------------------------------------------------------
+    def quat_apply_all(self, quat, vec):
+        out = np.zeros((self.n, 3), np.float32)
+        q = np.ascontiguousarray(quat, np.float32)
+        v = np.ascontiguousarray(vec, np.float32)
+        for i in range(self.n):
+            self.L.orc_quat_apply(self.fptr(q[i]), self.fptr(v), self.fptr(out[i]))
+        return torch.from_numpy(out)
+
+    def orientation_givens(self, t):
+        q = t.base_quat.numpy()
+        self.ns["projected_gravity"] = self.quat_apply_all(q, self.gravity)                    # KAMMA.py:749
+        self.ns["forward"] = self.quat_apply_all(q, np.array([1.0, 0.0, 0.0], np.float32))      # :701
+        self.ns["up_dir"] = self.quat_apply_all(q, np.array([0.0, 0.0, 1.0], np.float32))       # :707
+
+    def draw_reset(self, t_index):
+        self.reset_u[:] = self.rng.random(self.reset_u.shape, np.float32)
+        if self.task.gridsampling and not self.task.randsampling and not self.task.boxsampling:
+            assert self.n == 1
+            self.grid_seed = 5000 + t_index
+            torch.manual_seed(self.grid_seed)
+            self.reset_u[0, 6] = torch.rand(1)[0]
+            self.reset_u[0, 8] = torch.randn(1)[0]
+
+    # -- the run --------------------------------------------------------------------------------------------------
+    def start(self, seed):
+        self.draw_reset(-1)
+        self.first_reset_u = self.reset_u.copy()
+        self.orc.set_hooks(reset_u=self.reset_u)
+        self.orc.reset(seed)
+        self.task.post_reset()
+        return self.snapshot()
+
+    def step(self, t_index, actions, events=()):
+        A = self._abi
+        T = self.task
+        for kind, arena in events:
+            if kind == "fall":
+                self.orc.buffer(A.BUF_QUAT)[arena] = np.array([0.0, 1.0, 0.0, 0.0], np.float32)
+            elif kind == "oob":
+                self.orc.buffer(A.BUF_POSE)[arena, 0] += 60.0
+            elif kind == "oob_y":
+                self.orc.buffer(A.BUF_POSE)[arena, 1] -= 70.0
+        torch.manual_seed(1000 + t_index)
+        self.switch_u[:] = torch.rand(self.n, 1)[:, 0].numpy()   # the draw of KAMMA.py:633, recorded by replaying the seed
+        torch.manual_seed(1000 + t_index)
+        T.pre_physics_step(torch.from_numpy(actions.copy()))
+        pre = {"v_delta": T.v_delta.clone(), "omega_delta": T.omega_delta.clone(), "ac_left": T.ac_left.clone(),
+               "ac_right": T.ac_right.clone(), "torques": T.torques.clone(), "wheel_torqs": T.wheel_torqs.clone(),
+               "guiding": T.guiding_reward.clone()}
+        self.draw_reset(t_index)
+        self.orc.set_hooks(switch_u=self.switch_u, reset_u=self.reset_u, physics_out=self.S)
+        self.orc.step(actions)
+        T.post_physics_step()   # its refresh_*_state_tensors calls bind the simulator's outcome (Glue)
+        out = self.snapshot()
+        out.update({k: v.numpy() for k, v in pre.items()})
+        out.update(actions=actions.copy(), switch_u=self.switch_u.copy(), reset_u=self.reset_u.copy(), physics=self.S.copy())
+        # the projection's 3-term sum is order dependent (1 ulp); both sides continue from the oracle's value
+        orc_vfwd = torch.from_numpy(self.orc.buffer(A.BUF_POSE)[:, 3].copy())
+        assert torch.allclose(T.v_forward_projected, orc_vfwd, rtol=2e-6, atol=2e-7), (T.v_forward_projected, orc_vfwd)
+        T.v_forward_projected = orc_vfwd
+        return out
+
+    def snapshot(self):
+        T = self.task
+        sums = torch.stack([T.episode_sums[k] for k in SUM_KEYS], 1)
+        d = {"obs": T.obs_buf.clone(), "rew": T.rew_buf.clone(), "reset": T.reset_buf.to(torch.uint8), "timeout": T.timeout_buf.to(torch.uint8),
+             "sums": sums, "commands": T.commands.clone(), "episode_buf": T.episode_buf.to(torch.int32), "sim_steps": T.sim_steps.to(torch.int32),
+             "episode_count": T.episode_count.to(torch.int32), "prev_lin": T.previous_linear_velocity[:, 0].clone(),
+             "prev_ang": T.previous_angular_velocity[:, 2].clone(), "v_fwd": T.v_forward_projected.clone(),
+             "v_lat": T.v_lateral_projected.clone(), "v_up": T.v_upward_projected.clone()}
+        if all(k in T.episode_sums for k in EVAL_KEYS):
+            d["sums_eval"] = torch.stack([T.episode_sums[k] for k in EVAL_KEYS], 1)
+            d["old_torques"] = T.old_torques.clone()
+        for g in ("gamma_assist1", "gamma_assist2", "gamma_assist"):
+            if hasattr(T, g):
+                d[g] = T.__dict__[g].clone().float()
+        ex = T.extras.get("episode", {})
+        d["extras_keys"] = np.array(sorted(ex))
+        d["extras"] = np.array([float(ex[k]) for k in sorted(ex)], np.float64)
+        oc = getattr(T, "observed_components", None)
+        if oc:
+            d["components_keys"] = np.array(list(oc))
+            d["components"] = np.array([float(oc[k]) for k in oc], np.float64)
+        if hasattr(T, "fraction"):
+            d["fraction"] = T.fraction.clone()
+        return {k: (v.numpy() if isinstance(v, torch.Tensor) else v) for k, v in d.items()}
+
+
+RUNS = {  # variant -> (arenas, steps, {step: [(event, arena)]}); two synchronous timeouts need 199 steps
+    "KAMMA": (6, 204, {20: [("fall", 3)], 21: [("fall", 3)], 60: [("fall", 5)], 75: [("oob", 1)], 130: [("oob_y", 0), ("fall", 2)]}),
+    "KAMMA_medium": (4, 104, {33: [("fall", 1)]}),
+    "KAMMA_g11_g21": (4, 104, {33: [("oob", 2)]}),
+    "KAMMA_g1d_g21": (4, 104, {40: [("fall", 0)]}),
+    "KAMMA_curr1": (1, 204, {50: [("fall", 0)]}),     # BoxSampling / GridSampling only run with one arena (min(1.0, tensor))
+    "KAMMA_curr2": (1, 204, {50: [("oob", 0)]}),
+    "KAMMA_eval": (5, 130, {20: [("fall", 3)], 21: [("fall", 3)], 60: [("fall", 4)]}),
+    "KA_DDPG_4D": (4, 130, {20: [("fall", 3)], 45: [("oob", 0)]}),
+    "KA_DDPG_2D": (4, 104, {20: [("fall", 3)]}),
+    "KA_DDPG_1D": (4, 104, {20: [("fall", 1)]}),
+    "KA_DDPG_2D_eval": (3, 104, {20: [("fall", 1)]}),
+    "KA_DDPG_1D_eval": (3, 104, {30: [("fall", 2)]}),
+}
+# sim_steps where the gamma schedule is in the interior (the trajectories above start at 0: gamma 1 - 2e-4)
+START_SIM_STEPS = {"KAMMA": 150000, "KAMMA_medium": 420000, "KAMMA_g1d_g21": 250000, "KAMMA_curr1": 200000, "KAMMA_curr2": 300000,
+                   "KA_DDPG_4D": 350000, "KAMMA_eval": 20000, "KA_DDPG_2D_eval": 30000, "KA_DDPG_1D_eval": 49950}
+
+
+def run_variant(variant, n, T, seed, events):
+    from tests.cosim_check import check_step
+    from options_in_simulation_amd import _abi
+    co = Cosim(variant, n, seed)
+    first = co.start(seed)
+    check_step(co.orc, co.cfg, first, f"{variant} post_reset", first=True)
+    if variant in START_SIM_STEPS:   # a run that has been training for a while: same value on both sides
+        co.task.sim_steps[:] = START_SIM_STEPS[variant]
+        co.orc.buffer(_abi.BUF_COUNTERS)[:, 1] = START_SIM_STEPS[variant]
+    rng = np.random.default_rng(seed + 1)
+    lo = -1.2 if variant.startswith("KA_DDPG") else -0.2
+    steps = []
+    for t in range(T):
+        a = rng.uniform(lo, 1.5, (n, co.cfg.action_dim)).astype(np.float32)
+        try:
+            out = co.step(t, a, events.get(t, ()))
+        except ZeroDivisionError:
+            # KAMMA_g11_g21.py:859: 100.0 * (1 - gamma2) * comp / rew_buf[0].item() in Python floats. With gamma2 = 1 and the
+            # expert's torques inside the clip the reward is exactly 0 and the reference stops here (its sibling
+            # KAMMA_g1d_g21 has the guard :838-842 for this). Recorded: the step, and that the oracle's reward is 0 there.
+            assert co.orc.rew[0] == 0.0 and variant == "KAMMA_g11_g21"
+            co.raised_at = t
+            break
+        check_step(co.orc, co.cfg, out, f"{variant} step {t}")
+        steps.append(out)
+    return co, first, steps
+
+
+def pack(variant, co, first, steps):
+    d = {}
+    per_step = [k for k in steps[0] if k not in ("extras_keys", "components_keys")]
+    for k in per_step:
+        d[k] = np.stack([s[k] for s in steps])
+    d["extras_keys"], d["components_keys"] = steps[0]["extras_keys"], steps[0]["components_keys"]
+    assert all((s["extras_keys"] == d["extras_keys"]).all() and (s["components_keys"] == d["components_keys"]).all() for s in steps)
+    for k in ("commands", "episode_buf", "sim_steps", "episode_count", "extras"):
+        d["first__" + k] = first[k]
+    d["first__reset_u"] = co.first_reset_u
+    d["start_sim_steps"] = np.int32(START_SIM_STEPS.get(variant, 0))
+    d["reference_raised_zero_division_at"] = np.int32(getattr(co, "raised_at", -1))
+    return {f"{variant}__{k}": v for k, v in d.items()}
+
+
+def main():
+    fixture, report = {}, {}
+    for k, variant in enumerate(RUNS):
+        n, T, events = RUNS[variant]
+        co, first, steps = run_variant(variant, n, T, 100 + k, events)
+        fixture.update(pack(variant, co, first, steps))
+        report[variant] = rt.lines_report(co.lines)
+        resets = np.stack([s["reset"] for s in steps])
+        print(f"{variant}: {len(steps)} steps x {n} arenas, {int(resets.sum())} resets ({int(np.stack([s['timeout'] for s in steps]).sum())} timeouts), "
+              f"reference == oracle at every step")
+    np.savez_compressed(os.path.join(HERE, "refexec_cosim.npz"), **fixture)
+    json.dump(report, open(os.path.join(HERE, "refexec_cosim_lines.json"), "w"), indent=1)
+    print("wrote refexec_cosim.npz", os.path.getsize(os.path.join(HERE, "refexec_cosim.npz")), "bytes")
+
+
+if __name__ == "__main__":
+    main()
