@@ -78,6 +78,8 @@ def lib() -> C.CDLL:
         L.orc_metrics.restype = None
         L.orc_grid_command.argtypes = [C.c_int32, C.c_float, C.c_float, C.c_float, C.c_float, C.c_float]
         L.orc_grid_command.restype = C.c_float
+        L.orc_reset_ratios.argtypes = [fp, C.c_float, C.c_float, fp]
+        L.orc_reset_ratios.restype = None
         L.orc_box_bounds.argtypes = [C.c_int32, C.c_float, C.c_float, C.c_float, fp, fp]
         L.orc_box_bounds.restype = None
         L.orc_test_set_hooks.argtypes = [C.c_void_p, C.POINTER(ReplayHooks)]

@@ -943,6 +943,23 @@ typedef struct {
   float ret, len;
 } reset_contrib;
 
+/* the per-arena values reset_idx contributes to extras["episode"] (KAMMA.py:470-485): slot 0 the count, 1..8 the episode
+ * sums, 9..15 the ratio sums L * (100 * (1 - gamma2) * S_k / S_final) (gamma2 itself for the guiding one, :475) */
+void orc_reset_ratios(const float S[8], float gamma2, float L, float v[16]) {
+  float Sf = S[7];
+  float hg = 100.0f * (1.0f - gamma2); /* hundred * (one - gamma2) :470 */
+  float gg = 100.0f * gamma2;          /* hundred * gamma2         :475 */
+  v[OIS_EI_COUNT] = 1.0f;
+  for (int k = 0; k < 8; ++k) v[OIS_EI_R1 + k] = S[k];
+  v[OIS_EI_R1_OVER_FINAL] = L * ((hg * S[0]) / Sf);       /* :470 */
+  v[OIS_EI_R2_OVER_FINAL] = L * ((hg * S[1]) / Sf);       /* :471 */
+  v[OIS_EI_R3_OVER_FINAL] = L * ((hg * S[2]) / Sf);       /* :472 */
+  v[OIS_EI_DENSE_OVER_FINAL] = L * ((hg * S[3]) / Sf);    /* :473 */
+  v[OIS_EI_SPARSE_OVER_FINAL] = L * ((hg * S[4]) / Sf);   /* :474 */
+  v[OIS_EI_GUIDING_OVER_FINAL] = L * ((gg * S[5]) / Sf);  /* :475 */
+  v[OIS_EI_OBSERVED_OVER_FINAL] = L * ((hg * S[6]) / Sf); /* :476 */
+}
+
 /* reset_idx for ONE arena (KAMMA.py:417-498). Fills the contribution to extras, rewrites
  * pose / velocities / commands / counters / sums. step_ctr = sim_steps value used as RNG
  * counter. gamma2 = current reward assist (:467-476). */
@@ -954,18 +971,7 @@ static void reset_arena(orc_env* e, int i, uint32_t step_ctr, float gamma2, rese
   int32_t* cnt = &e->counters[4 * i];
   float S[8] = {sa[0], sa[1], sa[2], sa[3], sb[0], sb[1], sb[2], sb[3]};
   float Sf = S[7];
-  float hg = 100.0f * (1.0f - gamma2); /* hundred * (one - gamma2) :470 */
-  float gg = 100.0f * gamma2;          /* hundred * gamma2         :475 */
-  float L = c->episode_length_s;
-  rc->v[OIS_EI_COUNT] = 1.0f;
-  for (int k = 0; k < 8; ++k) rc->v[OIS_EI_R1 + k] = S[k];
-  rc->v[OIS_EI_R1_OVER_FINAL] = L * ((hg * S[0]) / Sf);       /* :470 */
-  rc->v[OIS_EI_R2_OVER_FINAL] = L * ((hg * S[1]) / Sf);       /* :471 */
-  rc->v[OIS_EI_R3_OVER_FINAL] = L * ((hg * S[2]) / Sf);       /* :472 */
-  rc->v[OIS_EI_DENSE_OVER_FINAL] = L * ((hg * S[3]) / Sf);    /* :473 */
-  rc->v[OIS_EI_SPARSE_OVER_FINAL] = L * ((hg * S[4]) / Sf);   /* :474 */
-  rc->v[OIS_EI_GUIDING_OVER_FINAL] = L * ((gg * S[5]) / Sf);  /* :475 */
-  rc->v[OIS_EI_OBSERVED_OVER_FINAL] = L * ((hg * S[6]) / Sf); /* :476 */
+  orc_reset_ratios(S, gamma2, c->episode_length_s, rc->v);
   rc->sm = sc[0]; rc->te = sc[1]; rc->dv = sc[2];
   rc->ret = Sf;
   rc->len = (float)cnt[0];

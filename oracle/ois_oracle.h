@@ -8,20 +8,26 @@
  * (options_in_simulation_amd/) never does.
  *
  * PARITY STATUS
- *   - pinned by the reference's OWN code executed here (tests/golden/refexec_*.npz, made by
- *     tests/golden/make_golden_ref.py: the function definitions are taken out of the reference's files
- *     by ast, compiled unchanged and run on seeded inputs; the modules cannot be imported whole — omni /
- *     pxr / gym / skrl at module level, plain ModuleNotFoundError, SURVEY §8c — and no stand-in for an
- *     absent library is supplied): TASK_CFG + update_config of the 12 env files, calculate_metrics
- *     (KAMMA.py:767, KA_DDPG_4D, KAMMA_eval),
- *     get_observations incl. the 26 env-0 diagnostics and KAMMA_g1d_g21's reward guard,
- *     sample_velocity_command's curriculum and EvalSampling branches, PPO's compute_gae, the terrain
- *     generator families and the Terrain class (tests/test_refexec.py).
- *   - the rest of the reference-followed math (controller, gamma, mixing, clip, termination, reset,
- *     projections, get_heights, the eval variants' old_torques bookkeeping): pinned against
- *     tests/golden/refmath_*.npz, produced by tests/golden/make_golden.py — a torch-CPU transcription of
- *     the cited KAMMA.py lines written in this repo (those functions call omni / skrl helpers or the
- *     simulator, so they cannot be run here).
+ *   - pinned by the reference's OWN statements executed here, step by step (tests/golden/refexec_cosim.npz and
+ *     refexec_blocks.npz, made by tests/golden/make_golden_cosim.py; tests/test_refexec_cosim.py): `TorqueDistributionTask`
+ *     of each of the 12 env files is compiled out of the reference's syntax tree WITHOUT the statements that need Isaac
+ *     Sim (tests/golden/refexec_task.py: rule R1-R4, the removed lines are listed in refexec_cosim_lines.json; nothing is
+ *     written in their place) and run in lock-step with orc_reset / orc_step for 100-200 steps with falls, bound
+ *     violations and timeouts: pre_physics_step (controller, gamma, switch / blend, 2-D / 1-D expansion, clip, guiding
+ *     reward, the eval sums), is_done, calculate_metrics, reset_idx (counters, small-command mask, ratio sums, extras,
+ *     fraction, Rand / Box / Grid / Eval samplers), get_observations with the 26 env-0 diagnostics, the projection tail,
+ *     the order of all of it inside post_physics_step. The simulator's outcome, the uniform draws and the three
+ *     quat_apply results per step are DATA in the fixture (orc_test_hooks below).
+ *   - pinned by whole functions of the reference executed on seeded inputs (tests/golden/refexec_*.npz, made by
+ *     tests/golden/make_golden_ref.py; the modules cannot be imported whole — omni / pxr / gym / skrl at module level,
+ *     plain ModuleNotFoundError, SURVEY 8c — and no stand-in for an absent library is supplied): TASK_CFG +
+ *     update_config of the 12 env files, calculate_metrics (KAMMA.py:767, KA_DDPG_4D, KAMMA_eval), get_observations,
+ *     sample_velocity_command's curriculum / EvalSampling / GridSampling branches, PPO's compute_gae, Agent.record_transition,
+ *     the terrain generator families and the Terrain class (tests/test_refexec.py).
+ *   - left on the build's own transcription (tests/golden/refmath_*.npz, tests/golden/make_golden.py), because the
+ *     statement itself is a call into omni.isaac.core.utils.torch, which is not under /root/reference: quat_apply (has_fallen
+ *     :749, forward / up :701, :707), quat_mul (the yaw quaternion :434), torch_rand_float (lower + (upper - lower) u,
+ *     :424-456, :571), normalize + quat_apply in get_heights (:872-899).
  *   - physics (PhysX 5 inside Isaac Sim 4.0.0, not in /root/reference, no golden vectors
  *     anywhere in the reference): PARITY UNPINNED. The model is defined by docs/SPEC.md §3;
  *     parity is oracle <-> HIP kernel only.
@@ -139,6 +145,9 @@ void orc_quat_mul(const float a[4], const float b[4], float out[4]);
  *     (order: pos x, pos y, yaw, cmd x, cmd y, cmd heading, x re-draw, discarded omega) */
 void orc_reset_draws(const ois_config* cfg, const float u[8], float pos3[3], float quat4[4],
                      float commands4[4]);
+
+/* a9: what one resetting arena contributes to extras["episode"] (KAMMA.py:470-485); v: the first 16 OIS_EI_* slots */
+void orc_reset_ratios(const float S[8], float gamma2, float episode_length_s, float v[16]);
 
 /* RNG + deterministic trig */
 void orc_philox4x32_10(const uint32_t ctr[4], const uint32_t key[2], uint32_t out[4]);

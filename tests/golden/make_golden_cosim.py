@@ -304,7 +304,148 @@ def pack(variant, co, first, steps):
     return {f"{variant}__{k}": v for k, v in d.items()}
 
 
+# ------------------------------------------------------------------------------------------------------------------
+# single methods on seeded random states (wider ranges than a trajectory reaches)
+def _rand(g):
+    return lambda *s, lo=-1.0, hi=1.0: (hi - lo) * torch.rand(*s, generator=g, dtype=F) + lo
+
+
+def block_prephysics(variant, n=129, seed=0):
+    """pre_physics_step of the file on random commands / speeds / actions, sim_steps from 0 to 1.3 max_sim_steps (the
+    clamp of the schedule at 0), actions beyond the action space (the clip). The torch.rand of the switch is the
+    reference's own; its draw is recorded by replaying the seed."""
+    co = Cosim(variant, n, 300 + seed)   # __init__ / update_config only: post_reset's samplers of curr1 / curr2 need one arena
+    T = co.task
+    g = torch.Generator().manual_seed(seed)
+    r = _rand(g)
+    T.commands = torch.stack([r(n, lo=0.0, hi=2.0), r(n, lo=-0.5, hi=0.5), r(n, lo=-0.3, hi=0.3), r(n, lo=1.0, hi=1.1)], 1)
+    T.v_forward_projected = r(n, lo=-0.5, hi=2.5)
+    T.base_velocities = r(n, 6)
+    T.sim_steps = torch.randint(0, int(1.3 * T.max_sim_steps), (n,), generator=g)
+    if hasattr(T, "old_torques"):
+        T.old_torques = torch.clip(r(n, 4, lo=-5.0, hi=5.0), -4.0, 4.0)
+        for k in ("Smoothness", "Desired velocity"):
+            T.episode_sums[k] = r(n, lo=0.0, hi=3.0)
+    A = co.cfg.action_dim
+    actions = r(n, A, lo=-1.3, hi=1.7)
+    inp = {"commands": T.commands.clone(), "v_forward_projected": T.v_forward_projected.clone(), "omega_z": T.base_velocities[:, 5].clone(),
+           "sim_steps": T.sim_steps.to(torch.int32), "actions": actions.clone()}
+    if hasattr(T, "old_torques"):
+        inp["old_torques"] = T.old_torques.clone()
+        inp["sums_eval_in"] = torch.stack([T.episode_sums["Smoothness"], T.episode_sums["Desired velocity"]], 1).clone()
+    torch.manual_seed(77 + seed)
+    inp["switch_u"] = torch.rand(n, 1)[:, 0]
+    torch.manual_seed(77 + seed)
+    T.pre_physics_step(actions)
+    out = {"v_delta": T.v_delta, "omega_delta": T.omega_delta, "ac_left": T.ac_left, "ac_right": T.ac_right, "torques": T.torques,
+           "wheel_torqs": T.wheel_torqs, "guiding": T.guiding_reward}
+    for gk in ("gamma_assist1", "gamma_assist2", "gamma_assist"):
+        if hasattr(T, gk):
+            out[gk] = T.__dict__[gk].float()
+    if hasattr(T, "old_torques"):
+        out["old_torques_out"] = T.old_torques
+        out["sums_eval_out"] = torch.stack([T.episode_sums["Smoothness"], T.episode_sums["Desired velocity"]], 1)
+    d = {k: v.numpy() for k, v in {**inp, **out}.items()}
+    d["max_sim_steps"] = np.float32(T.max_sim_steps)
+    return d
+
+
+def block_is_done(n=257, seed=1):
+    """is_done (KAMMA.py:736-764) with projected_gravity handed in (the quat_apply of :749 is removed)"""
+    co = Cosim("KAMMA", n, 400)
+    co.start(400)
+    T = co.task
+    g = torch.Generator().manual_seed(seed)
+    r = _rand(g)
+    q = torch.nn.functional.normalize(r(n, 4), dim=1)
+    q[: n // 3] = torch.nn.functional.normalize(torch.tensor([[1.0, 0.02, -0.03, 0.4]]) + 0.05 * r(n // 3, 4), dim=1)
+    T.base_quat = q
+    T.base_pos = r(n, 3, lo=-60.0, hi=60.0)
+    T.base_pos[::2] *= 0.1
+    T.base_pos[5, 0], T.base_pos[6, 0], T.base_pos[7, 1], T.base_pos[8, 1] = 50.0, -50.0, 50.0, -50.0   # on the bounds: inside
+    T.episode_buf = torch.randint(0, 120, (n,), generator=g)
+    T.episode_buf[:4] = torch.tensor([98, 99, 100, 97])
+    co.orientation_givens(T)
+    T.is_done()
+    return {"quat": q.numpy(), "base_pos": T.base_pos.numpy(), "episode_buf": T.episode_buf.to(torch.int32).numpy(),
+            "projected_gravity_z": co.ns["projected_gravity"][:, 2].numpy(), "reset": T.reset_buf.to(torch.uint8).numpy(),
+            "timeout": T.timeout_buf.to(torch.uint8).numpy(), "has_fallen": T.has_fallen.to(torch.uint8).numpy(),
+            "out_of_bounds": T.out_of_bounds.to(torch.uint8).numpy(), "max_episode_length": np.int32(T.max_episode_length)}
+
+
+def block_reset_extras(variant, n=64, seed=2, gamma=0.375):
+    """reset_idx (:458-488, :498) on random episode sums — some with a zero or tiny final sum (inf / nan ratios) — for a
+    subset of the arenas: counters, the ratio sums under their NEW keys (:470-476), the means of extras, `fraction`."""
+    co = Cosim(variant, n, 500 + seed)
+    co.start(500 + seed)
+    T = co.task
+    g = torch.Generator().manual_seed(seed)
+    sums = 10.0 * (torch.rand(n, 8, generator=g, dtype=F) - 0.7)
+    sums[3, 7] = 0.0; sums[9, 7] = 1e-30; sums[12] = 0.0
+    for j, k in enumerate(SUM_KEYS):
+        T.episode_sums[k] = sums[:, j].clone()
+    single = hasattr(T, "gamma_assist") and not hasattr(T, "gamma_assist2")
+    if single:
+        T.gamma_assist = torch.full((n,), gamma, dtype=F)
+    else:
+        T.gamma_assist1, T.gamma_assist2 = torch.full((n,), 0.25, dtype=F), torch.full((n,), gamma, dtype=F)
+    T.episode_buf = torch.randint(0, 100, (n,), generator=g)
+    T.episode_count = torch.randint(0, 50, (n,), generator=g)
+    ids = torch.arange(0, n, 3)
+    ids = ids[ids != 12]
+    before = {"episode_buf": T.episode_buf.clone(), "episode_count": T.episode_count.clone()}
+    co.draw_reset(0)
+    T.reset_idx(ids)
+    ex = T.extras["episode"]
+    keys = sorted(ex)
+    ratio_keys = ["r1/Final reward", "r2/Final reward", "r3/Final reward", "Dense/Final reward", "Sparse/Final reward", "Guiding/Final reward",
+                  "Observed/Final reward"]
+    # the ratio tensors are computed for EVERY arena before the sums of `ids` are zeroed; only ids' entries are then zeroed (:485)
+    return {"sums": sums.numpy(), "gamma2": np.float32(gamma), "gamma1": np.float32(gamma if single else 0.25), "ids": ids.numpy().astype(np.int32),
+            "episode_buf_in": before["episode_buf"].to(torch.int32).numpy(), "episode_count_in": before["episode_count"].to(torch.int32).numpy(),
+            "episode_buf_out": T.episode_buf.to(torch.int32).numpy(), "episode_count_out": T.episode_count.to(torch.int32).numpy(),
+            "extras_keys": np.array(keys), "extras": np.array([float(ex[k]) for k in keys], np.float64),
+            "sums_after": torch.stack([T.episode_sums[k] for k in SUM_KEYS], 1).numpy(),
+            "ratios_after": torch.stack([T.episode_sums[k] for k in ratio_keys], 1).numpy(),
+            "fraction": T.fraction.numpy(), "threshold_high": np.float32(T.threshold_high), "reset_u": co.reset_u.copy(),
+            "commands": T.commands.numpy(), "episode_length_s": np.float32(T.max_episode_length_s)}
+
+
+def block_box_bounds():
+    """KAMMA_curr1.py:579-591 over the whole schedule (one arena: `min(1.0, tensor)`), x_min / x_max read from the frame"""
+    co = Cosim("KAMMA_curr1", 1, 600)
+    co.start(600)
+    T = co.task
+    steps = np.concatenate([np.linspace(0, 620000, 60).astype(np.int64), [1, 499999, 500000, 500001]])
+    lo, hi, cmd = [], [], []
+    for k, st in enumerate(steps):
+        T.sim_steps = torch.tensor([int(st)])
+        co.draw_reset(k)
+        T._u6 = {0: torch.from_numpy(co.reset_u[:, 6].copy())[0]}
+        x, om = T.sample_velocity_command(0)
+        lo.append(float(co.box_bounds[0])); hi.append(float(co.box_bounds[1])); cmd.append([float(x), float(om), float(co.reset_u[0, 6])])
+    return {"sim_steps": steps.astype(np.int32), "x_min": np.array(lo, np.float32), "x_max": np.array(hi, np.float32),
+            "command_u": np.array(cmd, np.float32), "max_sim_steps": np.float32(T.max_sim_steps), "x_range": np.array(T.command_x_range, np.float32)}
+
+
+def blocks():
+    out = {}
+    for k, v in enumerate(RUNS):
+        for key, val in block_prephysics(v, seed=k).items():
+            out[f"prephysics__{v}__{key}"] = val
+    for key, val in block_is_done().items():
+        out[f"is_done__{key}"] = val
+    for v in ("KAMMA", "KA_DDPG_4D", "KAMMA_eval"):
+        for key, val in block_reset_extras(v).items():
+            out[f"reset_extras__{v}__{key}"] = val
+    for key, val in block_box_bounds().items():
+        out[f"box__{key}"] = val
+    np.savez_compressed(os.path.join(HERE, "refexec_blocks.npz"), **out)
+    print("wrote refexec_blocks.npz", os.path.getsize(os.path.join(HERE, "refexec_blocks.npz")), "bytes")
+
+
 def main():
+    blocks()
     fixture, report = {}, {}
     for k, variant in enumerate(RUNS):
         n, T, events = RUNS[variant]

@@ -98,3 +98,120 @@ def test_lines_report_names_what_ran_and_what_was_removed():
     # and what needs Isaac Sim is named as removed
     assert "651,653" in k["pre_physics_step"] and "749" in k["is_done"].split("removed: ")[1]
     assert "701,707" in k["post_physics_step"].split("removed: ")[1]
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# single methods of the reference on seeded random states (tests/golden/refexec_blocks.npz): the unit-level functions of
+# the oracle — the same static functions orc_step calls — on wider numeric ranges than a trajectory reaches
+@pytest.fixture(scope="module")
+def blocks():
+    return np.load(os.path.join(G, "refexec_blocks.npz"))
+
+
+def _f32(x):
+    return np.ascontiguousarray(x, np.float32)
+
+
+@pytest.mark.parametrize("variant", VARIANTS)
+def test_pre_physics_step_of_every_env_file(oracle_lib, blocks, variant):
+    from oracle.binding import fptr, iptr
+    d = {k[len(f"prephysics__{variant}__"):]: blocks[k] for k in blocks.files if k.startswith(f"prephysics__{variant}__")}
+    cfg = build_config(variant=variant, num_envs=1)
+    n = len(d["v_delta"])
+    assert float(d["max_sim_steps"]) == cfg.max_sim_steps
+    vd, od, al, ar = (np.zeros(n, np.float32) for _ in range(4))
+    oracle_lib.orc_criteria(n, fptr(_f32(d["commands"][:, 0])), fptr(_f32(d["commands"][:, 2])), fptr(_f32(d["v_forward_projected"])),
+                            fptr(_f32(d["omega_z"])), cfg.Kp, cfg.Kp_omega, cfg.vehicle_mass, cfg.vehicle_inertia, cfg.policy_dt,
+                            fptr(vd), fptr(od), fptr(al), fptr(ar))
+    for got, key in ((vd, "v_delta"), (od, "omega_delta"), (al, "ac_left"), (ar, "ac_right")):
+        assert np.array_equal(got, d[key]), key                                     # KAMMA.py:604-619, exact
+    sched = np.zeros(n, np.float32)
+    oracle_lib.orc_gamma(n, iptr(np.ascontiguousarray(d["sim_steps"])), cfg.max_sim_steps, fptr(sched))
+    ref_g1 = d.get("gamma_assist1", d.get("gamma_assist"))
+    ref_g2 = d.get("gamma_assist2", d.get("gamma_assist"))
+    g1 = np.full(n, cfg.gamma1_const, np.float32) if cfg.gamma1_mode == _abi.GAMMA_CONST else sched
+    g2 = np.full(n, cfg.gamma2_const, np.float32) if cfg.gamma2_mode == _abi.GAMMA_CONST else sched
+    assert np.array_equal(g1, ref_g1) and np.array_equal(g2, ref_g2)                # :627-628 and the files that comment them out
+    if cfg.gamma1_mode == _abi.GAMMA_SCHEDULE:
+        assert (sched == 0).any() and (sched > 0.5).any()                           # the clamp at 0 is exercised
+    a = d["actions"]
+    a4 = a if a.shape[1] == 4 else (np.repeat(a, 2, axis=1) if a.shape[1] == 2 else np.repeat(a, 4, axis=1))  # KA_DDPG_2D.py:623-624, 1D :600-603
+    tq, wt, gd = np.zeros((n, 4), np.float32), np.zeros((n, 4), np.float32), np.zeros(n, np.float32)
+    oracle_lib.orc_mix(n, cfg.mix_mode, cfg.guiding_mode, fptr(_f32(a4)), fptr(al), fptr(ar), fptr(_f32(g1)), fptr(_f32(d["switch_u"])),
+                       cfg.action_scale, cfg.torque_clip, fptr(tq), fptr(wt), fptr(gd))
+    assert np.array_equal(tq, d["torques"])                                         # :632-636 / KA_DDPG_4D.py:627-631
+    assert np.array_equal(wt, d["wheel_torqs"]) and (np.abs(wt) == 4.0).any()       # :649
+    np.testing.assert_allclose(gd, d["guiding"], rtol=1e-6, atol=1e-6)              # :656 / KA_DDPG_4D.py:637 (torch.norm's order)
+    if "old_torques" in d:                                                          # KAMMA_eval.py:677-685
+        sums = np.zeros((n, 4), np.float32)
+        sums[:, 0], sums[:, 2] = d["sums_eval_in"][:, 0], d["sums_eval_in"][:, 1]
+        oracle_lib.orc_eval_sums(n, fptr(_f32(d["old_torques"])), fptr(wt), fptr(_f32(d["commands"][:, 0])), None, fptr(sums))
+        np.testing.assert_allclose(sums[:, [0, 2]], d["sums_eval_out"], rtol=2e-6, atol=1e-6)
+        assert np.array_equal(d["old_torques_out"], wt)
+
+
+def test_is_done_of_the_reference(oracle_lib, blocks):
+    from oracle.binding import fptr, iptr, u8ptr
+    d = {k[len("is_done__"):]: blocks[k] for k in blocks.files if k.startswith("is_done__")}
+    n = len(d["reset"])
+    rs, to = np.zeros(n, np.uint8), np.zeros(n, np.uint8)
+    oracle_lib.orc_is_done(n, iptr(np.ascontiguousarray(d["episode_buf"])), int(d["max_episode_length"]), fptr(_f32(d["quat"])),
+                           fptr(_f32(d["base_pos"])), 50.0, u8ptr(rs), u8ptr(to))
+    assert np.array_equal(to, d["timeout"]) and np.array_equal(rs, d["reset"])      # KAMMA.py:740-760
+    assert list(d["timeout"][:4]) == [0, 1, 1, 0]                                  # >= max_episode_length - 1 = 99
+    assert not d["out_of_bounds"][5:9].any()                                        # exactly on the bounds: strict comparisons
+    assert np.array_equal(d["reset"], d["has_fallen"] | d["timeout"] | d["out_of_bounds"])
+    assert d["has_fallen"].sum() > 10 and d["out_of_bounds"].sum() > 10
+
+
+@pytest.mark.parametrize("variant", ["KAMMA", "KA_DDPG_4D", "KAMMA_eval"])
+def test_reset_idx_extras_of_the_reference(oracle_lib, blocks, variant):
+    from oracle.binding import fptr
+    d = {k[len(f"reset_extras__{variant}__"):]: blocks[k] for k in blocks.files if k.startswith(f"reset_extras__{variant}__")}
+    ids, S = d["ids"], d["sums"]
+    n = len(S)
+    v = np.zeros((n, 16), np.float32)
+    for i in range(n):
+        oracle_lib.orc_reset_ratios(fptr(_f32(S[i])), float(d["gamma2"]), float(d["episode_length_s"]), fptr(v[i]))
+    ratio = v[:, 9:16]
+    # :470-476 for every arena, then :485 zeroes the entries of the resetting ones
+    expect = ratio.copy(); expect[ids] = 0.0
+    np.testing.assert_allclose(expect, d["ratios_after"], rtol=1e-6, atol=0, equal_nan=True)
+    assert np.isinf(d["ratios_after"]).any() or np.isnan(d["ratios_after"]).any()    # the zero final sums
+    keep = np.ones(n, bool); keep[ids] = False
+    assert np.array_equal(d["sums_after"][keep], S[keep]) and (d["sums_after"][ids] == 0).all()
+    ex = dict(zip([str(k) for k in d["extras_keys"]], d["extras"]))
+    L = float(d["episode_length_s"])
+    names = ["r1: Tracking error reward (squared errors)", "r2: Convergence reward (squared accelerations)",
+             "r3: Torque penalty (sum of squared torques)", "Dense reward", "Sparse reward", "Guiding reward", "Observed reward", "Final reward"]
+    with np.errstate(invalid="ignore"):
+        for j, k in enumerate(names):
+            np.testing.assert_allclose(v[ids, 1 + j].astype(np.float64).mean() / L, ex["rew_" + k], rtol=2e-5, atol=1e-6)       # :482-484
+        for j, k in enumerate(["r1", "r2", "r3", "Dense", "Sparse", "Guiding", "Observed"]):
+            mine = np.float32(v[ids, 9 + j].astype(np.float32).mean()) / np.float32(L)
+            np.testing.assert_allclose(mine, ex[f"rew_{k}/Final reward"], rtol=2e-5, equal_nan=True)
+    for k in _abi.EPISODE_INFO_ZERO_KEYS:
+        assert ex[k] == 0.0                                                                       # declared :217-220, never written
+    if variant == "KA_DDPG_4D":
+        assert ex["gamma assist"] == np.float32(d["gamma2"]) and "gamma_1 action assist" not in ex  # KA_DDPG_4D.py:487
+    else:
+        assert ex["gamma_1 action assist"] == np.float32(d["gamma1"]) and ex["gamma_2 reward assist"] == np.float32(d["gamma2"])
+    assert ex["terrain_level"] == 0.0
+    # counters :462-463, fraction :498 (after the zeroing)
+    eb, ec = d["episode_buf_in"].copy(), d["episode_count_in"].copy()
+    eb[ids] = 0; ec[ids] += 1
+    assert np.array_equal(eb, d["episode_buf_out"]) and np.array_equal(ec, d["episode_count_out"])
+    assert np.array_equal(d["fraction"], d["sums_after"][:, 0] / np.float32(d["threshold_high"]))
+
+
+def test_box_sampler_bounds_of_the_reference(oracle_lib, blocks):
+    from oracle.binding import fptr
+    d = {k[len("box__"):]: blocks[k] for k in blocks.files if k.startswith("box__")}
+    lo, hi = np.zeros(1, np.float32), np.zeros(1, np.float32)
+    for k, st in enumerate(d["sim_steps"]):
+        oracle_lib.orc_box_bounds(int(st), float(d["max_sim_steps"]), float(d["x_range"][0]), float(d["x_range"][1]), fptr(lo), fptr(hi))
+        np.testing.assert_allclose([lo[0], hi[0]], [d["x_min"][k], d["x_max"][k]], rtol=2e-7)        # KAMMA_curr1.py:579-591
+        x, om, u = d["command_u"][k]
+        np.testing.assert_allclose(max((hi[0] - lo[0]) * u + lo[0], 0.0), x, rtol=2e-7)            # :593-597 on the recorded draw
+        assert om == 0.0
+    assert d["x_min"][0] > 1.4 and d["x_min"][-1] == 1.0 and d["x_max"][-1] == 2.0                   # opens from 10 % to the full range
