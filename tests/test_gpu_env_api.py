@@ -407,3 +407,115 @@ def test_c_abi_from_plain_c(tmp_path):
     res = subprocess.run([exe], capture_output=True, text=True, timeout=120)
     assert res.returncode == 0, res.stdout + res.stderr
     assert "c abi ok: 1000 arenas, 1000 episodes" in res.stdout
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# the caller's side of the boundary as the REFERENCE's trainer exercised it (tests/golden/refexec_trainer_trace.json, made by
+# tests/golden/make_golden_trainer.py: Trainer.single_agent_train / single_agent_eval of src/my_trainers/base_KA_DDPG.py
+# executed against a recording environment built from the reference's own task statements)
+def _summary(v):
+    if isinstance(v, torch.Tensor):
+        return {"type": "tensor", "shape": list(v.shape), "dtype": str(v.dtype).replace("torch.", "")}
+    if isinstance(v, bool):
+        return {"type": "bool"}
+    if isinstance(v, int):
+        return {"type": "int"}
+    if isinstance(v, float):
+        return {"type": "float"}
+    if isinstance(v, dict):
+        return {"type": "dict", "keys": sorted(v), "values": {k: _summary(v[k]) for k in sorted(v)}}
+    if isinstance(v, (tuple, list)):
+        return {"type": "tuple", "items": [_summary(x) for x in v]}
+    if v is None:
+        return {"type": "none"}
+    return {"type": type(v).__name__}
+
+
+def _trace_runs():
+    import json
+    return json.load(open(os.path.join(G, "refexec_trainer_trace.json")))["runs"]
+
+
+@pytest.mark.parametrize("index", range(4))
+def test_trainer_trace_replays_on_the_device(index):
+    """Every attribute the reference's trainer read resolves on the product's VecEnv, every key exists, every call takes the
+    recorded argument and returns the recorded structure (types, shapes, dtypes, key lists), in the recorded order — including
+    the 26 `observed_components` reads (:184-209), `wheel_torqs / action_scale` (:212), the `infos["episode"]` loop (:259-262:
+    one `Info / <key>` tag per key) and, with one arena, the second `env.reset()` after the step that ended the episode
+    (:268-275, twice: the reference has the block twice), which must hand back the cached observation as skrl's wrapper does."""
+    from options_in_simulation_amd import VecEnv
+    run = _trace_runs()[index]
+    N = run["num_envs"]
+    env = VecEnv(num_envs=N, device="cuda:0", variant=run["variant"], seed=3)
+    events = [e for b in run["blocks"] for _ in range(b["repeat"]) for e in b["events"]] + run["tail"]
+    g = torch.Generator(device="cuda").manual_seed(0)
+    cur = {}          # what the trainer's local variables hold
+    tags, resets, steps = [], 0, 0
+
+    def check_tags():   # one `Info / <key>` tag per key of the step's infos["episode"] (logged by both copies of the block)
+        if "step_infos" in cur:
+            assert set(tags) == {"Info / " + k for k in cur["step_infos"].get("episode", {})}, (steps, sorted(tags))
+
+    def resolve(path):
+        obj = env
+        for name in path.split(".")[1:]:
+            obj = getattr(obj, name)
+        return obj
+    for n_ev, e in enumerate(events):
+        where = f"event {n_ev}: {e.get('op')} {e.get('path', e.get('name'))} {e.get('key', '')}"
+        if e["op"] == "getattr":
+            v = resolve(e["path"])
+            want = e["result"]
+            if want["type"] in ("tensor", "int", "float", "bool"):
+                got = _summary(v)
+                assert got == {k: want[k] for k in got}, (where, got, want)
+                if "value" in want:
+                    assert v == want["value"], where
+            elif want["type"] == "dict":
+                assert isinstance(v, dict), where
+            cur[e["path"]] = v
+        elif e["op"] == "getitem":
+            v = resolve(e["path"])[e["key"]]
+            assert _summary(v) == e["result"], (where, _summary(v), e["result"])
+        elif e["op"] == "call" and e["path"] == "env.reset":
+            states, infos = env.reset()
+            assert _summary((states, infos)) == e["result"], (where, _summary((states, infos)), e["result"])
+            if resets:   # not the first call: skrl's wrapper returns its cached observation (the last step's)
+                assert bool(cur["terminated"].any()) and torch.equal(states, cur["next_states"]), where
+            cur["states"], cur["infos"] = states, infos
+            resets += 1
+        elif e["op"] == "call" and e["path"] == "env.step":
+            (a,) = e["args"]
+            lo = float(env.action_space.low.min())
+            actions = (1.0 - lo) * torch.rand(a["shape"], device="cuda", generator=g) + lo
+            assert _summary(actions) == a
+            check_tags()
+            out = env.step(actions)
+            got = _summary(out)
+            assert got == e["result"], (where, got, e["result"])
+            cur["next_states"], cur["rewards"], cur["terminated"], cur["truncated"], cur["infos"] = out
+            cur["step_infos"] = out[4]
+            tags.clear()
+            steps += 1
+        elif e["op"] == "call" and e["path"] == "env.render":
+            env.render()
+        elif e["op"] == "agent" and e["name"] == "act":
+            assert _summary(cur["states"]) == e["states"], where
+        elif e["op"] == "agent" and e["name"] == "record_transition":
+            kw = e["kwargs"]
+            if run["method"] == "single_agent_train":   # :212 the executed torques replace the agent's action
+                executed = cur["env.task.wheel_torqs"] / cur["env.task.action_scale"]
+                assert _summary(executed) == kw["actions"], where
+            for k in ("states", "rewards", "next_states", "terminated", "truncated", "infos"):
+                assert _summary(cur[k]) == kw[k], (where, k, _summary(cur[k]), kw[k])
+            cur["states_before"] = cur["states"]
+        elif e["op"] == "agent" and e["name"] == "track_data" and e["tag"].startswith("Info / "):
+            tags.append(e["tag"])
+            v = cur["infos"]["episode"][e["tag"][len("Info / "):]]
+            assert isinstance(v, torch.Tensor) and v.numel() == 1 and isinstance(v.item(), float), where   # :261-262
+        elif e["op"] == "agent" and e["name"] in ("post_interaction", "base.post_interaction"):
+            if N > 1 or not bool(cur["terminated"].any()):
+                cur["states"] = cur["next_states"]      # :266-267 / :276
+    check_tags()
+    assert resets == run["env_reset_calls"] and steps == run["timesteps"]
+    env.close()
