@@ -27,6 +27,7 @@ Prints ONE JSON line on rank 0 (contract in the task statement) with two extra o
                 bounded sample of the same workload (rank 0, N=1 only).
 """
 import argparse
+import contextlib
 import hashlib
 import json
 import os
@@ -45,8 +46,9 @@ HBM_PEAK_GBS = 8000.0             # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
 # (tools/isa_census.py: 614 executed VALU instructions, 344 of them packed = 1 440 FLOP per
 # arena-substep with fma = 2; x 20 substeps; pre/post-physics not counted)
 FP32_VECTOR_PEAK_TFLOPS = 157.3   # MI355X_MICROARCH.md
-FLOP_PER_ENV_STEP = 20 * 1440.0
+FLOP_PER_ENV_STEP = 20 * 1440.0   # fallback only: the general packed kernel (profiles/*_isa_census.json keys the launched one)
 ARENAS_PER_GPU = 65536
+ROUND = "r3"                      # the profiles/<round>_* artefacts this checkout quotes
 KERNEL_SOURCES = ("ois_kernels.hip", "ois_device.h", "ois_physics.h", "ois_physics_pk.h", "Makefile")
 
 
@@ -99,10 +101,56 @@ def measured_copy_gbs(torch, device, mb=1024, reps=10):
     return 2.0 * n * 4 * reps / (e0.elapsed_time(e1) * 1e-3) / 1e9
 
 
-def pmc_traffic(n_arenas, profile="r2_pmc_traffic.json"):
+def algorithmic_flop_per_env_step():
+    """operations of the MODEL (docs/SPEC.md section 3.11, tools/spec_flops.py) — independent of any kernel's instructions"""
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import spec_flops
+    return float(spec_flops.flop_per_env_step())
+
+
+def executed_flop_per_env_step(kernel_id, substeps, profile=None):
+    """fp32 operations the LAUNCHED step-kernel instantiation executes per arena and env-step, from the committed ISA census
+    (tools/isa_census.py --json; quoted only when taken on this checkout's kernel sources). Returns (flop, valu, provenance)."""
+    profile = profile or f"{ROUND}_isa_census.json"
+    try:
+        d = json.load(open(os.path.join(ROOT, "profiles", profile)))
+    except (OSError, ValueError):
+        return FLOP_PER_ENV_STEP, None, {"file": "profiles/" + profile, "status": "missing: fallback constant of the general packed kernel"}
+    prov = {"file": "profiles/" + profile, "kernel_src_sha256": d.get("kernel_src_sha256"), "kernel": kernel_id}
+    k = d.get("kernels", {}).get(kernel_id)
+    if d.get("kernel_src_sha256") != kernel_source_hash() or k is None:
+        prov["status"] = "not quoted: the kernel sources changed since the census (or the instantiation is not in it); fallback constant"
+        return FLOP_PER_ENV_STEP, None, prov
+    lanes = 2 if kernel_id.startswith("step_kernel<2") else 1
+    prov["status"] = "quoted: executed path of the substep loop x substeps x lanes per arena (pre / post-physics not counted)"
+    return float(k["substep_flop_per_lane"] * lanes * substeps), float(k["substep_valu"] * substeps), prov
+
+
+def pmc_sq(n_arenas, profile=None):
+    """issue-slot figures of single ois_step launches in the actor loop from the committed SQ counter run
+    (tools/profile_sq.sh; quoted under the same rule as `traffic`)"""
+    profile = profile or f"{ROUND}_pmc_sq.json"
+    try:
+        d = json.load(open(os.path.join(ROOT, "profiles", profile)))
+    except (OSError, ValueError):
+        return None, {"file": "profiles/" + profile, "status": "missing"}
+    prov = {"file": "profiles/" + profile, "kernel_src_sha256": d.get("kernel_src_sha256"), "mode": d.get("mode")}
+    if int(d.get("arenas", -1)) != int(n_arenas) or d.get("kernel_src_sha256") != kernel_source_hash():
+        prov["status"] = "not quoted: profile taken at another arena count or on other kernel sources"
+        return None, prov
+    prov["status"] = "quoted: rocprofv3 --pmc, one pass per counter, SQ_* in quad-cycles"
+    return {"valu_instructions_per_wave_per_env_step": d["valu_instr_per_wave_per_step"],
+            "quad_cycles_per_valu_instruction": d["quad_cycles_per_valu_instr"],
+            "valu_active_fraction_of_wave_life": d["valu_active_fraction_of_wave_life"], "clock_GHz": d["clock_GHz_est"],
+            "issue_limited_us": d["issue_limited_ns"] * 1e-3, "dispatch_us": d["dispatch_ns"] * 1e-3,
+            "issue_slot_utilisation": d["issue_slot_utilisation"]}, prov
+
+
+def pmc_traffic(n_arenas, profile=None):
     """HBM bytes per step_kernel launch from the committed PMC run (bench.py cannot collect counters
     on itself). Quoted only when the profile was taken at this arena count AND on the kernel sources
     of this checkout (sha256 recorded by tools/profile_round.sh); returns (bytes | None, provenance)."""
+    profile = profile or f"{ROUND}_pmc_traffic.json"
     path = os.path.join(ROOT, "profiles", profile)
     try:
         d = json.load(open(path))
@@ -174,7 +222,11 @@ def maybe_self_launch(args, argv):
     if args.gpus <= 1 or "RANK" in os.environ or "LOCAL_RANK" in os.environ:
         return
     env = dict(os.environ)
+    # the host driver of this pool only supports dmabuf IPC: without it RCCL's cross-process buffer sharing fails with
+    # hipIpcGetMemHandle: invalid argument (already exported on the pool's boxes; kept for a shell that lost it)
     env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    # torch.distributed.run sets OMP_NUM_THREADS=1 per rank when it is unset and warns about it; the ranks' host work is a
+    # few ctypes calls per step, so a small fixed number is enough and leaves the box's 16 cores per GPU unclaimed
     env.setdefault("OMP_NUM_THREADS", "4")
     sys.exit(subprocess.call(spawn_command(args.gpus, argv, free_port()), env=env))
 
@@ -188,6 +240,9 @@ def parse_args(argv):
     ap.add_argument("--log-interval", type=int, default=800)
     ap.add_argument("--prewarm", type=int, default=40,
                     help="iterations of the same loop on a scratch environment before the W warm-up steps (untimed; 0 = off)")
+    ap.add_argument("--shards", type=int, default=1, metavar="K",
+                    help="A/B: the rank's arenas as K environments (arena_offset i * N / K) on K HIP streams, the actor on each "
+                         "shard's rows — the env step of one shard can overlap the actor of another; same arenas, same results")
     ap.add_argument("--no-actor", action="store_true", help="env-only loop (fixed random actions)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="skip the env-only / fused side measurements after the timed region")
@@ -202,7 +257,7 @@ def parse_args(argv):
     return ap.parse_args(argv)
 
 
-def side_measurements(torch, env, _abi, fixed_actions, N, launches=200, fused_k=20, fused_launches=20):
+def side_measurements(torch, env, _abi, fixed_actions, N, flop_exec, launches=200, fused_k=20, fused_launches=20):
     """after the timed region, same env (its state simply moves on): the env-only single-launch loop
     and the fused 20-step rollout — the two lines that show the kernel rather than the actor"""
     res = {}
@@ -221,9 +276,36 @@ def side_measurements(torch, env, _abi, fixed_actions, N, launches=200, fused_k=
         ms, cnt = env.profile_end()
         sec = ms / cnt * 1e-3
         res[name] = {"env_steps_per_s_wall": N * per * n / wall, "kernel_us_per_policy_step": sec / per * 1e6,
-                     "valu_frac": FLOP_PER_ENV_STEP * N * per / sec / 1e12 / FP32_VECTOR_PEAK_TFLOPS,
+                     "valu_frac": flop_exec * N * per / sec / 1e12 / FP32_VECTOR_PEAK_TFLOPS,
                      "hbm_frac_algorithmic": ALGO_BYTES_PER_ENV_STEP * N * per / sec / 1e9 / HBM_PEAK_GBS, "launches": n}
     return res
+
+
+def merge_raw(sts):
+    """the finished-episode statistics of several shards of one rank as one record (sums add, extremes combine)"""
+    from options_in_simulation_amd import _abi
+    m = _abi.OisStats()
+    m.return_min, m.return_max = float("inf"), float("-inf")
+    for s in sts:
+        m.episodes += s.episodes; m.return_sum += s.return_sum; m.return_sqsum += s.return_sqsum
+        m.length_sum += s.length_sum; m.steps += s.steps
+        m.return_min, m.return_max = min(m.return_min, s.return_min), max(m.return_max, s.return_max)
+    return m
+
+
+def rank_rows(rows):
+    """[[rank, device, arena_offset, arenas, elapsed_s, kernel_ms], ...] (one all-gather) -> the rank table of the line"""
+    return [{"rank": int(r), "device": int(d), "arena_offset": int(o), "arenas": int(n), "elapsed_s": float(e), "kernel_ms": float(k)}
+            for r, d, o, n, e, k in rows]
+
+
+def scaling_detail(table, steps, per_launch):
+    """per-GPU rates of the same run, so that a SCALE line can be read without a second run: each rank's own env-steps/s over
+    ITS elapsed time, and which rank set the (max-over-ranks) time the headline value uses"""
+    rates = [t["arenas"] * steps * per_launch / t["elapsed_s"] if t["elapsed_s"] > 0 else None for t in table]
+    slow = max(table, key=lambda t: t["elapsed_s"])
+    return {"per_gpu_env_steps_per_s": rates, "slowest_rank": slow["rank"], "slowest_elapsed_s": slow["elapsed_s"],
+            "fastest_elapsed_s": min(t["elapsed_s"] for t in table)}
 
 
 def dry_run(args, world, rank):
@@ -237,17 +319,20 @@ def dry_run(args, world, rank):
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("gloo", rank=rank, world_size=world)
     lo, hi = shard_range(args.arenas * world, rank, world)
-    mine = torch.tensor([rank, -1, lo, hi - lo], dtype=torch.int64)
-    allr = torch.empty(world * 4, dtype=torch.int64)
+    t0 = time.perf_counter()
+    time.sleep(0.01 * (rank + 1))   # a stand-in for the timed region: the slowest rank is the last one
+    mine = torch.tensor([rank, -1, lo, hi - lo, time.perf_counter() - t0, 0.0], dtype=torch.float64)
+    allr = torch.empty(world * 6, dtype=torch.float64)
     if world > 1:
         dist.all_gather_into_tensor(allr, mine)
     else:
         allr.copy_(mine)
     if rank == 0:
+        table = rank_rows(allr.view(world, 6).tolist())
         print(json.dumps({"dryrun": True, "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-                          "config": {"ranks": dist.get_world_size() if world > 1 else 1,
-                                     "rank_table": [{"rank": r, "device": d, "arena_offset": o, "arenas": n}
-                                                    for r, d, o, n in allr.view(world, 4).tolist()]}}), flush=True)
+                          "effective_warmup": args.warmup + args.prewarm,
+                          "config": {"ranks": dist.get_world_size() if world > 1 else 1, "rank_table": table},
+                          "scaling_detail": scaling_detail(table, args.steps, 1)}), flush=True)
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
@@ -290,15 +375,23 @@ def main(argv=None):
             dist.init_process_group(backend, rank=rank, world_size=world)
 
     N = args.arenas
-    cfg = build_config(variant=args.variant, num_envs=N, seed=42, arena_offset=rank * N)
+    shards = max(1, args.shards)
+    if N % shards or ((N // shards) % 16 and shards > 1):
+        raise SystemExit("--shards must divide the arena count into multiples of 16 (the reduction groups)")
+    if shards > 1 and (args.fused or args.terrain):
+        raise SystemExit("--shards is an A/B of the single-step actor loop")
+    n_shard = N // shards
+    cfgs = [build_config(variant=args.variant, num_envs=n_shard, seed=42, arena_offset=rank * N + i * n_shard) for i in range(shards)]
+    cfg = cfgs[0]
     terrain_note = "flat terrain"
     if args.domain_rand:
         terrain_note = "per-arena friction U(0.5,1.0) + plane slope {-0.3,-0.2,0,0.2,0.3}"
     if args.terrain:
         terrain_note = "height-field terrain, 6 x 2 random tiles of 10 m (stairs +-0.15 m, obstacles, pyramid slopes)"
 
-    def make_env():
-        e = NativeEnv(cfg, device)
+    def make_env(c=None):
+        c = cfg if c is None else c
+        e = NativeEnv(c, device)
         if args.domain_rand:
             e.randomize_params(0.5, 1.0, [-0.3, -0.2, 0.0, 0.2, 0.3])  # origin_terrain_generator.py:92
         if args.terrain:
@@ -310,82 +403,114 @@ def main(argv=None):
         return e
 
     actor = None if args.no_actor else build_actor(torch, device)
-    # Steady state before the contract's W warm-up steps: clocks, hipBLASLt's kernel choice and the code caches
-    # settle over the first few dozen iterations of the loop (20 timed steps after 5 warm-up steps: 0.549 ms per
-    # step, after 50: 0.510). A SCRATCH environment of the same configuration takes those iterations, so the
-    # measured environment's state (gamma schedule, episode phase) is exactly what W + K steps make it.
-    if args.prewarm > 0:
-        scratch = make_env()
-        sobs = scratch.buffer(_abi.BUF_OBS)
-        sfixed = torch.rand((N, cfg.action_dim), device=device)
-        for _ in range(args.prewarm):
-            if args.fused > 0:
-                scratch.rollout(args.fused, _abi.POLICY_RANDOM)
-            else:
-                with torch.no_grad():
-                    scratch.step(sfixed if actor is None else actor(sobs))
-        torch.cuda.synchronize()
-        scratch.close()
-        del scratch, sobs
-    env = make_env()
-    obs = env.buffer(_abi.BUF_OBS)
-    fixed_actions = torch.rand((N, cfg.action_dim), device=device, generator=torch.Generator(device).manual_seed(1))
-
     K_fused = max(0, args.fused)
     if K_fused:
         actor = None
 
-    def one_step():
-        with torch.no_grad():
-            a = fixed_actions if actor is None else actor(obs)
-        if K_fused:
-            env.rollout(K_fused, _abi.POLICY_RANDOM)
-        else:
-            env.step(a)
+    def loop(envs, obs_list, fixed_list, streams, steps):
+        """the benchmark's step, `steps` times: actor (or fixed actions) -> ois_step (or a fused rollout) per shard"""
+        for _ in range(steps):
+            for e, o, f, st in zip(envs, obs_list, fixed_list, streams):
+                ctx = torch.cuda.stream(st) if st is not None else contextlib.nullcontext()
+                with ctx, torch.no_grad():
+                    if K_fused:
+                        e.rollout(K_fused, _abi.POLICY_RANDOM)
+                    else:
+                        e.step(f if actor is None else actor(o))
+
+    def build_shards():
+        envs = [make_env(c) for c in cfgs]
+        obs_l = [e.buffer(_abi.BUF_OBS) for e in envs]
+        fixed = [torch.rand((n_shard, cfg.action_dim), device=device, generator=torch.Generator(device).manual_seed(1 + i))
+                 for i in range(shards)]
+        streams = [torch.cuda.Stream(device) for _ in range(shards)] if shards > 1 else [None]
+        return envs, obs_l, fixed, streams
+
+    # What a cold process gives, and the steady state before the contract's W warm-up steps. A SCRATCH set of environments of
+    # the same configuration first does exactly the contract's W + K steps, timed (`cold_start`: clocks, hipBLASLt's kernel
+    # choice and the code caches are still settling), then `--prewarm` more untimed iterations. The measured environments'
+    # state (gamma schedule, episode phase) is exactly what W + K steps make it.
+    cold = None
+    if args.prewarm > 0:
+        sc = build_shards()
+        loop(*sc, args.warmup)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        loop(*sc, args.steps)
+        torch.cuda.synchronize()
+        cold = (time.perf_counter() - t0) / args.steps * 1e3
+        loop(*sc, args.prewarm)
+        torch.cuda.synchronize()
+        for e in sc[0]:
+            e.close()
+        del sc
+    envs, obs_l, fixed_l, streams = build_shards()
+    env, fixed_actions = envs[0], fixed_l[0]
 
     def barrier():
         if dist_on:
             dist.barrier()
         torch.cuda.synchronize()
 
-    for _ in range(args.warmup):
-        one_step()
+    loop(envs, obs_l, fixed_l, streams, args.warmup)
     if dist_on:  # warm the collective too
         gather_stats(env.stats(reset_after=True), device)
+        for e in envs[1:]:
+            e.stats(reset_after=True)
     barrier()
-    env.profile_begin()  # start / stop events on every step kernel's own dispatch packet
+    for e in envs:
+        e.profile_begin()  # start / stop events on every step kernel's own dispatch packet
     t0 = time.perf_counter()
     gathered = None
     for s in range(args.steps):
-        one_step()
+        loop(envs, obs_l, fixed_l, streams, 1)
         if (s + 1) % args.log_interval == 0 or s + 1 == args.steps:
-            st = env.stats(reset_after=True)           # one tiny D2H per logging interval
+            sts = [e.stats(reset_after=True) for e in envs]      # one tiny D2H per logging interval (and shard)
+            st = sts[0] if shards == 1 else merge_raw(sts)
             gathered = gather_stats(st, device) if dist_on else [st]
     barrier()
     elapsed = time.perf_counter() - t0
-    kernel_ms_total, launches = env.profile_end()
+    my_elapsed = elapsed
+    prof = [e.profile_end() for e in envs]
+    kernel_ms_total, launches = sum(p[0] for p in prof), sum(p[1] for p in prof)
+    kernel_ms = kernel_ms_total / max(1, launches)
+    # the same K steps without the event pairs (hipLaunchKernel instead of hipExtLaunchKernel + two events): what the
+    # instrumentation of the timed region costs
+    torch.cuda.synchronize()
+    t1 = time.perf_counter()
+    loop(envs, obs_l, fixed_l, streams, args.steps)
+    torch.cuda.synchronize()
+    uninstrumented_ms = (time.perf_counter() - t1) / args.steps * 1e3
     if dist_on:
         t = torch.tensor([elapsed], dtype=torch.float64, device=comm_device)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
-        # who took part: every rank's (rank, device, arena_offset, arenas) through the same collective
-        mine = torch.tensor([rank, dev_index, cfg.arena_offset, N], dtype=torch.int64, device=comm_device)
-        allr = torch.empty(world * 4, dtype=torch.int64, device=comm_device)
+        # who took part and how long each took: (rank, device, arena_offset, arenas, elapsed_s, kernel_ms) through one all-gather
+        mine = torch.tensor([rank, dev_index, cfg.arena_offset, N, my_elapsed, kernel_ms], dtype=torch.float64, device=comm_device)
+        allr = torch.empty(world * 6, dtype=torch.float64, device=comm_device)
         dist.all_gather_into_tensor(allr, mine)
-        rank_table = allr.view(world, 4).cpu().tolist()
+        rank_table = rank_rows(allr.view(world, 6).cpu().tolist())
     else:
-        rank_table = [[0, dev_index, int(cfg.arena_offset), N]]
+        rank_table = rank_rows([[0, dev_index, int(cfg.arena_offset), N, my_elapsed, kernel_ms]])
 
-    kernel_ms = kernel_ms_total / max(1, launches)
     per_launch = max(1, K_fused)
     total_env_steps = float(N) * world * args.steps * per_launch
     value = total_env_steps / elapsed
 
     if rank == 0:
-        flops = FLOP_PER_ENV_STEP * N * per_launch / (kernel_ms * 1e-3) / 1e12
-        hbm = ALGO_BYTES_PER_ENV_STEP * N * per_launch / (kernel_ms * 1e-3) / 1e9
+        kinfo = env.kernel_info()
+        kid = kinfo.split(" ")[0]
+        nsub = cfg.decimation + cfg.extra_substeps
+        flop_exec, valu_exec, flop_prov = executed_flop_per_env_step(kid, nsub)
+        flop_algo = algorithmic_flop_per_env_step()
+        arenas_per_launch = n_shard
+        flops = flop_exec * arenas_per_launch * per_launch / (kernel_ms * 1e-3) / 1e12
+        flops_algo = flop_algo * arenas_per_launch * per_launch / (kernel_ms * 1e-3) / 1e12
+        hbm = ALGO_BYTES_PER_ENV_STEP * arenas_per_launch * per_launch / (kernel_ms * 1e-3) / 1e9
         copy_gbs = measured_copy_gbs(torch, device)  # after the timed region
-        traffic, traffic_prov = (None, {"status": "not quoted for this workload"}) if (args.terrain or K_fused) else pmc_traffic(N)
+        plain = not (args.terrain or K_fused or shards > 1)
+        traffic, traffic_prov = pmc_traffic(N) if plain else (None, {"status": "not quoted for this workload"})
+        sq, sq_prov = pmc_sq(N) if (plain and actor is not None) else (None, {"status": "not quoted for this workload"})
         gamma_note = ""
         if args.variant in ("KAMMA", "KAMMA_medium", "KAMMA_curr1", "KAMMA_curr2") and actor is not None:
             g = 1.0 - (args.warmup + args.steps + 1) / float(cfg.max_sim_steps)
@@ -394,47 +519,70 @@ def main(argv=None):
         out = {
             "metric": "env-steps/sec at 65 536 parallel arenas; achieved HBM GB/s vs roofline",
             "value": value, "unit": "env-steps/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "effective_warmup": args.warmup + args.prewarm,
             "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": f"{N} arenas/GPU, {terrain_note}, {args.variant} task, "
                                    + (f"in-kernel random-torque policy, {K_fused} policy steps per launch (env only)" if K_fused else
                                       "fixed random actions (env only)" if actor is None else
                                       "scripted actor MLP 6-512-512-128-4 (fp32 PyTorch-ROCm) inference in-loop")
+                                   + (f", as {shards} shards of {n_shard} arenas on {shards} HIP streams" if shards > 1 else "")
                                    + (" [BASELINE.json configs[3]]" if (args.domain_rand or args.terrain) else " [BASELINE.json configs[2]]")
                                    + gamma_note,
-                       "arenas_per_gpu": N, "prewarm_scratch_iterations": args.prewarm, "substeps_per_step": cfg.decimation + cfg.extra_substeps,
+                       "arenas_per_gpu": N, "shards": shards, "prewarm_scratch_iterations": args.prewarm, "substeps_per_step": nsub,
                        "solver_iterations": cfg.solver_iterations, "sharding": f"arenas x{world}, no data-path collective",
                        "stats_allgather_every": args.log_interval,
                        "ranks": dist.get_world_size() if dist_on else 1,
                        "backend": (dist.get_backend() + (" (RCCL)" if backend == "nccl" else "")) if dist_on else "none",
-                       "rank_table": [{"rank": r, "device": d, "arena_offset": o, "arenas": n} for r, d, o, n in rank_table]},
+                       "rank_table": rank_table},
+            "warmup_detail": {"contract_warmup_steps": args.warmup, "prewarm_iterations_on_scratch_environments": args.prewarm,
+                              "cold_start_ms_per_step": cold,
+                              "cold_start_what": "the same W + K steps in this process BEFORE anything was warm (scratch environments, then "
+                                                 "the pre-warm iterations): what a run with only the contract's W warm-up steps would report",
+                              "uninstrumented_ms_per_step": uninstrumented_ms,
+                              "uninstrumented_what": "K more steps right after the timed region without the two events per launch "
+                                                     "(plain hipLaunchKernel): the cost of timing the kernel inside the timed region"},
             "roofline": {"bound": "valu", "achieved": flops, "peak": FP32_VECTOR_PEAK_TFLOPS, "unit": "TFLOP/s",
                          "frac": flops / FP32_VECTOR_PEAK_TFLOPS, "traffic": traffic,
-                         "kernel": "step_kernel", "kernel_ms": kernel_ms, "kernel_launches": launches,
+                         "kernel": kinfo, "kernel_ms": kernel_ms, "kernel_launches": launches, "arenas_per_launch": arenas_per_launch,
                          "kernel_ms_how": "mean over the timed region of hipEventElapsedTime(start, stop) with both events "
                                           "attached to the kernel's dispatch packet (hipExtLaunchKernel): kernel begin -> end as "
                                           "rocprofv3 --kernel-trace measures it, no launch gap",
-                         "flop_per_env_step": FLOP_PER_ENV_STEP,
-                         "flop_how": "ISA instruction mix of the substep loop x 20 substeps (tools/isa_census.py: 1 440 FLOP per "
-                                     "arena-substep, fma = 2); one wave per SIMD issues one VALU instruction per ~4 cycles, "
-                                     "i.e. at most ~50 % of the vector peak with the kernel's half-packed mix",
+                         "flop_per_env_step": flop_exec, "flop_provenance": flop_prov,
+                         "flop_how": "EXECUTED fp32 operations of the launched instantiation: ISA instruction mix of its substep loop x "
+                                     "substeps (tools/isa_census.py, fma = 2, packed = x 2); a kernel that issues more instructions scores "
+                                     "higher on this figure, hence the two instruction-independent ones beside it",
+                         "flop_algorithmic_per_env_step": flop_algo,
+                         "flop_algorithmic_how": "operations of the MODEL counted from docs/SPEC.md section 3.11 (tools/spec_flops.py): "
+                                                 "20 substeps x 1 653 + 171 for the policy step's own arithmetic",
+                         "algorithmic": {"achieved": flops_algo, "frac": flops_algo / FP32_VECTOR_PEAK_TFLOPS, "unit": "TFLOP/s"},
+                         "executed_over_algorithmic": flop_exec / flop_algo,
+                         "valu_issue": sq, "valu_issue_provenance": sq_prov,
+                         "valu_issue_live": None if valu_exec is None else {
+                             "valu_instructions_per_lane_per_env_step_substeps_only": valu_exec,
+                             "issue_limited_us_at_2_GHz": valu_exec * 4.0 / 2.0e3,
+                             "issue_slot_utilisation_at_2_GHz": valu_exec * 4.0 / 2.0e3 / (kernel_ms * 1e3),
+                             "what": "substep-loop VALU instructions of the census x 4 cycles (one wave per SIMD issues one VALU instruction per "
+                                     "4 cycles) / 2.0 GHz over this run's event-timed kernel duration; `valu_issue` has the counters"},
                          "hbm": {"achieved": hbm, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": hbm / HBM_PEAK_GBS,
-                                 "algorithmic_bytes_per_launch": ALGO_BYTES_PER_ENV_STEP * N * per_launch,
+                                 "algorithmic_bytes_per_launch": ALGO_BYTES_PER_ENV_STEP * arenas_per_launch * per_launch,
                                  "measured_copy": {"GB/s": copy_gbs, "frac": hbm / copy_gbs,
                                                    "what": "1 GiB device-to-device torch copy on this GPU, read + write bytes / time"}},
                          "traffic_provenance": traffic_prov,
-                         "note": "fp32-VALU issue bound, not HBM bound: 20 substeps x 4-iteration contact solve = ~12.6k VALU "
+                         "note": "fp32-VALU issue bound, not HBM bound: 20 substeps x 4-iteration contact solve = ~12k VALU "
                                  "instructions per env-step, more than half of them packed; one wave per SIMD at 65 536 arenas "
                                  "(1024 waves on 1024 SIMDs). BASELINE.md's >= 50 % HBM target would need <= 140 lane-instructions "
                                  "per arena-substep; DESIGN.md section 4"},
-            "env_only_env_steps_per_s": N * per_launch / (kernel_ms * 1e-3),
+            "env_only_env_steps_per_s": arenas_per_launch * per_launch / (kernel_ms * 1e-3),
+            "kernel_src_sha256": kernel_source_hash(),
+            "scaling_detail": scaling_detail(rank_table, args.steps, per_launch),
         }
         if gathered:
             m = merge_stats(gathered)
             out["episode_stats"] = {"episodes": m["episodes"], "return_mean": m["return_mean"], "return_std": m["return_std"],
                                     "episodes_per_rank": [g.episodes for g in gathered]}
-        if not args.no_extras and not K_fused and not args.terrain:
-            out["env_only"] = side_measurements(torch, env, _abi, fixed_actions, N)
+        if not args.no_extras and not K_fused and not args.terrain and shards == 1:
+            out["env_only"] = side_measurements(torch, env, _abi, fixed_actions, N, flop_exec)
         if world == 1 and not args.no_cpu_baseline:
             try:
                 out["cpu_baseline"] = cpu_baseline(N)
@@ -445,7 +593,8 @@ def main(argv=None):
     if dist_on:
         dist.barrier()
         dist.destroy_process_group()
-    env.close()
+    for e in envs:
+        e.close()
 
 
 if __name__ == "__main__":

@@ -62,7 +62,9 @@ extern "C" {
  * 4: ois_config: wheel_limit_velocity / wheel_limit_damping (two of the reserved words); state blobs of
  *    version 3 do not load (the solver and the joint model changed, see docs/SPEC.md 3.3, 3.5);
  *    OIS_CMD_LEVEL, OIS_BUF_CMD_FRACTION, ois_profile_* */
-#define OIS_ABI_VERSION 4
+/* 5: ois_kernel_info; state blobs carry the flat-plane flag (version 4 blobs do not load); ois_config validation
+ *    also refuses an unstable joint resistance and a negative depenetration velocity */
+#define OIS_ABI_VERSION 5
 
 /* error codes */
 #define OIS_OK 0
@@ -291,6 +293,13 @@ int ois_buffer(ois_env* env, int id, void** ptr_device, size_t* bytes);
  * from Philox keyed by the global arena id. n_slopes == 0 keeps the flat plane. */
 int ois_randomize_params(ois_env* env, float mu_lo, float mu_hi, const float* slopes_host,
                          int n_slopes, void* stream);
+
+/* Which step-kernel instantiation ois_step / ois_rollout launch for this environment right now (measurement aid:
+ * bench.py keys its per-kernel figures on it), e.g. "step_kernel<1,1,4,1> lanes_per_arena=1 packed iterations=4(unrolled)
+ * plane=flat" (the template arguments: lanes per arena, packed, unrolled iterations, flat). plane=flat: no ois_randomize_params slopes since ois_create (or a blob saved so) and no terrain — the
+ * kernel then takes the plane normal as (0, 0, 1) and does not read it from OIS_BUF_PARAMS; a caller that writes
+ * normals into that buffer itself must go through ois_randomize_params, or set OIS_FLAT=0. */
+int ois_kernel_info(const ois_env* env, char* out, size_t cap);
 
 /* push_robots (KAMMA.py:729-733): the world linear velocity x, y of EVERY arena is replaced by U(-1, 1)
  * draws (Philox purpose 7, counter = the arena's sim_steps; torch_rand_float(-1.0, 1.0, ...)). The reference

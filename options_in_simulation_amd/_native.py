@@ -20,7 +20,7 @@ SYMBOLS = (
     "ois_episode_info", "ois_stats_fetch", "ois_env0_diag", "ois_state_bytes", "ois_save_state",
     "ois_load_state", "ois_replay_bytes", "ois_replay_attach", "ois_replay_buffer", "ois_replay_cursor",
     "ois_gae_scratch_bytes", "ois_gae", "ois_terrain_attach", "ois_height_scan", "ois_replay_sample",
-    "ois_profile_begin", "ois_profile_end", "ois_minfield_bytes", "ois_push_robots",
+    "ois_profile_begin", "ois_profile_end", "ois_minfield_bytes", "ois_push_robots", "ois_kernel_info",
 )
 
 _lib = None
@@ -86,6 +86,7 @@ def load() -> C.CDLL:
     L.ois_height_scan.argtypes = [vp, vp, vp]
     L.ois_minfield_bytes.argtypes = [C.c_int, C.c_int]
     L.ois_minfield_bytes.restype = C.c_size_t
+    L.ois_kernel_info.argtypes = [vp, C.c_char_p, C.c_size_t]
     L.ois_profile_begin.argtypes = [vp]
     L.ois_profile_end.argtypes = [vp, C.POINTER(C.c_double), C.POINTER(C.c_longlong)]
     if L.ois_abi_version() != _abi.ABI_VERSION:

@@ -123,7 +123,7 @@ OIS_DEV void store_arena(const DevConsts& K, const DevBuffers& B, int i, int h, 
 }
 
 // ------------------------------------------------------------------ the step kernel ---
-template <int LPA, bool PK, bool TER, int NIT>
+template <int LPA, bool PK, bool TER, int NIT, bool FLAT = false>
 OIS_DEV void step_body(const DevConsts& K, const DevBuffers& B, const float* __restrict__ actions,
                        float* __restrict__ reward_sum, int N, int ksteps, int policy, int rp_head) {
   constexpr int W = 4 / LPA;
@@ -265,11 +265,11 @@ OIS_DEV void step_body(const DevConsts& K, const DevBuffers& B, const float* __r
 #pragma unroll
       for (int k = 0; k < 3; ++k) X.to[k] = tor[k];
       if constexpr (PK && LPA == 1) {  // packed fp32 over wheel pairs (ois_physics_pk.h)
-        substep_pk<true, TER, NIT>(K, B.ter, X);
-        for (int i = 1; i < K.nsub; ++i) substep_pk<false, TER, NIT>(K, B.ter, X);
+        substep_pk<true, TER, NIT, FLAT>(K, B.ter, X);
+        for (int i = 1; i < K.nsub; ++i) substep_pk<false, TER, NIT, FLAT>(K, B.ter, X);
       } else if constexpr (PK && LPA == 2) {  // a lane pair per arena, each lane one packed side pair
-        substep_pk2<true, NIT>(K, wheel0, X);
-        for (int i = 1; i < K.nsub; ++i) substep_pk2<false, NIT>(K, wheel0, X);
+        substep_pk2<true, NIT, FLAT>(K, wheel0, X);
+        for (int i = 1; i < K.nsub; ++i) substep_pk2<false, NIT, FLAT>(K, wheel0, X);
       } else {
         substep<true, LPA, TER, NIT>(K, B.ter, wheel0, X);
         for (int i = 1; i < K.nsub; ++i) substep<false, LPA, TER, NIT>(K, B.ter, wheel0, X);
@@ -363,8 +363,9 @@ OIS_DEV void step_body(const DevConsts& K, const DevBuffers& B, const float* __r
     const float ob[6] = {clipf(S.cmd[0], -co, co), clipf(S.cmd[2], -co, co), clipf(vd, -co, co),
                          clipf(od, -co, co),       clipf(lin_acc, -co, co),  clipf(ang_acc, -co, co)};
     // KAMMA_g1d_g21.py:838-842: get_observations replaces a (nearly) zero rew_buf[0] by 1e-12 before it is
-    // returned; the episode sums above already hold the unmodified value (local arena 0, like the diagnostics)
-    if (K.env0_reward_guard && arena == 0 && fabs((double)rew) < 1e-12) rew = 1e-12f;
+    // returned; the episode sums above already hold the unmodified value. Global arena 0: a sharded run equals the
+    // unsharded one (the env-0 diagnostics below stay per environment, i.e. per shard)
+    if (K.env0_reward_guard && gid == 0 && fabs((double)rew) < 1e-12) rew = 1e-12f;
     rsum += rew;
     // FIFO transition memory row (train_kaddpg_4d_nofifo_random_RLIL.py:147-156; executed action:
     // base_KA_DDPG.py:212)
@@ -382,6 +383,10 @@ OIS_DEV void step_body(const DevConsts& K, const DevBuffers& B, const float* __r
 #pragma unroll
     for (int k = 0; k < 6; ++k) o_prev[k] = ob[k];
     // outputs (only the last step of a rollout is observable)
+    // (Sending the [N, 6] observation rows through an LDS tile so that they leave as whole 128-byte lines — one float4
+    // per lane instead of three float2 at a 24-byte stride — was built and measured in round 3: 9.42 vs 8.96 us for a
+    // one-substep launch back to back, 36.25 vs 35.88 behind a cache sweep (profiles/r3_ab_flat_transposed.txt): the
+    // barrier and the LDS round trip cost more than the partial-line stores, which L2 merges anyway. Not kept.)
     if (last && valid) {
       if (h == 0) {
         float* o = B.obs + (size_t)arena * 6;
@@ -445,17 +450,20 @@ OIS_DEV void step_body(const DevConsts& K, const DevBuffers& B, const float* __r
 // the actor's GEMMs the scratch traffic of the second is cold: 59.3 vs 39.6 us per launch under
 // rocprofv3 (profiles/r1_waves_ab.txt), hence the size rule. OIS_STEP_WAVES=1|2 overrides it.
 // The terrain kernels lose 2-4 % under the limit (59-110 spills) and always keep the default.
-template <int LPA, bool PK, int NIT>
+//  * FLAT (the packed, 4-iteration shells only): every arena stands on the default plane n = (0, 0, 1) — no
+//    ois_randomize_params slopes since ois_create, no terrain: the host's knowledge (ois_env::flat) — so the
+//    substeps take n_b and n.p from R and p directly (-12 instructions per substep, ois_physics_pk.h).
+template <int LPA, bool PK, int NIT, bool FLAT = false>
 __global__ __launch_bounds__(kBlock) void step_kernel(DevConsts K, DevBuffers B, const float* __restrict__ actions,
                                                       float* __restrict__ reward_sum, int N, int ksteps, int policy,
                                                       int rp_head) {
-  step_body<LPA, PK, false, NIT>(K, B, actions, reward_sum, N, ksteps, policy, rp_head);
+  step_body<LPA, PK, false, NIT, FLAT>(K, B, actions, reward_sum, N, ksteps, policy, rp_head);
 }
-template <bool PK, int NIT>
+template <bool PK, int NIT, bool FLAT = false>
 __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(2, 2)))
 void step_kernel_w2(DevConsts K, DevBuffers B, const float* __restrict__ actions, float* __restrict__ reward_sum, int N,
                     int ksteps, int policy, int rp_head) {
-  step_body<1, PK, false, NIT>(K, B, actions, reward_sum, N, ksteps, policy, rp_head);
+  step_body<1, PK, false, NIT, FLAT>(K, B, actions, reward_sum, N, ksteps, policy, rp_head);
 }
 template <bool PK, int NIT>
 __global__ __launch_bounds__(kBlock) void step_kernel_terrain(DevConsts K, DevBuffers B, const float* __restrict__ actions,
@@ -940,6 +948,12 @@ int validate(const ois_config* c) {
   if (!(c->baumgarte > 0.0f && c->baumgarte < 1.0f)) return fail(OIS_EINVAL, "baumgarte must be in (0, 1)");
   if (!(c->wheel_damping >= 0.0f) || !(c->wheel_limit_damping >= 0.0f) || !(c->wheel_limit_velocity >= 0.0f))
     return fail(OIS_EINVAL, "wheel joint resistance constants must be >= 0");
+  // the joint resistance is integrated explicitly, spin += dt / Is * (tau - c1 w - c2 over) (SPEC 3.3): it oscillates
+  // with growing amplitude once (c1 + c2) dt / Is reaches 2
+  if (!((c->wheel_damping + c->wheel_limit_damping) * c->sim_dt / c->wheel_spin_inertia < 2.0f))
+    return fail(OIS_EINVAL, "(wheel_damping + wheel_limit_damping) * sim_dt / wheel_spin_inertia must be < 2 (explicit integration)");
+  // the normal-row bias is min(-gap / dt, -beta gap / dt, v_dep) (SPEC 3.4): v_dep < 0 would push separating contacts
+  if (!(c->max_depenetration_velocity >= 0.0f)) return fail(OIS_EINVAL, "max_depenetration_velocity must be >= 0");
   return OIS_OK;
 }
 
@@ -1010,6 +1024,9 @@ struct ois_env {
   int lpa;  // lanes per arena of the step kernel (1 | 2), chosen by pick_lpa()
   int lpa_forced;  // OIS_LANES_PER_ARENA: 0 = choose by size
   int simds;
+  bool flat;    // every arena stands on the default plane n = (0, 0, 1): no ois_randomize_params slopes since ois_create /
+                // the last ois_load_state of a flat blob (OIS_FLAT=0 forces the general kernels)
+  bool flat_allowed;
   bool packed;  // LPA = 1 only: per-wheel math on v_pk_*_f32 (ois_physics_pk.h)
   bool waves2;  // plane kernel shell held to 256 registers (step_kernel_w2), chosen by arena count
   uint64_t seed;  // seed of the last ois_reset (RNG key of the episode stream)
@@ -1157,6 +1174,9 @@ int ois_create(const ois_config* cfg, int device, void* workspace_device, size_t
     // OIS_PACKED=0 selects the scalar kernel.
     const char* pk = getenv("OIS_PACKED");
     e->packed = pk ? (pk[0] == '1') : true;
+    const char* fl = getenv("OIS_FLAT");
+    e->flat_allowed = fl ? (fl[0] == '1') : true;
+    e->flat = e->flat_allowed;  // params start as (mu, 0, 0, 1) below
     // Plane kernel shell (see step_kernel / step_kernel_w2): the 256-register one only where a
     // second wave per SIMD exists to be had, i.e. more arenas than one wave per SIMD covers.
     int simds = 1024;
@@ -1300,7 +1320,12 @@ static int launch_kernel(ois_env* e, int k, int policy, const float* actions, fl
   // instantiations: lanes per arena (2 = experiment), packed wheel pairs, height-field terrain
   // (ois_terrain_attach refuses LPA = 2), solver iterations unrolled (the default 4) or run-time
   const bool it4 = e->K.iters == 4;
-  if (e->lpa == 2) {
+  const bool flat = e->flat && e->packed && it4 && !e->B.ter.on;  // the FLAT shells exist for the default configuration
+  if (flat) {
+    if (e->lpa == 2) OIS_LAUNCH((step_kernel<2, true, 4, true>), 2);
+    else if (e->waves2) OIS_LAUNCH((step_kernel_w2<true, 4, true>), 1);
+    else OIS_LAUNCH((step_kernel<1, true, 4, true>), 1);
+  } else if (e->lpa == 2) {
     if (e->packed) { if (it4) OIS_LAUNCH((step_kernel<2, true, 4>), 2); else OIS_LAUNCH((step_kernel<2, true, 0>), 2); }
     else OIS_LAUNCH((step_kernel<2, false, 0>), 2);
   }
@@ -1385,6 +1410,23 @@ int ois_randomize_params(ois_env* e, float mu_lo, float mu_hi, const float* slop
                      mu_lo, mu_hi, tbl, n_slopes);
   HIP_TRY(hipGetLastError());
   if (n_slopes > 0) HIP_TRY(hipStreamSynchronize((hipStream_t)stream));  // slopes_host may be freed by the caller
+  e->flat = e->flat_allowed && n_slopes == 0;  // without slopes the kernel wrote n = (0, 0, 1) for every arena
+  return OIS_OK;
+}
+
+int ois_kernel_info(const ois_env* e, char* out, size_t cap) {
+  if (!e || !out || cap == 0) return fail(OIS_EINVAL, "null argument");
+  const bool it4 = e->K.iters == 4;
+  const bool flat = e->flat && e->packed && it4 && !e->B.ter.on;
+  const int nit = it4 ? 4 : 0, pk = e->packed ? 1 : 0;
+  char id[64];
+  if (e->B.ter.on) std::snprintf(id, sizeof id, "step_kernel_terrain<%d,%d>", pk, nit);
+  else if (e->lpa == 2) std::snprintf(id, sizeof id, "step_kernel<2,%d,%d,%d>", pk, pk ? nit : 0, flat ? 1 : 0);
+  else if (e->waves2) std::snprintf(id, sizeof id, "step_kernel_w2<%d,%d,%d>", pk, nit, flat ? 1 : 0);
+  else std::snprintf(id, sizeof id, "step_kernel<1,%d,%d,%d>", pk, nit, flat ? 1 : 0);
+  std::snprintf(out, cap, "%s lanes_per_arena=%d %s iterations=%s plane=%s%s", id, e->B.ter.on ? 1 : e->lpa,
+                e->packed ? "packed" : "scalar", it4 ? "4(unrolled)" : "runtime", e->B.ter.on ? "height-field" : (flat ? "flat" : "per-arena"),
+                e->K.cmd_sampler == OIS_CMD_LEVEL ? " +level_command_kernel" : "");
   return OIS_OK;
 }
 
@@ -1573,6 +1615,7 @@ struct StateHeader {
   uint64_t terrain_hash;  // descriptor of the attached terrain, 0 = none
   int32_t rp_size, rp_head, rp_filled;  // transition memory cursor (the memory itself is the caller's)
   int32_t cmd_sampler;    // effective sampler (a terrain with curriculum switches it)
+  int32_t plane_flat;     // every params row holds n = (0, 0, 1) (ois_env::flat)
 };
 
 static uint64_t fnv1a(const void* p, size_t n, uint64_t h = 1469598103934665603ull) {
@@ -1619,6 +1662,7 @@ int ois_save_state(ois_env* e, void* host_blob, size_t bytes, void* stream) {
   h.seed = e->seed; h.steps_done = e->steps_done; h.payload = e->L.total;
   h.config_hash = fnv1a(&e->cfg, sizeof e->cfg); h.terrain_hash = terrain_hash(e);
   h.rp_size = e->B.rp_size; h.rp_head = e->rp_head; h.rp_filled = e->rp_filled ? 1 : 0; h.cmd_sampler = e->K.cmd_sampler;
+  h.plane_flat = e->flat ? 1 : 0;
   std::memcpy(host_blob, &h, sizeof h);
   HIP_TRY(hipMemcpyAsync((char*)host_blob + sizeof h, e->ws, e->L.total, hipMemcpyDeviceToHost, (hipStream_t)stream));
   HIP_TRY(hipStreamSynchronize((hipStream_t)stream));
@@ -1649,6 +1693,7 @@ int ois_load_state(ois_env* e, const void* host_blob, size_t bytes, void* stream
   e->K.seed_hi = (uint32_t)(h.seed >> 32);
   e->steps_done = h.steps_done;
   e->rp_head = h.rp_head; e->rp_filled = h.rp_filled != 0;
+  e->flat = e->flat_allowed && h.plane_flat != 0;  // the params rows came with the blob
   return OIS_OK;
 }
 

@@ -53,8 +53,12 @@ OIS_DEV f2 newton_rcp2(f2 m, f2 k) {
   return fma2(m, e, m);
 }
 
-template <bool EXACT, bool TER = false, int NIT = 0>
+// FLAT: the ground is the default plane n = (0, 0, 1) for every arena (no ois_randomize_params slopes, no terrain —
+// the host knows): n_b is the third row of R and n.p is p_z; the 12 instructions that multiply by the zero components of n
+// are not issued (SPEC 3.2: the same IEEE values, a zero may carry the other sign).
+template <bool EXACT, bool TER = false, int NIT = 0, bool FLAT = false>
 OIS_DEV void substep_pk(const DevConsts& K, const DevTerrain& T, PhysT<1>& S) {
+  static_assert(!(FLAT && TER), "the height field has its own plane");
 #define OIS_PR _Pragma("unroll") for (int j = 0; j < 2; ++j)
   float R[9];
   rotmat(S.q, R);
@@ -67,7 +71,8 @@ OIS_DEV void substep_pk(const DevConsts& K, const DevTerrain& T, PhysT<1>& S) {
     terrain_plane(K, S, n, off);
   }
   rotT(R, S.v, vb);
-  rotT(R, n, nb);
+  if constexpr (FLAT) { nb[0] = R[6]; nb[1] = R[7]; nb[2] = R[8]; }
+  else rotT(R, n, nb);
   vb[0] = __builtin_fmaf(-K.gdt, R[6], vb[0]);
   vb[1] = __builtin_fmaf(-K.gdt, R[7], vb[1]);
   vb[2] = __builtin_fmaf(-K.gdt, R[8], vb[2]);
@@ -99,7 +104,7 @@ OIS_DEV void substep_pk(const DevConsts& K, const DevTerrain& T, PhysT<1>& S) {
   const float t2x = nb[1] * t1z;
   const float t2y = __builtin_fmaf(nb[2], t1x, -(nb[0] * t1z));
   const float t2z = -(nb[1] * t1x);
-  const float np = __builtin_fmaf(n[2], S.p[2], __builtin_fmaf(n[1], S.p[1], n[0] * S.p[0]));
+  const float np = FLAT ? S.p[2] : __builtin_fmaf(n[2], S.p[2], __builtin_fmaf(n[1], S.p[1], n[0] * S.p[0]));
   const float cz = K.cz;
   const f2 cy = {K.wy, -K.wy};  // (left, right) wheel of each axle (urdf:112-142: left = +y)
   const f2 ry = cy;
@@ -238,14 +243,15 @@ OIS_DEV void substep_pk(const DevConsts& K, const DevTerrain& T, PhysT<1>& S) {
 // stream is shorter (one packed pair instead of two) and the machine still holds one wave per SIMD.
 OIS_DEV float sum_side(f2 c) { return side_sum<2>(c.x + c.y); }
 
-template <bool EXACT, int NIT = 0>
+template <bool EXACT, int NIT = 0, bool FLAT = false>
 OIS_DEV void substep_pk2(const DevConsts& K, int wheel0, PhysT<2>& S) {
   float R[9];
   rotmat(S.q, R);
   float vb[3], nb[3], wb[3] = {S.wb[0], S.wb[1], S.wb[2]};
   const float n[3] = {S.n[0], S.n[1], S.n[2]};
   rotT(R, S.v, vb);
-  rotT(R, n, nb);
+  if constexpr (FLAT) { nb[0] = R[6]; nb[1] = R[7]; nb[2] = R[8]; }
+  else rotT(R, n, nb);
   vb[0] = __builtin_fmaf(-K.gdt, R[6], vb[0]);
   vb[1] = __builtin_fmaf(-K.gdt, R[7], vb[1]);
   vb[2] = __builtin_fmaf(-K.gdt, R[8], vb[2]);
@@ -268,7 +274,7 @@ OIS_DEV void substep_pk2(const DevConsts& K, int wheel0, PhysT<2>& S) {
   const float t2x = nb[1] * t1z;
   const float t2y = __builtin_fmaf(nb[2], t1x, -(nb[0] * t1z));
   const float t2z = -(nb[1] * t1x);
-  const float np = __builtin_fmaf(n[2], S.p[2], __builtin_fmaf(n[1], S.p[1], n[0] * S.p[0]));
+  const float np = FLAT ? S.p[2] : __builtin_fmaf(n[2], S.p[2], __builtin_fmaf(n[1], S.p[1], n[0] * S.p[0]));
   const float cz = K.cz;
   const f2 cx = {K.wx, -K.wx};                    // (front, rear) wheel of the side
   const float cy = (wheel0 & 2) ? -K.wy : K.wy;   // left side = +y (urdf:112-142)

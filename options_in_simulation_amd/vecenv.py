@@ -147,6 +147,13 @@ class NativeEnv:
         self.policy_steps += int(k)
         self.epoch += 1
 
+    def kernel_info(self) -> str:
+        """the step-kernel instantiation this environment launches right now (ois_kernel_info)"""
+        import ctypes as C
+        buf = C.create_string_buffer(256)
+        _native.check(self.L.ois_kernel_info(self.h, buf, 256))
+        return buf.value.decode()
+
     def profile_begin(self):
         """start kernel-only timing of the step launches (include/ois.h ois_profile_begin)"""
         _native.check(self.L.ois_profile_begin(self.h))

@@ -841,6 +841,11 @@ int orc_create(const ois_config* cfg, orc_env** out) {
   if (cfg->action_dim != 4 && cfg->action_dim != 2 && cfg->action_dim != 1) return fail(OIS_EINVAL, "action_dim must be 4, 2 or 1");
   if (cfg->solver_iterations < 1 || cfg->solver_iterations > 16) return fail(OIS_EINVAL, "solver_iterations out of range");
   if (!(cfg->baumgarte > 0.0f && cfg->baumgarte < 1.0f)) return fail(OIS_EINVAL, "baumgarte must be in (0, 1)");
+  if (!(cfg->wheel_damping >= 0.0f) || !(cfg->wheel_limit_damping >= 0.0f) || !(cfg->wheel_limit_velocity >= 0.0f))
+    return fail(OIS_EINVAL, "wheel joint resistance constants must be >= 0");
+  if (!((cfg->wheel_damping + cfg->wheel_limit_damping) * cfg->sim_dt / cfg->wheel_spin_inertia < 2.0f))
+    return fail(OIS_EINVAL, "(wheel_damping + wheel_limit_damping) * sim_dt / wheel_spin_inertia must be < 2 (explicit integration)");
+  if (!(cfg->max_depenetration_velocity >= 0.0f)) return fail(OIS_EINVAL, "max_depenetration_velocity must be >= 0");
   orc_env* e = (orc_env*)zalloc(sizeof *e);
   if (!e) return fail(OIS_ENOMEM, "host alloc");
   e->cfg = *cfg;
@@ -1295,7 +1300,7 @@ static float step_arena(orc_env* e, int i, const float* act /*[A]*/, uint8_t* rs
   for (int k = 0; k < 6; ++k) ob[k] = clipf(o[k], -c->clip_obs, c->clip_obs); /* rl_task.py:99 clamp in the VecEnv */
   /* KAMMA_g1d_g21.py:838-842: get_observations replaces a (nearly) zero rew_buf[0] by 1e-12 before it is
    * returned (division guard of the env-0 percentages); the episode sums were added in calculate_metrics */
-  if (c->env0_reward_guard && i == 0 && fabs((double)mo.rew) < 1e-12) mo.rew = 1e-12f;
+  if (c->env0_reward_guard && gid == 0 && fabs((double)mo.rew) < 1e-12) mo.rew = 1e-12f;
   if (e->rp_size > 0) {
     /* FIFOMemory row (train_kaddpg_4d_nofifo_random_RLIL.py:147-156): states = the previous
      * observation, actions = executed torques / action_scale (base_KA_DDPG.py:212) */

@@ -57,11 +57,20 @@ def test_workspace_size_and_config_validation(lib):
     state = 15 * 65536 * 16 + 65536 * (24 + 4 + 1 + 1)
     assert state <= nbytes < state + 4 * 1024 * 1024
     for field, bad in (("num_envs", 0), ("action_dim", 3), ("solver_iterations", 0), ("sim_dt", 0.0),
-                       ("body_mass", -1.0), ("struct_bytes", 12), ("cmd_sampler", 9)):
+                       ("body_mass", -1.0), ("struct_bytes", 12), ("cmd_sampler", 9),
+                       # the explicit joint-resistance step diverges at (c1 + c2) dt / Is >= 2; a negative depenetration
+                       # velocity would push separating contacts (SPEC 3.3, 3.4)
+                       ("wheel_limit_damping", 2.0), ("wheel_damping", 2.5), ("max_depenetration_velocity", -1.0)):
         c = build_config(variant="KAMMA_medium", num_envs=8)
         setattr(c, field, bad)
         assert lib.ois_workspace_bytes(C.byref(c)) == 0, field
         assert lib.ois_last_error().decode() != ""
+        if field in ("wheel_limit_damping", "wheel_damping", "max_depenetration_velocity"):   # the oracle refuses the same
+            from oracle.binding import lib as orc
+            h = C.c_void_p()
+            assert orc().orc_create(C.byref(c), C.byref(h)) != 0, field
+    c = build_config(variant="KAMMA_medium", num_envs=8, wheel_limit_damping=1.9, max_depenetration_velocity=0.0)
+    assert lib.ois_workspace_bytes(C.byref(c)) > 0
 
 
 def test_null_and_order_errors_without_touching_a_gpu(lib):

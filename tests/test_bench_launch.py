@@ -51,6 +51,28 @@ def test_bare_bench_gpus_2_starts_two_ranks_and_prints_one_line():
     assert [(r["arena_offset"], r["arenas"]) for r in table] == [(0, 1000), (1000, 1000)]
 
 
+def test_bare_bench_gpus_8_starts_eight_ranks_with_a_timed_rank_table():
+    """the driver's 8-GPU launch shape on this container's 8 cores (gloo, no GPU): one line, ranks: 8, eight rows with each
+    rank's own elapsed time and kernel time through the one all-gather, and the per-GPU rates / slowest rank that let a SCALE
+    line be read without a second run"""
+    res = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "8", "--steps", "3", "--warmup", "1",
+                          "--arenas", "65536"], env=_clean_env(OIS_BENCH_DRYRUN="1", OMP_NUM_THREADS="1"), capture_output=True, text=True,
+                         timeout=600)
+    assert res.returncode == 0, res.stderr[-2000:]
+    lines = [l for l in res.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 8 and d["config"]["ranks"] == 8
+    table = d["config"]["rank_table"]
+    assert [r["rank"] for r in table] == list(range(8))
+    assert [(r["arena_offset"], r["arenas"]) for r in table] == [(i * 65536, 65536) for i in range(8)]   # BASELINE configs[4]: 524 288
+    assert all(r["elapsed_s"] > 0 and "kernel_ms" in r for r in table)
+    sd = d["scaling_detail"]
+    assert len(sd["per_gpu_env_steps_per_s"]) == 8 and sd["slowest_rank"] == 7   # the dry run sleeps 10 ms x (rank + 1)
+    assert sd["slowest_elapsed_s"] >= sd["fastest_elapsed_s"] > 0
+    assert d["effective_warmup"] == d["warmup"] + 40
+
+
 def test_world_size_mismatch_is_an_error_not_a_silent_run():
     res = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2"],
                          env=_clean_env(RANK="0", LOCAL_RANK="0", WORLD_SIZE="1", OIS_BENCH_DRYRUN="1"),

@@ -10,7 +10,14 @@ mkdir -p $OUT
 export TMPDIR=/tmp
 P=/tmp/ois_prof_$$
 rm -rf $P && mkdir -p $P
-# the traffic counters first: bench.py quotes `traffic` from profiles/${R}_pmc_traffic.json when its source hash is this checkout's
+HASH=$(python3 -c "import bench; print(bench.kernel_source_hash())")
+echo "kernel sources sha256 $HASH" > $OUT/${R}_kernel_src_sha256.txt
+# the issue counters of single launches in the actor loop: bench.py quotes `roofline.valu_issue` from profiles/${R}_pmc_sq.json
+bash tools/profile_sq.sh $R > $OUT/${R}_sq.log 2>&1 || { tail -5 $OUT/${R}_sq.log; exit 1; }
+cp $OUT/${R}_pmc_sq.json profiles/${R}_pmc_sq.json
+bash tools/profile_sq.sh $R fused >> $OUT/${R}_sq.log 2>&1 || { tail -5 $OUT/${R}_sq.log; exit 1; }
+echo "sq counters done"
+# the traffic counters: bench.py quotes `traffic` from profiles/${R}_pmc_traffic.json when its source hash is this checkout's
 for C in FETCH_SIZE WRITE_SIZE; do
   (cd /tmp && rocprofv3 --pmc $C --kernel-trace --output-format csv -d $P/$C -- python3 $OLDPWD/bench.py --steps 60 --warmup 10 --no-actor --no-cpu-baseline --no-extras > /dev/null 2> $P/$C.err) || { tail -5 $P/$C.err; exit 1; }
   cp $(find $P/$C -name '*counter_collection.csv' | head -1) $P/$C.csv
@@ -40,7 +47,7 @@ out = {"FETCH_SIZE_KB_per_launch_mean": fm, "FETCH_SIZE_launches": len(f), "WRIT
        "hbm_bytes_per_launch": (2.0 * fm + wm) * 1024.0, "arenas": 65536,
        "bytes_per_arena_step": (2.0 * fm + wm) * 1024.0 / 65536, "ratio_to_algorithmic_352": (2.0 * fm + wm) * 1024.0 / 65536 / 352.0,
        "kernel_src_sha256": bench.kernel_source_hash(), "git_head": head,
-       "kernel": "step_kernel<1,true,4> (one arena per lane, packed fp32 over wheel pairs, 1 policy step per launch)",
+       "kernel": "step_kernel<1,1,4,1> (one arena per lane, packed fp32 over wheel pairs, flat plane, 1 policy step per launch)",
        "command": "rocprofv3 --pmc FETCH_SIZE|WRITE_SIZE --kernel-trace --output-format csv -- python3 bench.py --steps 60 "
                   "--warmup 10 --no-actor --no-cpu-baseline (two separate passes; FETCH_SIZE x2 = the guide's gfx950 correction)"}
 json.dump(out, open(f"{OUT}/{R}_pmc_traffic.json", "w"), indent=1)
@@ -57,3 +64,13 @@ grep step_kernel $OUT/${R}_bench_kernel_stats.csv | cut -c1-200
 # the multi-process path on this 1-GPU box: two gloo ranks sharing the card, launched by bench.py itself
 OIS_DIST_BACKEND=gloo python bench.py --gpus 2 --steps 120 --warmup 10 > $OUT/${R}_bench_gloo2.json 2>> $OUT/${R}_bench.err
 tail -c 400 $OUT/${R}_bench_gloo2.json
+# side measurements of the round (each file starts with the kernel-source hash it was taken on)
+(echo "# kernel sources sha256 $HASH"; python tools/launch_overhead_probe.py 4096 16384 65536) > $OUT/${R}_launch_overhead.txt 2>&1
+(echo "# kernel sources sha256 $HASH"; python tools/inloop_probe.py) > $OUT/${R}_inloop_probe.txt 2>&1
+(echo "# kernel sources sha256 $HASH"; python tools/overlap_probe.py) > $OUT/${R}_overlap.txt 2>&1
+python bench.py --shards 2 --no-cpu-baseline > $OUT/${R}_bench_shards2.json 2>> $OUT/${R}_bench.err
+python bench.py --fused 20 --steps 60 --warmup 5 --no-cpu-baseline > $OUT/${R}_bench_fused20.json 2>> $OUT/${R}_bench.err
+python bench.py --domain-rand --no-cpu-baseline > $OUT/${R}_bench_config4_domain_rand.json 2>> $OUT/${R}_bench.err
+python bench.py --terrain --no-cpu-baseline > $OUT/${R}_bench_config4_terrain.json 2>> $OUT/${R}_bench.err
+python bench.py --steps 20 --warmup 5 > $OUT/${R}_bench_driver_shape.json 2>> $OUT/${R}_bench.err
+echo "side measurements done"
