@@ -141,6 +141,9 @@ OIS_DEV void step_body(const DevConsts& K, const DevBuffers& B, const float* __r
   load_arena<LPA>(K, B, la, h, S);
   // bit 8 of `policy`: this launch continues a rollout that is split into launches (OIS_CMD_LEVEL)
   const bool rsum_continue = (policy & 0x100) != 0;
+  // bit 9: the per-level command re-draw that follows the PREVIOUS step of this rollout (level_command_kernel's work,
+  // KAMMA.py:719-725) is done here, in the prologue of the next step's launch, instead of by a launch of its own
+  const bool fold_level = (policy & 0x200) != 0;
   policy &= 0xff;
   float rsum = (rsum_continue && reward_sum != nullptr) ? reward_sum[la] : 0.0f;
   bool cmd_dirty = false;
@@ -156,6 +159,18 @@ OIS_DEV void step_body(const DevConsts& K, const DevBuffers& B, const float* __r
     const int4 ti = B.terrain_idx[la];
     tor[0] = eo.x; tor[1] = eo.y; tor[2] = eo.z;
     tlevel = ti.x; ttype = ti.y;
+  }
+  if (fold_level) {
+    const int sim = S.sim_steps;  // == episode_step_counter of the step just done
+    float fr = B.cmd_fraction[la];
+    if (B.reset_stamp[sim & 1] == sim) {  // some arena reset in that step: `fraction` of every arena is re-snapshot (:498)
+      fr = S.sa[0] / K.cmd_thr_high;
+      if (valid && h == 0) B.cmd_fraction[la] = fr;
+    }
+    float u[4];
+    draw4(K, gid, (uint32_t)sim, PURPOSE_CMD, u);
+    level_command(TER ? tlevel : 0, fr, sim, normal_det(u[0], u[1]), K.cmd_dt, K.cmd_episode_s, S.cmd[0], S.cmd[2]);
+    cmd_dirty = true;
   }
   // FIFO transition memory: "states" of the first appended row = the observation the caller saw
   float o_prev[6] = {0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f};
@@ -1354,17 +1369,19 @@ static int launch_steps(ois_env* e, int k, int policy, const float* actions, flo
   if (!level && !(e->K.eval_sums && k > 1)) return launch_kernel(e, k, policy, actions, reward_sum, stream);
   // per-level command curriculum: the commands of all arenas are re-drawn between two policy steps
   // from a quantity that depends on every arena of the step before (level_command_kernel), so a
-  // rollout is k launches of one step, each followed by the command launch. The eval variants' Smoothness
+  // rollout is k launches of one step. The eval variants' Smoothness
   // sum has the same kind of dependence (old_torques of all arenas zeroed by any reset, KAMMA_eval.py:470):
   // k launches of one step
+  // The command launch is only needed for what the caller can see: inside a rollout the NEXT step's launch does that work
+  // in its prologue (bit 9, step_body), so a rollout of k steps is k + 1 launches instead of 2 k.
   for (int s = 0; s < k; ++s) {
     const float* a = (policy == OIS_POLICY_EXTERNAL) ? actions + (size_t)s * e->N * e->K.action_dim : actions;
-    int rc = launch_kernel(e, 1, policy | (s > 0 ? 0x100 : 0), a, reward_sum, stream);
+    int rc = launch_kernel(e, 1, policy | (s > 0 ? 0x100 : 0) | ((level && s > 0) ? 0x200 : 0), a, reward_sum, stream);
     if (rc != OIS_OK) return rc;
-    if (level) {
-      hipLaunchKernelGGL(level_command_kernel, dim3((e->N + 255) / 256), dim3(256), 0, (hipStream_t)stream, e->K, e->B, e->N);
-      HIP_TRY(hipGetLastError());
-    }
+  }
+  if (level) {
+    hipLaunchKernelGGL(level_command_kernel, dim3((e->N + 255) / 256), dim3(256), 0, (hipStream_t)stream, e->K, e->B, e->N);
+    HIP_TRY(hipGetLastError());
   }
   return OIS_OK;
 }

@@ -2,6 +2,7 @@
 import ctypes as C
 import os
 import re
+import sys
 import subprocess
 
 import numpy as np
@@ -191,3 +192,24 @@ def test_new_entry_points_reject_bad_arguments_without_a_gpu(lib):
     assert lib.ois_gae(0, 4, 4, None, one, one, one, 0.99, 0.95, 0, one, one, None, 0, None) == _abi.EINVAL  # null tensor
     assert lib.ois_gae(0, 4, 4, one, one, one, one, 0.99, 0.95, 1, one, one, None, 0, None) == _abi.ENOMEM  # normalize without scratch
     assert b"scratch" in lib.ois_last_error()
+
+
+def test_algorithmic_flop_count_is_the_one_bench_quotes():
+    """docs/SPEC.md 3.11 = tools/spec_flops.py = bench.py's flop_algorithmic_per_env_step: a figure counted from the
+    model, not from any kernel's instructions (VERDICT r2 #6)"""
+    import re
+    import bench
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import spec_flops
+    assert spec_flops.flop_per_substep() == 1653 and spec_flops.flop_per_env_step() == 20 * 1653 + 171
+    assert bench.algorithmic_flop_per_env_step() == float(spec_flops.flop_per_env_step())
+    spec = open(os.path.join(ROOT, "docs", "SPEC.md")).read()
+    assert f"**{spec_flops.flop_per_substep()}**" in spec and f"**{spec_flops.flop_per_env_step()}**" in spec
+    rows = re.findall(r"^\| 3\.\d \|.*\| (\d+) \| (\d+) \| (\d+) \|$", spec, flags=re.M)
+    assert len(rows) == len(spec_flops.SUBSTEP) and all(int(a) * int(b) == int(c) for a, b, c in rows)
+    # the executed figure is keyed on the launched instantiation and quoted only on this checkout's kernel sources
+    flop, valu, prov = bench.executed_flop_per_env_step("step_kernel<1,1,4,1>", 20)
+    if prov["status"].startswith("quoted"):
+        assert valu == 20 * 602 and 0.8 < flop / bench.algorithmic_flop_per_env_step() < 1.0
+    flop2, _, prov2 = bench.executed_flop_per_env_step("step_kernel<9,9,9,9>", 20)
+    assert flop2 == bench.FLOP_PER_ENV_STEP and prov2["status"].startswith("not quoted")

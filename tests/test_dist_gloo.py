@@ -175,3 +175,110 @@ def test_two_product_shards_on_gloo_match_the_unsharded_product_run(tmp_path):
     assert got["count"] == ref["count"] == total and got["step"] == ref["step"] == 198
     for key in ref:
         assert got[key] == pytest.approx(ref[key], rel=1e-5, abs=1e-6, nan_ok=True), key
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# The quantities the reference defines over `num_envs` are per ENVIRONMENT, i.e. per shard: the eval variants'
+# old_torques zeroing (KAMMA_eval.py:470) and the `fraction` snapshot of the level curriculum (KAMMA.py:498). A sharded
+# run of those variants is the run of one reference process per shard — NOT the unsharded run. Pinned here; the env-0
+# reward guard of KAMMA_g1d_g21 goes by GLOBAL arena id and therefore IS shard-invariant.
+def _run_shards(make, variant, total, bounds, steps, seed, falls, **kw):
+    """one environment per [lo, hi) of `bounds`, stepped in lock-step on the same global actions; `falls` = {step: global
+    arena} robots put on their back before that step. Returns the concatenated per-step buffers."""
+    envs = [make(build_config(variant=variant, num_envs=hi - lo, seed=seed, arena_offset=lo, **kw)) for lo, hi in bounds]
+    for e in envs:
+        e.reset(seed)
+    rng = np.random.default_rng(seed)
+    A = envs[0].cfg.action_dim
+    out = []
+    for t in range(steps):
+        a = rng.uniform(-1, 1, (total, A)).astype(np.float32)
+        for e, (lo, hi) in zip(envs, bounds):
+            if t in falls and lo <= falls[t] < hi:
+                e.set_quat(falls[t] - lo, [0.0, 1.0, 0.0, 0.0])
+            e.step(a[lo:hi])
+        out.append({k: np.concatenate([e.get(bid) for e in envs]) for k, bid in
+                    (("sums_c", _abi.BUF_SUMS_C), ("rew", _abi.BUF_REW), ("done", _abi.BUF_DONE), ("commands", _abi.BUF_COMMANDS),
+                     ("fraction", _abi.BUF_CMD_FRACTION), ("pose", _abi.BUF_POSE))})
+    return out
+
+
+class _OrcShard:
+    def __init__(self, cfg):
+        from oracle.binding import OracleEnv
+        self.cfg, self.e = cfg, OracleEnv(cfg)
+
+    def reset(self, seed): self.e.reset(seed)
+    def step(self, a): self.e.step(a)
+    def set_quat(self, i, q): self.e.buffer(_abi.BUF_QUAT)[i] = np.array(q, np.float32)
+    def get(self, bid): return np.array(self.e.buffer(bid), copy=True)
+
+
+class _DevShard:
+    def __init__(self, cfg):
+        from options_in_simulation_amd.vecenv import NativeEnv
+        self.cfg, self.e = cfg, NativeEnv(cfg, "cuda:0")
+
+    def reset(self, seed): self.e.reset(seed)
+    def step(self, a): self.e.step(torch.from_numpy(a).cuda())
+    def set_quat(self, i, q): self.e.buffer(_abi.BUF_QUAT)[i] = torch.tensor(q, device="cuda")
+    def get(self, bid): return self.e.buffer(bid).cpu().numpy()
+
+
+def _check_eval_shard_semantics(make):
+    total, steps, falls = 12, 40, {20: 2}          # arena 2 (shard 0) falls alone at step 20
+    whole = _run_shards(make, "KAMMA_eval", total, [(0, total)], steps, 5, falls)
+    split = _run_shards(make, "KAMMA_eval", total, [(0, 6), (6, total)], steps, 5, falls)
+    for t in range(steps):
+        assert np.array_equal(whole[t]["pose"], split[t]["pose"]) and np.array_equal(whole[t]["done"], split[t]["done"])  # the arenas agree
+        if t <= 20:
+            assert np.array_equal(whole[t]["sums_c"], split[t]["sums_c"]), t
+    assert whole[20]["done"].sum() == 1 and whole[20]["done"][2] == 1
+    # step 21: the reset_idx call of step 20 zeroed old_torques of every arena of ITS environment — all 12 in the
+    # unsharded run, the 6 of shard 0 in the sharded one; shard 1 keeps the previous torques in its Smoothness term
+    d = whole[21]["sums_c"][:, 0] != split[21]["sums_c"][:, 0]
+    assert not d[:6].any() and d[6:].all()
+    return split
+
+
+def test_eval_variant_shards_are_per_environment_on_the_oracle():
+    _check_eval_shard_semantics(_OrcShard)
+
+
+def test_level_curriculum_fraction_is_per_environment_on_the_oracle():
+    total, steps, falls = 8, 30, {12: 1}
+    kw = dict(cmd_sampler=_abi.CMD_LEVEL)
+    whole = _run_shards(_OrcShard, "KAMMA_medium", total, [(0, total)], steps, 9, falls, **kw)
+    split = _run_shards(_OrcShard, "KAMMA_medium", total, [(0, 4), (4, total)], steps, 9, falls, **kw)
+    assert np.array_equal(whole[11]["fraction"], split[11]["fraction"])
+    # the fall in shard 0 re-snapshots `fraction` (KAMMA.py:498) of all 8 arenas in the unsharded run, of shard 0's 4 otherwise
+    d = whole[12]["fraction"] != split[12]["fraction"]
+    assert not d[:4].any() and d[4:].all() and (split[12]["fraction"][4:] == split[11]["fraction"][4:]).all()
+
+
+def test_env0_reward_guard_goes_by_global_arena_id_on_the_oracle():
+    total, steps = 8, 60
+    kw = dict(max_sim_steps=40.0)   # gamma1 reaches 0 quickly... the guard needs rew == 0: gamma2 = 1 and unclipped expert torques
+    whole = _run_shards(_OrcShard, "KAMMA_g1d_g21", total, [(0, total)], steps, 3, {})
+    split = _run_shards(_OrcShard, "KAMMA_g1d_g21", total, [(0, 4), (4, total)], steps, 3, {})
+    guarded = [t for t in range(steps) if whole[t]["rew"][0] == np.float32(1e-12)]
+    assert guarded, "the guard never fired: lengthen the run"
+    for t in range(steps):
+        assert np.array_equal(whole[t]["rew"], split[t]["rew"]), t          # shard-invariant
+        assert not (split[t]["rew"][4] == np.float32(1e-12))                # local arena 0 of shard 1 is global arena 4: not guarded
+    del kw
+
+
+@pytest.mark.gpu
+def test_eval_and_guard_shard_semantics_on_the_hip_path():
+    """the product's shards behave as the oracle's with the same boundaries (bit for bit), incl. the per-environment
+    old_torques zeroing and the global-id reward guard"""
+    dev = _check_eval_shard_semantics(_DevShard)
+    orc = _run_shards(_OrcShard, "KAMMA_eval", 12, [(0, 6), (6, 12)], 40, 5, {20: 2})
+    for t in range(40):
+        for k in ("sums_c", "rew", "done", "commands", "pose"):
+            assert np.array_equal(dev[t][k], orc[t][k]), (t, k)
+    a = _run_shards(_DevShard, "KAMMA_g1d_g21", 8, [(0, 4), (4, 8)], 60, 3, {})
+    b = _run_shards(_OrcShard, "KAMMA_g1d_g21", 8, [(0, 8)], 60, 3, {})
+    for t in range(60):
+        assert np.array_equal(a[t]["rew"], b[t]["rew"]), t
