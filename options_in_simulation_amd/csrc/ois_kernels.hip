@@ -123,7 +123,7 @@ OIS_DEV void store_arena(const DevConsts& K, const DevBuffers& B, int i, int h, 
 }
 
 // ------------------------------------------------------------------ the step kernel ---
-template <int LPA, bool PK, bool TER, int NIT, bool FLAT = false>
+template <int LPA, bool PK, bool TER, int NIT, bool FLAT = false, bool FOLD = false>
 OIS_DEV void step_body(const DevConsts& K, const DevBuffers& B, const float* __restrict__ actions,
                        float* __restrict__ reward_sum, int N, int ksteps, int policy, int rp_head) {
   constexpr int W = 4 / LPA;
@@ -143,7 +143,8 @@ OIS_DEV void step_body(const DevConsts& K, const DevBuffers& B, const float* __r
   const bool rsum_continue = (policy & 0x100) != 0;
   // bit 9: the per-level command re-draw that follows the PREVIOUS step of this rollout (level_command_kernel's work,
   // KAMMA.py:719-725) is done here, in the prologue of the next step's launch, instead of by a launch of its own
-  const bool fold_level = (policy & 0x200) != 0;
+  // (FOLD shells only: carried by every shell, the code cost the default path 0.2 us per launch, profiles/r3_ab_fold.txt)
+  const bool fold_level = FOLD && (policy & 0x200) != 0;
   policy &= 0xff;
   float rsum = (rsum_continue && reward_sum != nullptr) ? reward_sum[la] : 0.0f;
   bool cmd_dirty = false;
@@ -160,7 +161,7 @@ OIS_DEV void step_body(const DevConsts& K, const DevBuffers& B, const float* __r
     tor[0] = eo.x; tor[1] = eo.y; tor[2] = eo.z;
     tlevel = ti.x; ttype = ti.y;
   }
-  if (fold_level) {
+  if constexpr (FOLD) if (fold_level) {
     const int sim = S.sim_steps;  // == episode_step_counter of the step just done
     float fr = B.cmd_fraction[la];
     if (B.reset_stamp[sim & 1] == sim) {  // some arena reset in that step: `fraction` of every arena is re-snapshot (:498)
@@ -468,23 +469,25 @@ OIS_DEV void step_body(const DevConsts& K, const DevBuffers& B, const float* __r
 //  * FLAT (the packed, 4-iteration shells only): every arena stands on the default plane n = (0, 0, 1) — no
 //    ois_randomize_params slopes since ois_create, no terrain: the host's knowledge (ois_env::flat) — so the
 //    substeps take n_b and n.p from R and p directly (-12 instructions per substep, ois_physics_pk.h).
-template <int LPA, bool PK, int NIT, bool FLAT = false>
+//  * FOLD (the packed, 4-iteration shells only): the continuation launches of a rollout under the per-level command
+//    curriculum, whose prologue re-draws the commands that follow the previous step (level_command_kernel's work).
+template <int LPA, bool PK, int NIT, bool FLAT = false, bool FOLD = false>
 __global__ __launch_bounds__(kBlock) void step_kernel(DevConsts K, DevBuffers B, const float* __restrict__ actions,
                                                       float* __restrict__ reward_sum, int N, int ksteps, int policy,
                                                       int rp_head) {
-  step_body<LPA, PK, false, NIT, FLAT>(K, B, actions, reward_sum, N, ksteps, policy, rp_head);
+  step_body<LPA, PK, false, NIT, FLAT, FOLD>(K, B, actions, reward_sum, N, ksteps, policy, rp_head);
 }
-template <bool PK, int NIT, bool FLAT = false>
+template <bool PK, int NIT, bool FLAT = false, bool FOLD = false>
 __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(2, 2)))
 void step_kernel_w2(DevConsts K, DevBuffers B, const float* __restrict__ actions, float* __restrict__ reward_sum, int N,
                     int ksteps, int policy, int rp_head) {
-  step_body<1, PK, false, NIT, FLAT>(K, B, actions, reward_sum, N, ksteps, policy, rp_head);
+  step_body<1, PK, false, NIT, FLAT, FOLD>(K, B, actions, reward_sum, N, ksteps, policy, rp_head);
 }
-template <bool PK, int NIT>
+template <bool PK, int NIT, bool FOLD = false>
 __global__ __launch_bounds__(kBlock) void step_kernel_terrain(DevConsts K, DevBuffers B, const float* __restrict__ actions,
                                                               float* __restrict__ reward_sum, int N, int ksteps, int policy,
                                                               int rp_head) {
-  step_body<1, PK, true, NIT>(K, B, actions, reward_sum, N, ksteps, policy, rp_head);
+  step_body<1, PK, true, NIT, false, FOLD>(K, B, actions, reward_sum, N, ksteps, policy, rp_head);
 }
 
 // ------------------------------------------------------------------ get_heights -------
@@ -1336,7 +1339,12 @@ static int launch_kernel(ois_env* e, int k, int policy, const float* actions, fl
   // (ois_terrain_attach refuses LPA = 2), solver iterations unrolled (the default 4) or run-time
   const bool it4 = e->K.iters == 4;
   const bool flat = e->flat && e->packed && it4 && !e->B.ter.on;  // the FLAT shells exist for the default configuration
-  if (flat) {
+  if ((policy & 0x200) != 0) {  // continuation launch of a level-curriculum rollout (can_fold() said these shells exist)
+    if (e->B.ter.on) OIS_LAUNCH((step_kernel_terrain<true, 4, true>), 1);
+    else if (e->lpa == 2) { if (flat) OIS_LAUNCH((step_kernel<2, true, 4, true, true>), 2); else OIS_LAUNCH((step_kernel<2, true, 4, false, true>), 2); }
+    else if (e->waves2) { if (flat) OIS_LAUNCH((step_kernel_w2<true, 4, true, true>), 1); else OIS_LAUNCH((step_kernel_w2<true, 4, false, true>), 1); }
+    else { if (flat) OIS_LAUNCH((step_kernel<1, true, 4, true, true>), 1); else OIS_LAUNCH((step_kernel<1, true, 4, false, true>), 1); }
+  } else if (flat) {
     if (e->lpa == 2) OIS_LAUNCH((step_kernel<2, true, 4, true>), 2);
     else if (e->waves2) OIS_LAUNCH((step_kernel_w2<true, 4, true>), 1);
     else OIS_LAUNCH((step_kernel<1, true, 4, true>), 1);
@@ -1373,15 +1381,17 @@ static int launch_steps(ois_env* e, int k, int policy, const float* actions, flo
   // sum has the same kind of dependence (old_torques of all arenas zeroed by any reset, KAMMA_eval.py:470):
   // k launches of one step
   // The command launch is only needed for what the caller can see: inside a rollout the NEXT step's launch does that work
-  // in its prologue (bit 9, step_body), so a rollout of k steps is k + 1 launches instead of 2 k.
+  // in its prologue (bit 9, the FOLD shells of step_body), so a rollout of k steps is k + 1 launches instead of 2 k. The FOLD
+  // shells exist for the packed, 4-iteration configuration (the default); any other keeps the launch pairs.
+  const bool fold = level && e->packed && e->K.iters == 4;
   for (int s = 0; s < k; ++s) {
     const float* a = (policy == OIS_POLICY_EXTERNAL) ? actions + (size_t)s * e->N * e->K.action_dim : actions;
-    int rc = launch_kernel(e, 1, policy | (s > 0 ? 0x100 : 0) | ((level && s > 0) ? 0x200 : 0), a, reward_sum, stream);
+    int rc = launch_kernel(e, 1, policy | (s > 0 ? 0x100 : 0) | ((fold && s > 0) ? 0x200 : 0), a, reward_sum, stream);
     if (rc != OIS_OK) return rc;
-  }
-  if (level) {
-    hipLaunchKernelGGL(level_command_kernel, dim3((e->N + 255) / 256), dim3(256), 0, (hipStream_t)stream, e->K, e->B, e->N);
-    HIP_TRY(hipGetLastError());
+    if (level && (!fold || s == k - 1)) {
+      hipLaunchKernelGGL(level_command_kernel, dim3((e->N + 255) / 256), dim3(256), 0, (hipStream_t)stream, e->K, e->B, e->N);
+      HIP_TRY(hipGetLastError());
+    }
   }
   return OIS_OK;
 }

@@ -39,6 +39,17 @@ int main(void) {
   CHECK(ois_create(&cfg, 0, ws, bytes, &env));
   if (ois_step(env, (const float*)ws, stream) != OIS_ESTATE) { fprintf(stderr, "step before reset not refused\n"); return 1; }
   CHECK(ois_reset(env, 5, stream));
+  char info[256];
+  CHECK(ois_kernel_info(env, info, sizeof info)); /* 1000 arenas on the default plane: a lane pair per arena, flat shell */
+  if (strncmp(info, "step_kernel<2,1,4,1>", 20) != 0 || !strstr(info, "plane=flat")) { fprintf(stderr, "kernel info: %s\n", info); return 1; }
+  float slopes[2] = {0.0f, 0.2f};
+  CHECK(ois_randomize_params(env, 0.5f, 1.0f, slopes, 2, stream));
+  CHECK(ois_kernel_info(env, info, sizeof info));
+  if (!strstr(info, "plane=per-arena")) { fprintf(stderr, "slopes did not leave the flat shell: %s\n", info); return 1; }
+  CHECK(ois_randomize_params(env, 0.85f, 0.85f, NULL, 0, stream)); /* friction only: flat again */
+  CHECK(ois_kernel_info(env, info, sizeof info));
+  if (!strstr(info, "plane=flat")) { fprintf(stderr, "friction-only randomisation left the flat shell: %s\n", info); return 1; }
+  if (ois_kernel_info(env, NULL, 0) != OIS_EINVAL) { fprintf(stderr, "null kernel-info buffer not refused\n"); return 1; }
 
   float* h_act = (float*)malloc(sizeof(float) * N * 4);
   for (int i = 0; i < N * 4; ++i) h_act[i] = (float)((i * 37) % 100) / 100.0f;

@@ -519,3 +519,41 @@ def test_trainer_trace_replays_on_the_device(index):
     check_tags()
     assert resets == run["env_reset_calls"] and steps == run["timesteps"]
     env.close()
+
+
+def test_flat_plane_shell_follows_the_params_and_the_state_blob():
+    """ois_kernel_info: the flat-plane shells run exactly while every arena stands on n = (0, 0, 1) — slopes from
+    ois_randomize_params leave them, friction alone does not, a state blob carries the flag — and a flat run equals the same
+    run forced through the general kernels (OIS_FLAT=0 is read at ois_create) value for value."""
+    from options_in_simulation_amd.vecenv import NativeEnv
+    N = 40000
+    cfg = build_config(variant="KAMMA_medium", num_envs=N, seed=3)
+    a = NativeEnv(cfg, "cuda:0")
+    assert a.kernel_info().startswith("step_kernel<1,1,4,1>") and "plane=flat" in a.kernel_info()
+    os.environ["OIS_FLAT"] = "0"
+    try:
+        b = NativeEnv(cfg, "cuda:0")
+    finally:
+        del os.environ["OIS_FLAT"]
+    assert b.kernel_info().startswith("step_kernel<1,1,4,0>") and "plane=per-arena" in b.kernel_info()
+    a.reset(3); b.reset(3)
+    a.rollout(130, _abi.POLICY_RANDOM); b.rollout(130, _abi.POLICY_RANDOM)
+    for bid in (_abi.BUF_POSE, _abi.BUF_QUAT, _abi.BUF_LINVEL, _abi.BUF_ANGVEL, _abi.BUF_WHEEL_VEL, _abi.BUF_SUMS_A, _abi.BUF_SUMS_B,
+                _abi.BUF_OBS, _abi.BUF_REW, _abi.BUF_COUNTERS, _abi.BUF_COMMANDS):
+        assert torch.equal(a.buffer(bid), b.buffer(bid)), bid      # IEEE value equality: -0 == +0 (docs/SPEC.md 3.2)
+    blob = a.save_state()
+    a.randomize_params(0.5, 1.0, [0.0, 0.2])
+    assert "plane=per-arena" in a.kernel_info()
+    sloped = a.save_state()
+    a.randomize_params(0.5, 1.0)
+    assert "plane=flat" in a.kernel_info()                          # friction only
+    a.load_state(sloped)
+    assert "plane=per-arena" in a.kernel_info()                     # the blob's params rows hold slopes
+    a.load_state(blob)
+    assert "plane=flat" in a.kernel_info()
+    small = NativeEnv(build_config(variant="KAMMA_medium", num_envs=64, seed=3), "cuda:0")
+    assert small.kernel_info().startswith("step_kernel<2,1,4,1>")   # a lane pair per arena up to 32 768 arenas
+    big = NativeEnv(build_config(variant="KAMMA_medium", num_envs=140000, seed=3), "cuda:0")
+    assert big.kernel_info().startswith("step_kernel_w2<1,4,1>")    # two waves per SIMD above 65 536
+    for e in (a, b, small, big):
+        e.close()

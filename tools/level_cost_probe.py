@@ -16,5 +16,14 @@ for name, kw in (("RAND sampler", {}), ("LEVEL sampler", {"cmd_sampler": _abi.CM
     for _ in range(300):
         env.step(a)
     torch.cuda.synchronize()
-    print(f"{name}: {(time.perf_counter() - t0) / 300 * 1e6:.2f} us per policy step (wall, back to back)")
+    print(f"{name}: {(time.perf_counter() - t0) / 300 * 1e6:.2f} us per policy step (wall, back to back ois_step)", flush=True)
+    # 20-step rollouts: under the level sampler k single-step launches + ONE command launch (the continuation launches
+    # re-draw the commands of the step before them in their prologue)
+    for _ in range(3):
+        env.rollout(20, _abi.POLICY_RANDOM)
+    torch.cuda.synchronize(); t0 = time.perf_counter()
+    for _ in range(30):
+        env.rollout(20, _abi.POLICY_RANDOM)
+    torch.cuda.synchronize()
+    print(f"{name}: {(time.perf_counter() - t0) / 600 * 1e6:.2f} us per policy step in 20-step rollouts", flush=True)
     env.close()
