@@ -68,6 +68,7 @@ tail -c 400 $OUT/${R}_bench_gloo2.json
 (echo "# kernel sources sha256 $HASH"; python tools/launch_overhead_probe.py 4096 16384 65536) > $OUT/${R}_launch_overhead.txt 2>&1
 (echo "# kernel sources sha256 $HASH"; python tools/inloop_probe.py) > $OUT/${R}_inloop_probe.txt 2>&1
 (echo "# kernel sources sha256 $HASH"; python tools/overlap_probe.py) > $OUT/${R}_overlap.txt 2>&1
+(echo "# kernel sources sha256 $HASH"; python tools/level_cost_probe.py) > $OUT/${R}_level_cost.txt 2>&1
 python bench.py --shards 2 --no-cpu-baseline > $OUT/${R}_bench_shards2.json 2>> $OUT/${R}_bench.err
 python bench.py --fused 20 --steps 60 --warmup 5 --no-cpu-baseline > $OUT/${R}_bench_fused20.json 2>> $OUT/${R}_bench.err
 python bench.py --domain-rand --no-cpu-baseline > $OUT/${R}_bench_config4_domain_rand.json 2>> $OUT/${R}_bench.err
