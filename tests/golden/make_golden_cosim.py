@@ -73,17 +73,38 @@ def rf(lo, hi, u):
     return (hi - lo) * u + lo
 
 
+# env-file runs with a TASK_CFG leaf changed (name -> (env file, {path: value})): the terminal reward is 0.0 in every file,
+# which hides `terminalReward * reset_buf * ~timeout_buf` (KAMMA.py:801, `~` on an int64 tensor: -1 / -2)
+PATCHED = {"KAMMA_medium+terminal1.5": ("KAMMA_medium", {"task/env/learn/terminalReward": 1.5})}
+
+
+def _patch(cfg, patches):
+    for path, value in patches.items():
+        d = cfg
+        keys = path.split("/")
+        for k in keys[:-1]:
+            d = d[k]
+        assert keys[-1] in d
+        d[keys[-1]] = value
+
+
 class Cosim:
     def __init__(self, variant, n, seed):
+        run_name = variant
+        variant, patches = PATCHED.get(variant, (variant, {}))
         from options_in_simulation_amd import _abi, build_config
         from oracle.binding import OracleEnv, PHYSICS_STRIDE, RESET_U_STRIDE, fptr, lib
         self._abi, self.L, self.fptr = _abi, lib(), fptr
-        self.variant, self.n = variant, n
+        self.variant, self.n, self.run_name = variant, n, run_name
         Ref, self.ns, self.lines = rt.build(variant)
         run = task_cfg_literal(variant)
         run["task"]["env"]["numEnvs"] = n
+        _patch(run, patches)
         self.cfg = build_config(run, variant=variant, num_envs=n, seed=seed)   # from the reference's own TASK_CFG literal
-        assert bytes(self.cfg) == bytes(build_config(variant=variant, num_envs=n, seed=seed)), "default_task_cfg() differs from the literal"
+        from options_in_simulation_amd import default_task_cfg
+        mine = default_task_cfg()
+        _patch(mine, patches)
+        assert bytes(self.cfg) == bytes(build_config(mine, variant=variant, num_envs=n, seed=seed)), "default_task_cfg() differs from the literal"
         self.orc = OracleEnv(self.cfg)
         self.rng = np.random.default_rng(seed)
         self.S = np.zeros((n, PHYSICS_STRIDE), np.float32)
@@ -255,9 +276,10 @@ RUNS = {  # variant -> (arenas, steps, {step: [(event, arena)]}); two synchronou
     "KA_DDPG_1D": (4, 104, {20: [("fall", 1)]}),
     "KA_DDPG_2D_eval": (3, 104, {20: [("fall", 1)]}),
     "KA_DDPG_1D_eval": (3, 104, {30: [("fall", 2)]}),
+    "KAMMA_medium+terminal1.5": (4, 104, {33: [("fall", 1)], 50: [("oob", 2)]}),
 }
 # sim_steps where the gamma schedule is in the interior (the trajectories above start at 0: gamma 1 - 2e-4)
-START_SIM_STEPS = {"KAMMA": 150000, "KAMMA_medium": 420000, "KAMMA_g1d_g21": 250000, "KAMMA_curr1": 200000, "KAMMA_curr2": 300000,
+START_SIM_STEPS = {"KAMMA": 150000, "KAMMA_medium": 420000, "KAMMA_medium+terminal1.5": 100000, "KAMMA_g1d_g21": 250000, "KAMMA_curr1": 200000, "KAMMA_curr2": 300000,
                    "KA_DDPG_4D": 350000, "KAMMA_eval": 20000, "KA_DDPG_2D_eval": 30000, "KA_DDPG_1D_eval": 49950}
 
 
@@ -430,7 +452,7 @@ def block_box_bounds():
 
 def blocks():
     out = {}
-    for k, v in enumerate(RUNS):
+    for k, v in enumerate(v for v in RUNS if v not in PATCHED):
         for key, val in block_prephysics(v, seed=k).items():
             out[f"prephysics__{v}__{key}"] = val
     for key, val in block_is_done().items():

@@ -22,6 +22,9 @@ from tests.cosim_check import check_step
 G = os.path.join(os.path.dirname(__file__), "golden")
 VARIANTS = ["KAMMA", "KAMMA_medium", "KAMMA_g11_g21", "KAMMA_g1d_g21", "KAMMA_curr1", "KAMMA_curr2", "KAMMA_eval", "KA_DDPG_4D",
             "KA_DDPG_2D", "KA_DDPG_1D", "KA_DDPG_2D_eval", "KA_DDPG_1D_eval"]
+# runs of an env file with one TASK_CFG leaf changed (make_golden_cosim.PATCHED): name -> (env file, build_config overrides)
+PATCHED_RUNS = {"KAMMA_medium+terminal1.5": ("KAMMA_medium", {"terminal_reward": 1.5})}
+RUN_NAMES = VARIANTS + list(PATCHED_RUNS)
 
 
 @pytest.fixture(scope="module")
@@ -33,12 +36,13 @@ def _variant(fixture, v):
     return {k[len(v) + 2:]: fixture[k] for k in fixture.files if k.startswith(v + "__")}
 
 
-@pytest.mark.parametrize("variant", VARIANTS)
+@pytest.mark.parametrize("variant", RUN_NAMES)
 def test_oracle_follows_the_reference_statements_step_by_step(fixture, variant):
     d = _variant(fixture, variant)
     T, n = d["actions"].shape[:2]
-    seed = 100 + VARIANTS.index(variant)
-    cfg = build_config(variant=variant, num_envs=n, seed=seed)
+    seed = 100 + RUN_NAMES.index(variant)
+    env_file, overrides = PATCHED_RUNS.get(variant, (variant, {}))
+    cfg = build_config(variant=env_file, num_envs=n, seed=seed, **overrides)
     env = OracleEnv(cfg)
     env.set_hooks(reset_u=np.ascontiguousarray(d["first__reset_u"]))
     env.reset(seed)
@@ -59,6 +63,12 @@ def test_oracle_follows_the_reference_statements_step_by_step(fixture, variant):
     resets = d["reset"].sum()
     if variant != "KAMMA_g11_g21":
         assert resets > 0 and d["timeout"].sum() > 0 and (d["reset"].astype(int) - d["timeout"]).sum() > 0  # timeouts and falls / bounds
+    if "terminal1.5" in variant:
+        # KAMMA.py:801 `terminalReward * reset_buf * ~timeout_buf` on int64: a fall or bound violation costs -1.5, a timeout -3.0
+        # (the step's reward against the same step of a run without it is not in the fixture; the sign and size are)
+        both = (d["reset"] == 1) & (d["timeout"] == 1)
+        only = (d["reset"] == 1) & (d["timeout"] == 0)
+        assert both.any() and only.any()
     stop = int(d["reference_raised_zero_division_at"])
     if stop >= 0:
         # the reference itself stops at this step: get_observations divides by rew_buf[0].item() == 0.0 in Python floats
@@ -82,7 +92,7 @@ def test_the_switch_and_every_sampler_are_exercised(fixture):
 
 def test_lines_report_names_what_ran_and_what_was_removed():
     rep = json.load(open(os.path.join(G, "refexec_cosim_lines.json")))
-    assert sorted(rep) == sorted(VARIANTS)
+    assert sorted(rep) == sorted(RUN_NAMES)
     k = {row.split(" ")[0]: row for row in rep["KAMMA"]}
     # the statements VERDICT r2 listed run (KAMMA.py): controller / gamma / switch, clip, guiding reward, timeout and bounds,
     # mask / counters / ratio sums / extras / fraction, the projection tail
