@@ -58,6 +58,44 @@ def torch_rand_float_from(lower, upper, u):
     return (upper - lower) * u + lower
 
 
+def prephysics_formulas(commands, v_forward_projected, omega_z, actions4, sim_steps, rand_vals, *, Kp, Kp_omega, vehicle_mass,
+                        vehicle_inertia, dt, action_scale, max_sim_steps):
+    """the transcription of pre_physics_step's arithmetic on given inputs (torch float32 tensors; actions4 already [N, 4]):
+    KAMMA.py:604-636, :649, :656 and KA_DDPG_4D.py:627-631, :637. make_golden_cosim.py asserts that it equals what the
+    reference's own statements compute on the same inputs."""
+    out = {}
+    # ---- KAMMA.py:604-624 criteria controller ----
+    desired_v = commands[:, 0]
+    desired_omega = commands[:, 2]
+    current_v = v_forward_projected
+    current_omega = omega_z
+    v_delta = desired_v - current_v
+    omega_delta = desired_omega - current_omega
+    ac_left = Kp * (vehicle_mass * (v_delta / dt)) - Kp_omega * (vehicle_inertia * (omega_delta / dt))
+    ac_right = Kp * (vehicle_mass * (v_delta / dt)) + Kp_omega * (vehicle_inertia * (omega_delta / dt))
+    criteria_action = torch.stack([ac_left, ac_left, ac_right, ac_right], dim=1)
+    out.update(v_delta=v_delta, omega_delta=omega_delta, ac_left=ac_left, ac_right=ac_right)
+
+    # ---- KAMMA.py:627-628 gamma schedule ----
+    gamma_assist = torch.clamp(1.0 - (sim_steps.float() / max_sim_steps), min=0.0)
+    out.update(gamma=gamma_assist)
+
+    # ---- KAMMA.py:632-636 stochastic switch, :649 clip, :656 guiding reward ----
+    gamma = gamma_assist.view(-1, 1)
+    mask = (rand_vals.view(-1, 1) < gamma).float()
+    execution_action = mask * criteria_action + (1 - mask) * (actions4 * action_scale)
+    wheel_torqs = torch.clip(execution_action, -4.0, 4.0)
+    guiding_reward = -torch.norm(wheel_torqs - criteria_action, dim=1)
+    out.update(switch_torques=execution_action, switch_wheel_torqs=wheel_torqs, switch_guiding=guiding_reward)
+
+    # ---- KA_DDPG_4D.py:627-631 deterministic blend, :637 guiding on the unclipped policy torque ----
+    blend = (torch.tensor(1.0) - gamma) * actions4 * action_scale + gamma * criteria_action
+    blend_wheel = torch.clip(blend, -4.0, 4.0)
+    blend_guiding = -torch.norm(actions4 * action_scale - criteria_action, dim=1)
+    out.update(blend_torques=blend, blend_wheel_torqs=blend_wheel, blend_guiding=blend_guiding)
+    return out
+
+
 # ----------------------------------------------------------------------------------------
 def refmath_step(seed=0, n=257):
     g = torch.Generator().manual_seed(seed)
@@ -75,35 +113,13 @@ def refmath_step(seed=0, n=257):
     out.update(commands=commands, v_forward_projected=v_forward_projected, base_velocities=base_velocities,
                actions=actions, sim_steps=sim_steps.to(torch.int32), rand_vals=rand_vals[:, 0])
 
-    # ---- KAMMA.py:604-624 criteria controller ----
-    desired_v = commands[:, 0]
-    desired_omega = commands[:, 2]
-    current_v = v_forward_projected
-    current_omega = base_velocities[:, 5]
-    v_delta = desired_v - current_v
-    omega_delta = desired_omega - current_omega
-    ac_left = Kp * (vehicle_mass * (v_delta / dt)) - Kp_omega * (vehicle_inertia * (omega_delta / dt))
-    ac_right = Kp * (vehicle_mass * (v_delta / dt)) + Kp_omega * (vehicle_inertia * (omega_delta / dt))
-    criteria_action = torch.stack([ac_left, ac_left, ac_right, ac_right], dim=1)
-    out.update(v_delta=v_delta, omega_delta=omega_delta, ac_left=ac_left, ac_right=ac_right)
-
-    # ---- KAMMA.py:627-628 gamma schedule ----
-    gamma_assist = torch.clamp(1.0 - (sim_steps.float() / max_sim_steps), min=0.0)
-    out.update(gamma=gamma_assist)
-
-    # ---- KAMMA.py:632-636 stochastic switch, :649 clip, :656 guiding reward ----
-    gamma = gamma_assist.view(-1, 1)
-    mask = (rand_vals < gamma).float()
-    execution_action = mask * criteria_action + (1 - mask) * (actions * action_scale)
-    wheel_torqs = torch.clip(execution_action, -4.0, 4.0)
-    guiding_reward = -torch.norm(wheel_torqs - criteria_action, dim=1)
-    out.update(switch_torques=execution_action, switch_wheel_torqs=wheel_torqs, switch_guiding=guiding_reward)
-
-    # ---- KA_DDPG_4D.py:627-631 deterministic blend, :637 guiding on the unclipped policy torque ----
-    blend = (torch.tensor(1.0) - gamma) * actions * action_scale + gamma * criteria_action
-    blend_wheel = torch.clip(blend, -4.0, 4.0)
-    blend_guiding = -torch.norm(actions * action_scale - criteria_action, dim=1)
-    out.update(blend_torques=blend, blend_wheel_torqs=blend_wheel, blend_guiding=blend_guiding)
+    pre = prephysics_formulas(commands, v_forward_projected, base_velocities[:, 5], actions, sim_steps, rand_vals[:, 0], Kp=Kp,
+                              Kp_omega=Kp_omega, vehicle_mass=vehicle_mass, vehicle_inertia=vehicle_inertia, dt=dt, action_scale=action_scale,
+                              max_sim_steps=max_sim_steps)
+    out.update(pre)
+    v_delta, omega_delta, gamma_assist = pre["v_delta"], pre["omega_delta"], pre["gamma"]
+    wheel_torqs, guiding_reward = pre["switch_wheel_torqs"], pre["switch_guiding"]
+    desired_v, desired_omega = commands[:, 0], commands[:, 2]
 
     # ---- KAMMA.py:736-764 is_done ----
     q = torch.nn.functional.normalize(r(n, 4), dim=1)

@@ -367,6 +367,22 @@ def block_prephysics(variant, n=129, seed=0):
     if hasattr(T, "old_torques"):
         out["old_torques_out"] = T.old_torques
         out["sums_eval_out"] = torch.stack([T.episode_sums["Smoothness"], T.episode_sums["Desired velocity"]], 1)
+    # the build's own transcription (make_golden.prephysics_formulas, what refmath_step.npz was made with) on the same inputs
+    from tests.golden.make_golden import prephysics_formulas
+    a4 = actions if A == 4 else (actions.repeat_interleave(2, dim=1) if A == 2 else actions.repeat(1, 4))
+    tr = prephysics_formulas(inp["commands"], inp["v_forward_projected"], inp["omega_z"], a4, T.sim_steps, inp["switch_u"], Kp=T.Kp, Kp_omega=T.Kp_omega,
+                             vehicle_mass=T.vehicle_mass, vehicle_inertia=T.vehicle_inertia, dt=T.dt, action_scale=T.action_scale,
+                             max_sim_steps=T.max_sim_steps)
+    kind = "blend" if variant.startswith("KA_DDPG") else "switch"
+    for mine, theirs in (("v_delta", "v_delta"), ("omega_delta", "omega_delta"), ("ac_left", "ac_left"), ("ac_right", "ac_right")):
+        assert torch.equal(tr[mine], out[theirs]), (variant, mine)
+    const_gamma = co.cfg.gamma1_mode == co._abi.GAMMA_CONST
+    if not const_gamma:   # with the schedule lines commented out the files keep their constructor value: nothing to transcribe
+        assert torch.equal(tr["gamma"], out.get("gamma_assist1", out.get("gamma_assist"))), variant
+        assert torch.equal(tr[kind + "_torques"], out["torques"]) and torch.equal(tr[kind + "_wheel_torqs"], out["wheel_torqs"]), variant
+        guide = "blend_guiding" if kind == "blend" else "switch_guiding"   # (KAMMA_curr1 / _curr2 set the policy-torque form
+        # first and overwrite it after the loop with the executed-torque one, like KAMMA.py:656)
+        assert torch.equal(tr[guide], out["guiding"]), (variant, guide)
     d = {k: v.numpy() for k, v in {**inp, **out}.items()}
     d["max_sim_steps"] = np.float32(T.max_sim_steps)
     return d
