@@ -7,10 +7,11 @@ train_kamma_4d_nofifo_random_RLIL.py:21-36; fixed-seed random weights, fp32 PyTo
 inference) in the loop: obs -> actor -> ois_step, all on one stream, no host sync.
 
 One "step" = one policy step of all arenas of this rank. N>1: one process per GPU
-(torch.distributed / RCCL), arenas sharded by rank (weak scaling: 65 536 per GPU, global
-arena ids keep every stream identical to a 1-GPU run), ONE all-gather of the episode-return
-statistics per logging interval (800 steps, train_kamma_4d_nofifo_random_RLIL.py:176) — the
-path's only exchange.
+(torch.distributed / RCCL), arenas sharded by rank (weak scaling: 65 536 per GPU; global
+arena ids keep every per-arena stream identical to a 1-GPU run — the benchmark's KAMMA_medium task has
+no per-environment quantity; the eval / level-curriculum variants have two), ONE
+all-gather of the episode-return statistics per logging interval (800 steps,
+train_kamma_4d_nofifo_random_RLIL.py:176) — the path's only exchange.
 
 `python bench.py --gpus N` with N > 1 and no torch.distributed environment launches its own N
 ranks (a child `python -m torch.distributed.run`, started before anything in this process touches
@@ -22,7 +23,10 @@ Prints ONE JSON line on rank 0 (contract in the task statement) with two extra o
                 figure on the algorithmic 352 B/env-step of SURVEY.md section 8d sits beside it).
                 The kernel time is measured live: start / stop events on the kernel's own dispatch
                 packets over the timed region (ois_profile_*), i.e. what rocprofv3 --kernel-trace
-                reports for the same launches.
+                reports for the same launches. FLOPs three ways: executed by the launched instantiation
+                (ISA census), algorithmic (docs/SPEC.md 3.11), and the issue-slot utilisation from the
+                committed SQ counters — each quoted only when its artefact was taken on this checkout's
+                kernel sources.
   cpu_baseline  the CPU oracle (oracle/, test infrastructure) timed on this host's cores on a
                 bounded sample of the same workload (rank 0, N=1 only).
 """
