@@ -466,8 +466,55 @@ def block_box_bounds():
             "command_u": np.array(cmd, np.float32), "max_sim_steps": np.float32(T.max_sim_steps), "x_range": np.array(T.command_x_range, np.float32)}
 
 
+def block_get_heights(n=96, seed=4):
+    """get_heights (KAMMA.py:872-893) on the field of the reference's OWN terrain generator (origin_terrain_generator.Terrain,
+    executed: make_golden_ref.terrain_namespace). `points` — the scan lattice after quat_apply_yaw (:874-879, removed: omni's
+    normalize / quat_apply) plus the base position — is handed in from the build's transcription (make_golden.refmath_heights'
+    formulas); the border shift, the division by the horizontal scale, the truncation, the index clipping, the two gathers,
+    their minimum and the vertical scale are the reference's statements."""
+    from make_golden_ref import terrain_namespace
+    ns_t = terrain_namespace()
+    np.random.seed(3)
+    terr = ns_t["Terrain"]({"mapLength": 4.0, "mapWidth": 4.0, "numLevels": 2, "numTerrains": 2, "slopeTreshold": 0.5,
+                            "terrainProportions": [0.1, 0.5, 0.4], "curriculum": True}, n)
+    co = Cosim("KAMMA", n, 700)
+    T = co.task
+    T.terrain = terr
+    T.height_samples = torch.tensor(terr.heightsamples).view(terr.tot_rows, terr.tot_cols)
+    g = torch.Generator().manual_seed(seed)
+    base_pos = torch.rand((n, 3), generator=g) * torch.tensor([10.0, 10.0, 1.0]) - torch.tensor([1.0, 1.0, 0.0])   # the 2 x 2 tiles of 4 m
+    base_pos[:8] = torch.tensor([[-25.0, 1.0, 0], [40.0, 1.0, 0], [1.0, -29.0, 0], [1.0, 40.0, 0], [-20.0, -20.0, 0], [27.9, 27.9, 0],
+                                 [-19.99, 3.0, 0], [3.0, 27.95, 0]])                                          # beyond the field: index clipping
+    base_quat = torch.nn.functional.normalize(torch.randn((n, 4), generator=g), dim=1)
+    base_quat[::3, 1:3] *= 0.05
+    base_quat = torch.nn.functional.normalize(base_quat, dim=1)
+    # --- the build's transcription of init_height_points (:278-292, commented out in the reference) and quat_apply_yaw (:895-899)
+    y = 0.1 * torch.tensor([-5, -4, -3, -2, -1, 1, 2, 3, 4, 5])
+    x = 0.1 * torch.tensor([-8, -7, -6, -5, -4, -3, -2, 2, 3, 4, 5, 6, 7, 8])
+    grid_x, grid_y = torch.meshgrid(x, y, indexing="ij")
+    npts = grid_x.numel()
+    height_points = torch.zeros(n, npts, 3)
+    height_points[:, :, 0] = grid_x.flatten()
+    height_points[:, :, 1] = grid_y.flatten()
+    quat_yaw = base_quat.repeat(1, npts).clone().view(-1, 4)
+    quat_yaw[:, 1:3] = 0.0
+    quat_yaw = quat_yaw / quat_yaw.norm(p=2, dim=-1).clamp(min=1e-9, max=None).unsqueeze(-1)
+    b = height_points.reshape(-1, 3)
+    xyz = quat_yaw[:, 1:]
+    t = xyz.cross(b, dim=-1) * 2
+    rotated = (b + quat_yaw[:, :1] * t + xyz.cross(t, dim=-1)).view(height_points.shape)
+    co.ns["points"] = rotated + base_pos.unsqueeze(1)
+    T.base_pos, T.base_quat, T.num_height_points, T.height_points = base_pos, base_quat, npts, height_points
+    measured = T.get_heights()
+    return {"height_samples": T.height_samples.numpy(), "base_pos": base_pos.numpy(), "base_quat": base_quat.numpy(),
+            "horizontal_scale": np.float32(terr.horizontal_scale), "vertical_scale": np.float32(terr.vertical_scale),
+            "border_size": np.float32(terr.border_size), "measured_heights": measured.numpy()}
+
+
 def blocks():
     out = {}
+    for key, val in block_get_heights().items():
+        out[f"heights__{key}"] = val
     for k, v in enumerate(v for v in RUNS if v not in PATCHED):
         for key, val in block_prephysics(v, seed=k).items():
             out[f"prephysics__{v}__{key}"] = val

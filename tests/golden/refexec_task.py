@@ -17,7 +17,8 @@ env file and removes, by a mechanical rule, exactly the statements that cannot r
       removed too.
   R3  a statement that reads a local whose every assignment was removed is removed as well — unless the harness
       hands that value in as a GIVEN (a module global of the compiled code): `projected_gravity` for is_done,
-      `forward` / `up_dir` for the projection tail, `x_vel` for the uniform command draw. Givens are data computed
+      `forward` / `up_dir` for the projection tail, `x_vel` for the uniform command draw, `points` (the scan lattice after
+      `quat_apply_yaw`) for get_heights. Givens are data computed
       by the caller (here: by the oracle's quaternion helpers / the fixture's uniform draws), never code.
   R4  a compound statement whose header is removable goes as a whole; otherwise its body is filtered recursively.
 
@@ -41,8 +42,9 @@ REF = "/root/reference/src"
 SIM_ATTRS = {"world", "_robots", "_env"}
 METHODS = ["__init__", "update_config", "post_reset", "reset_idx", "sample_velocity_command", "refresh_dof_state_tensors",
            "refresh_body_state_tensors", "pre_physics_step", "post_physics_step", "push_robots", "is_done", "calculate_metrics",
-           "get_observations"]
-GIVENS = {"is_done": {"projected_gravity"}, "post_physics_step": {"forward", "up_dir"}, "sample_velocity_command": {"x_vel"}}
+           "get_observations", "get_heights"]
+GIVENS = {"is_done": {"projected_gravity"}, "post_physics_step": {"forward", "up_dir"}, "sample_velocity_command": {"x_vel"},
+          "get_heights": {"points"}}
 
 
 class _Playing(ast.NodeTransformer):

@@ -225,3 +225,14 @@ def test_box_sampler_bounds_of_the_reference(oracle_lib, blocks):
         np.testing.assert_allclose(max((hi[0] - lo[0]) * u + lo[0], 0.0), x, rtol=2e-7)            # :593-597 on the recorded draw
         assert om == 0.0
     assert d["x_min"][0] > 1.4 and d["x_min"][-1] == 1.0 and d["x_max"][-1] == 2.0                   # opens from 10 % to the full range
+
+
+def test_get_heights_of_the_reference_on_its_own_terrain(blocks):
+    """KAMMA.py:882-893 (border shift, division, truncation, index clipping, two gathers, minimum, vertical scale) executed on
+    the field the reference's own Terrain class generated; only the rotated lattice (`quat_apply_yaw`, omni) is handed in."""
+    from oracle.binding import get_heights
+    d = {k[len("heights__"):]: blocks[k] for k in blocks.files if k.startswith("heights__")}
+    mine = get_heights(d["base_pos"], d["base_quat"], d["height_samples"], float(d["horizontal_scale"]), float(d["vertical_scale"]),
+                       float(d["border_size"]))
+    assert np.array_equal(mine, d["measured_heights"])
+    assert (d["measured_heights"] != 0).mean() > 0.1 and len(np.unique(d["measured_heights"])) > 30   # on the tiles, not the flat border
