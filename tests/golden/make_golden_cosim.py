@@ -475,16 +475,16 @@ def block_get_heights(n=96, seed=4):
     from make_golden_ref import terrain_namespace
     ns_t = terrain_namespace()
     np.random.seed(3)
-    terr = ns_t["Terrain"]({"mapLength": 4.0, "mapWidth": 4.0, "numLevels": 2, "numTerrains": 2, "slopeTreshold": 0.5,
-                            "terrainProportions": [0.1, 0.5, 0.4], "curriculum": True}, n)
+    terr = ns_t["Terrain"]({"mapLength": 4.0, "mapWidth": 4.0, "numLevels": 3, "numTerrains": 3, "slopeTreshold": 0.5,
+                            "terrainProportions": [0.1, 0.5, 0.4], "curriculum": False}, n)   # randomized_terrain: every family
     co = Cosim("KAMMA", n, 700)
     T = co.task
     T.terrain = terr
     T.height_samples = torch.tensor(terr.heightsamples).view(terr.tot_rows, terr.tot_cols)
     g = torch.Generator().manual_seed(seed)
-    base_pos = torch.rand((n, 3), generator=g) * torch.tensor([10.0, 10.0, 1.0]) - torch.tensor([1.0, 1.0, 0.0])   # the 2 x 2 tiles of 4 m
-    base_pos[:8] = torch.tensor([[-25.0, 1.0, 0], [40.0, 1.0, 0], [1.0, -29.0, 0], [1.0, 40.0, 0], [-20.0, -20.0, 0], [27.9, 27.9, 0],
-                                 [-19.99, 3.0, 0], [3.0, 27.95, 0]])                                          # beyond the field: index clipping
+    base_pos = torch.rand((n, 3), generator=g) * torch.tensor([14.0, 14.0, 1.0]) - torch.tensor([1.0, 1.0, 0.0])   # the 3 x 3 tiles of 4 m
+    base_pos[:8] = torch.tensor([[-25.0, 1.0, 0], [40.0, 1.0, 0], [1.0, -29.0, 0], [1.0, 40.0, 0], [-20.0, -20.0, 0], [31.9, 31.9, 0],
+                                 [-19.99, 3.0, 0], [3.0, 31.95, 0]])                                          # beyond the field: index clipping
     base_quat = torch.nn.functional.normalize(torch.randn((n, 4), generator=g), dim=1)
     base_quat[::3, 1:3] *= 0.05
     base_quat = torch.nn.functional.normalize(base_quat, dim=1)
