@@ -27,7 +27,8 @@
  *   - left on the build's own transcription (tests/golden/refmath_*.npz, tests/golden/make_golden.py), because the
  *     statement itself is a call into omni.isaac.core.utils.torch, which is not under /root/reference: quat_apply (has_fallen
  *     :749, forward / up :701, :707), quat_mul (the yaw quaternion :434), torch_rand_float (lower + (upper - lower) u,
- *     :424-456, :571), normalize + quat_apply in get_heights (:872-899).
+ *     :424-456, :571), normalize + quat_apply inside quat_apply_yaw (:895-899; the index arithmetic of get_heights,
+ *     :882-893, is executed on a field of the reference's own Terrain class: refexec_blocks.npz heights__*).
  *   - physics (PhysX 5 inside Isaac Sim 4.0.0, not in /root/reference, no golden vectors
  *     anywhere in the reference): PARITY UNPINNED. The model is defined by docs/SPEC.md §3;
  *     parity is oracle <-> HIP kernel only.
