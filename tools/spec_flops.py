@@ -30,8 +30,8 @@ SUBSTEP = [
             "lateral (3 fma), fma, clamp (2), delta, o update (3 fma) = 17", 17 + 22 + 17, 4 * SOLVER_ITERATIONS),
     ("3.5", "iteration, averaging (as in the warm start)", 9 + 6 + 12, SOLVER_ITERATIONS),
     ("3.5", "v_b = n_b un + t1 u1 + t2 u2 (x: mul + 2 fma, y: mul + fma, z: mul + 2 fma)", 5 + 3 + 5, 1),
-    ("3.7", "v = R v_b (15); |w_b| cap: |w|^2 (5), rsqrt, mul, min, 3 mul (11); 4 spin caps (2 each); p += dt v (3 fma); "
-            "q (x) (0, w_b): 4 x (mul + 2 fma); q += dt/2 (...) (4 fma); |q|^2 (mul + 3 fma), 1.5 - 0.5 |q|^2 (fma), 4 mul", 15 + 11 + 8 + 6 + 20 + 8 + 13, 1),
+    ("3.7", "v = R v_b (15); cap of norm(w_b): w.w (5), rsqrt, mul, min, 3 mul (11); 4 spin caps (2 each); p += dt v (3 fma); "
+            "q (x) (0, w_b): 4 x (mul + 2 fma); q += dt/2 (...) (4 fma); q.q (mul + 3 fma), 1.5 - 0.5 q.q (fma), 4 mul", 15 + 11 + 8 + 6 + 20 + 8 + 13, 1),
 ]
 
 # the policy step's own arithmetic (SPEC section 2; once per 20 substeps)
