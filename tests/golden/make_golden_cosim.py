@@ -75,7 +75,14 @@ def rf(lo, hi, u):
 
 # env-file runs with a TASK_CFG leaf changed (name -> (env file, {path: value})): the terminal reward is 0.0 in every file,
 # which hides `terminalReward * reset_buf * ~timeout_buf` (KAMMA.py:801, `~` on an int64 tensor: -1 / -2)
-PATCHED = {"KAMMA_medium+terminal1.5": ("KAMMA_medium", {"task/env/learn/terminalReward": 1.5})}
+PATCHED = {"KAMMA_medium+terminal1.5": ("KAMMA_medium", {"task/env/learn/terminalReward": 1.5}),
+           # config plumbing through the whole step: controller gain, action scale, policy dt = 5 x 0.01 s and an 80-step
+           # episode (update_config :258-263), a tight observation clip (rl_task.py:99), and a command range whose small
+           # draws are zeroed by the mask of :458
+           "KAMMA+config": ("KAMMA", {"task/env/control/stiffness": 0.05, "task/env/control/actionScale": 2.0,
+                                      "task/env/control/decimation": 5, "task/env/learn/episodeLength_s": 4.0,
+                                      "task/env/clipObservations": 5.0,
+                                      "task/env/randomCommandVelocityRanges/linear_x": [0.0, 0.6]})}
 
 
 def _patch(cfg, patches):
@@ -277,9 +284,10 @@ RUNS = {  # variant -> (arenas, steps, {step: [(event, arena)]}); two synchronou
     "KA_DDPG_2D_eval": (3, 104, {20: [("fall", 1)]}),
     "KA_DDPG_1D_eval": (3, 104, {30: [("fall", 2)]}),
     "KAMMA_medium+terminal1.5": (4, 104, {33: [("fall", 1)], 50: [("oob", 2)]}),
+    "KAMMA+config": (6, 170, {33: [("fall", 1)], 50: [("oob", 2)]}),
 }
 # sim_steps where the gamma schedule is in the interior (the trajectories above start at 0: gamma 1 - 2e-4)
-START_SIM_STEPS = {"KAMMA": 150000, "KAMMA_medium": 420000, "KAMMA_medium+terminal1.5": 100000, "KAMMA_g1d_g21": 250000, "KAMMA_curr1": 200000, "KAMMA_curr2": 300000,
+START_SIM_STEPS = {"KAMMA+config": 250000, "KAMMA": 150000, "KAMMA_medium": 420000, "KAMMA_medium+terminal1.5": 100000, "KAMMA_g1d_g21": 250000, "KAMMA_curr1": 200000, "KAMMA_curr2": 300000,
                    "KA_DDPG_4D": 350000, "KAMMA_eval": 20000, "KA_DDPG_2D_eval": 30000, "KA_DDPG_1D_eval": 49950}
 
 
@@ -323,6 +331,8 @@ def pack(variant, co, first, steps):
     d["first__reset_u"] = co.first_reset_u
     d["start_sim_steps"] = np.int32(START_SIM_STEPS.get(variant, 0))
     d["reference_raised_zero_division_at"] = np.int32(getattr(co, "raised_at", -1))
+    d["env_file"] = np.array(co.variant)
+    d["task_cfg_patches_json"] = np.array(json.dumps(PATCHED.get(variant, (variant, {}))[1], sort_keys=True))
     return {f"{variant}__{k}": v for k, v in d.items()}
 
 

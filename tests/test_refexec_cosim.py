@@ -22,9 +22,8 @@ from tests.cosim_check import check_step
 G = os.path.join(os.path.dirname(__file__), "golden")
 VARIANTS = ["KAMMA", "KAMMA_medium", "KAMMA_g11_g21", "KAMMA_g1d_g21", "KAMMA_curr1", "KAMMA_curr2", "KAMMA_eval", "KA_DDPG_4D",
             "KA_DDPG_2D", "KA_DDPG_1D", "KA_DDPG_2D_eval", "KA_DDPG_1D_eval"]
-# runs of an env file with one TASK_CFG leaf changed (make_golden_cosim.PATCHED): name -> (env file, build_config overrides)
-PATCHED_RUNS = {"KAMMA_medium+terminal1.5": ("KAMMA_medium", {"terminal_reward": 1.5})}
-RUN_NAMES = VARIANTS + list(PATCHED_RUNS)
+# runs of an env file with TASK_CFG leaves changed (make_golden_cosim.PATCHED; the fixture stores the env file and the patches)
+RUN_NAMES = VARIANTS + ["KAMMA_medium+terminal1.5", "KAMMA+config"]
 
 
 @pytest.fixture(scope="module")
@@ -41,8 +40,15 @@ def test_oracle_follows_the_reference_statements_step_by_step(fixture, variant):
     d = _variant(fixture, variant)
     T, n = d["actions"].shape[:2]
     seed = 100 + RUN_NAMES.index(variant)
-    env_file, overrides = PATCHED_RUNS.get(variant, (variant, {}))
-    cfg = build_config(variant=env_file, num_envs=n, seed=seed, **overrides)
+    from options_in_simulation_amd import default_task_cfg
+    task_cfg = default_task_cfg()
+    for path, value in json.loads(str(d["task_cfg_patches_json"])).items():   # the same TASK_CFG leaves the reference run had changed
+        node, keys = task_cfg, path.split("/")
+        for k in keys[:-1]:
+            node = node[k]
+        assert keys[-1] in node
+        node[keys[-1]] = value
+    cfg = build_config(task_cfg, variant=str(d["env_file"]), num_envs=n, seed=seed)
     env = OracleEnv(cfg)
     env.set_hooks(reset_u=np.ascontiguousarray(d["first__reset_u"]))
     env.reset(seed)
@@ -52,7 +58,7 @@ def test_oracle_follows_the_reference_statements_step_by_step(fixture, variant):
     if int(d["start_sim_steps"]):
         env.buffer(_abi.BUF_COUNTERS)[:, 1] = int(d["start_sim_steps"])
     per_step = [k for k in d if not k.startswith("first__") and k not in ("extras_keys", "components_keys", "start_sim_steps",
-                                                                          "reference_raised_zero_division_at")]
+                                                                          "reference_raised_zero_division_at", "env_file", "task_cfg_patches_json")]
     for t in range(T):
         env.set_hooks(switch_u=np.ascontiguousarray(d["switch_u"][t]), reset_u=np.ascontiguousarray(d["reset_u"][t]),
                       physics_in=np.ascontiguousarray(d["physics"][t]))
@@ -69,6 +75,13 @@ def test_oracle_follows_the_reference_statements_step_by_step(fixture, variant):
         both = (d["reset"] == 1) & (d["timeout"] == 1)
         only = (d["reset"] == 1) & (d["timeout"] == 0)
         assert both.any() and only.any()
+    if variant == "KAMMA+config":
+        assert cfg.max_episode_length == 80 and cfg.policy_dt == np.float32(0.05) and cfg.Kp == np.float32(0.05) and cfg.action_scale == 2.0
+        assert (np.abs(d["obs"]) > 5.0).any()                                   # the task's own buffer is unclipped; the wrapper clips (rl_task.py:99)
+        zeroed = (d["commands"][:, :, 1] == 0) & (d["commands"][:, :, 3] == 0)
+        assert zeroed.any() and not zeroed.all()                                # 'set small commands to zero' (:458) hit on some resets
+        t_first = int(np.argmax(d["timeout"].any(axis=1)))
+        assert d["episode_buf"][t_first - 1].max() == 78                        # timeout at episode_buf >= max_episode_length - 1 = 79
     stop = int(d["reference_raised_zero_division_at"])
     if stop >= 0:
         # the reference itself stops at this step: get_observations divides by rew_buf[0].item() == 0.0 in Python floats
