@@ -496,3 +496,35 @@ def test_misaligned_actions_are_refused():
     assert rc == _abi.EINVAL and b"aligned" in env.L.ois_last_error()
     assert env.L.ois_step(env.h, C.c_void_p(buf.data_ptr()), None) == 0
     torch.cuda.synchronize()
+
+
+def test_patched_task_cfg_parity_on_the_hip_path():
+    """The TASK_CFG leaves of the lock-step run `KAMMA+config` (tests/golden/refexec_cosim.npz: the reference's own statements
+    against the oracle) on the kernel: controller gain, action scale, 5 substeps of 0.01 s + 10, 80-step episodes, observation
+    clip 5.0, a command range whose small draws are zeroed — kernel and oracle bit for bit across two timeouts."""
+    from options_in_simulation_amd import default_task_cfg
+    from options_in_simulation_amd.vecenv import NativeEnv
+    from oracle.binding import OracleEnv
+    tc = default_task_cfg()
+    env = tc["task"]["env"]
+    env["control"].update(stiffness=0.05, actionScale=2.0, decimation=5)
+    env["learn"]["episodeLength_s"] = 4.0
+    env["clipObservations"] = 5.0
+    env["randomCommandVelocityRanges"]["linear_x"] = [0.0, 0.6]
+    N = 1000
+    cfg = build_config(tc, variant="KAMMA", num_envs=N, seed=21, max_sim_steps=300.0)
+    assert cfg.max_episode_length == 80 and cfg.decimation == 5
+    dev, orc = NativeEnv(cfg, "cuda:0"), OracleEnv(cfg)
+    dev.reset(21); orc.reset(21)
+    rng = np.random.default_rng(3)
+    for t in range(165):
+        a = rng.uniform(-0.2, 1.5, size=(N, 4)).astype(np.float32)
+        dev.step(torch.from_numpy(a).cuda()); orc.step(a)
+        if t % 20 == 0 or t in (78, 79, 80, 158, 159):
+            compare(dev, orc, f"patched config step {t}", exact_float=True)
+    compare(dev, orc, "patched config end", exact_float=True)
+    cnt = dev.buffer(_abi.BUF_COUNTERS).cpu().numpy()
+    assert (cnt[:, 2] >= 3).all()                        # post_reset + two synchronous timeouts at 79-step episodes
+    cmd = dev.buffer(_abi.BUF_COMMANDS).cpu().numpy()
+    assert ((cmd[:, 1] == 0) & (cmd[:, 3] == 0)).any()   # the small-command mask fired for some arenas
+    assert float(dev.buffer(_abi.BUF_OBS).abs().max()) <= 5.0
