@@ -83,14 +83,17 @@ class WrappedRefEnv:
     """skrl's wrapper semantics (third-party, restated from its published source) around the reference's own
     task statements on the oracle's physics"""
 
-    def __init__(self, variant, n, seed):
+    def __init__(self, variant, n, seed, events=None):
+        self.events = events or {}
         self.co = Cosim(variant, n, seed)
         self.task = self.co.task
         self.num_envs, self.num_agents = n, 1
         self._first, self._obs, self._t = True, None, 0
+        self.history = []
 
     def _step(self, actions):
-        out = self.co.step(self._t, actions.numpy().astype(np.float32))
+        out = self.co.step(self._t, actions.numpy().astype(np.float32), self.events.get(self._t, ()))
+        self.history.append(out)
         self._t += 1
         T = self.task
         obs = torch.clamp(T.obs_buf, -T.clip_obs, T.clip_obs).clone()           # rl_task.py:99 / VecEnvBase.step
@@ -155,7 +158,81 @@ def run(method, variant, n, timesteps, headless, seed):
             "env_reset_calls": len(resets), "events": log}
 
 
+def extract_method_in_class(relpath, cls, method, base, extra_globals):
+    """a method that uses zero-argument super(): compiled inside a class statement (so that the __class__ cell exists) whose
+    base is `base`; returns the class"""
+    import ast
+    from make_golden_ref import REF
+    path = os.path.join(REF, relpath)
+    tree = ast.parse(open(path).read(), filename=path)
+    c = next(n for n in tree.body if isinstance(n, ast.ClassDef) and n.name == cls)
+    fn = next(n for n in c.body if isinstance(n, ast.FunctionDef) and n.name == method)
+    new = ast.ClassDef(name=cls, bases=[ast.Name("Base_", ast.Load())], keywords=[], body=[fn], decorator_list=[])
+    mod = ast.Module(body=[new], type_ignores=[])
+    ast.fix_missing_locations(mod)
+    ns = {"torch": torch, "np": np, "Base_": base}
+    ns.update(extra_globals)
+    exec(compile(mod, path, "exec"), ns)
+    return ns[cls]
+
+
+def fifo_case(n=3, timesteps=41, memory_size=16, seed=31):
+    """The whole caller chain as the reference wrote it: Trainer.single_agent_train (base_KA_DDPG.py:153) ->
+    DDPG.record_transition (my_agents/ddpg.py:270: super().record_transition = Agent.record_transition, base.py:270, then
+    self.memory.add_samples) -> FIFOMemory.add_samples (train/train_kaddpg_4d_nofifo_random_RLIL.py:152, the script's own
+    class), all executed unchanged on the reference's own task statements. skrl's Memory base class (third-party) is not used:
+    what its constructor and create_tensor leave on the object — tensors[name] of shape (memory_size, num_envs, size),
+    memory_index, env_index, filled — is set here as its published source does. Output: the memory after `timesteps` steps
+    (it wraps) plus the run's inputs, so that the oracle's transition ring (orc_replay_*, the mirror of ois_replay_*) can
+    replay it."""
+    import collections
+    from typing import Any, List, Tuple
+    train, _ = extract("my_trainers/base_KA_DDPG.py", "Trainer", "single_agent_train", extra_globals={"tqdm": __import__("tqdm"), "sys": sys})
+    AgentBase = extract_method_in_class("my_agents/base.py", "Agent", "record_transition", object, {"Any": Any})
+    DDPG = extract_method_in_class("my_agents/ddpg.py", "DDPG", "record_transition", AgentBase, {"Any": Any})
+    add_samples, _ = extract("../train/train_kaddpg_4d_nofifo_random_RLIL.py", "FIFOMemory", "add_samples",
+                             extra_globals={"Tuple": Tuple, "List": List})
+    log = []
+    env = WrappedRefEnv("KA_DDPG_4D", n, seed, events={33: [("fall", 1)], 34: [("fall", 1)]})   # an episode ends inside the last 16 rows
+
+    class Memory:   # what skrl's Memory.__init__ / create_tensor leave behind (shapes per its published source)
+        pass
+    mem = Memory()
+    mem.memory_size, mem.num_envs, mem.memory_index, mem.env_index, mem.filled = memory_size, n, 0, 0, False
+    mem.tensors = {"states": torch.zeros(memory_size, n, 6), "actions": torch.zeros(memory_size, n, 4), "rewards": torch.zeros(memory_size, n, 1),
+                   "next_states": torch.zeros(memory_size, n, 6), "terminated": torch.zeros(memory_size, n, 1, dtype=torch.bool)}
+    mem.add_samples = types.MethodType(add_samples, mem)
+
+    class Agent(DDPG):
+        def __init__(self):
+            self.write_interval, self._cumulative_rewards, self._cumulative_timesteps = 800, None, None
+            self._track_rewards, self._track_timesteps = collections.deque(maxlen=100), collections.deque(maxlen=100)
+            self.tracking_data = collections.defaultdict(list)
+            self.memory, self._rewards_shaper, self.secondary_memories = mem, None, []
+            self.g = torch.Generator().manual_seed(1)
+
+        def pre_interaction(self, timestep, timesteps): pass
+        def post_interaction(self, timestep, timesteps): pass
+        def track_data(self, tag, value): pass
+
+        def act(self, states, timestep, timesteps):
+            return 2.0 * torch.rand((states.shape[0], 4), generator=self.g) - 1.0, None, {}
+    S = types.SimpleNamespace(env=env, agents=Agent(), num_simultaneous_agents=1, initial_timestep=0, timesteps=timesteps,
+                              disable_progressbar=True, headless=True, environment_info="episode")
+    train(S)
+    h = env.history   # [0] = the zero-action step inside the first env.reset()
+    out = {"first_reset_u": env.co.first_reset_u, "memory_size": np.int32(memory_size), "timesteps": np.int32(timesteps), "seed": np.int32(seed),
+           "memory_index": np.int32(mem.memory_index), "filled": np.bool_(mem.filled)}
+    for k in ("actions", "switch_u", "reset_u", "physics"):
+        out["step__" + k] = np.stack([x[k] for x in h])
+    for k, v in mem.tensors.items():
+        out["memory__" + k] = v.numpy()
+    out["track_rewards"] = np.array(S.agents._track_rewards, np.float64)
+    return out
+
+
 def main():
+    np.savez_compressed(os.path.join(HERE, "refexec_fifo.npz"), **fifo_case())
     runs = [run("single_agent_train", "KAMMA_medium", 4, 3, False, 21),      # num_envs > 1, rendering on
             run("single_agent_train", "KAMMA_medium", 1, 101, True, 22),      # num_envs == 1 across the timeout at step 99
             run("single_agent_train", "KA_DDPG_2D", 3, 2, True, 23),

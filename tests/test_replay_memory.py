@@ -342,3 +342,34 @@ def test_policy_and_executed_action_modes():
     torch.testing.assert_close(m4.get_tensor_by_name("actions")[0], env4.task.wheel_torqs / env4.task.action_scale, rtol=3e-7, atol=0)
     assert not torch.equal(m4.get_tensor_by_name("actions")[0], a4)
     m4.close(); env4.close()
+
+
+def test_ring_equals_the_memory_the_references_own_chain_filled():
+    """tests/golden/refexec_fifo.npz (tests/golden/make_golden_trainer.py): the reference's trainer loop -> DDPG.record_transition
+    -> Agent.record_transition -> the script's FIFOMemory.add_samples, all executed unchanged on the reference's own task
+    statements, 41 steps into a 16-row memory (it wraps twice). The oracle's transition ring — the mirror of what the step kernel
+    writes (ois_replay_*), attached after the wrapper's first reset as DeviceFIFOMemory is — replays the run's inputs and must hold
+    the same rows at the same cursor: states = the observation the action was computed from, actions = executed torques /
+    action_scale (base_KA_DDPG.py:212), next_states, rewards, terminated."""
+    import os
+    d = np.load(os.path.join(os.path.dirname(__file__), "golden", "refexec_fifo.npz"))
+    T1, n = d["step__actions"].shape[:2]          # [0] = the zero-action step inside the first env.reset()
+    M = int(d["memory_size"])
+    cfg = build_config(variant="KA_DDPG_4D", num_envs=n, seed=int(d["seed"]))
+    env = OracleEnv(cfg)
+    env.set_hooks(reset_u=np.ascontiguousarray(d["first_reset_u"]))
+    env.reset(7)
+    mem = None
+    for t in range(T1):
+        env.set_hooks(switch_u=np.ascontiguousarray(d["step__switch_u"][t]), reset_u=np.ascontiguousarray(d["step__reset_u"][t]),
+                      physics_in=np.ascontiguousarray(d["step__physics"][t]))
+        env.step(d["step__actions"][t])
+        if t == 0:
+            mem = env.attach_replay(M)             # the reference records nothing for the wrapper's own first step
+    assert env.replay_cursor() == (int(d["memory_index"]), bool(d["filled"])) == ((T1 - 1) % M, True)
+    np.testing.assert_array_equal(mem["states"], d["memory__states"])
+    np.testing.assert_array_equal(mem["next_states"], d["memory__next_states"])
+    np.testing.assert_array_equal(mem["actions"], d["memory__actions"])
+    np.testing.assert_array_equal(mem["terminated"].astype(bool), d["memory__terminated"])
+    np.testing.assert_allclose(mem["rewards"], d["memory__rewards"], rtol=3e-6, atol=3e-6)   # r3 / guiding: order of a 4-wheel sum
+    assert d["memory__terminated"].any()           # an episode ended inside the window
