@@ -18,6 +18,7 @@ What is executed (file:line of the definitions in /root/reference/src):
   my_envs/KAMMA_curr2.py      .sample_velocity_command (GridSampling :600-640)
   my_envs/KAMMA_g1d_g21.py    .get_observations (env-0 reward guard :838-842)
   my_agents/ppo.py            PPO._update.compute_gae :320 (nested function)
+  my_agents/ppoc.py           PPOC.compute_advantages_and_returns :305
   my_agents/base.py           Agent.record_transition :270 (episode return / length bookkeeping)
   options_sim/cli/artifacts.py          _collect_timeseries :68, _write_csv :96 (over the build's event files)
   options_sim/cli/eval_artifacts.py     _get_series :62, _align_by_step :76, _moving_average :90
@@ -306,9 +307,24 @@ def gae_case():
                              discount_factor=float(d["discount_factor"]), lambda_coefficient=float(d["lambda_coefficient"]))
     assert np.array_equal(returns.numpy(), d["ppo_returns"]) and np.array_equal(advantages.numpy(), d["ppo_advantages"]), \
         "make_golden.refmath_gae differs from the reference's compute_gae"
+    # PPOC.compute_advantages_and_returns (my_agents/ppoc.py:305-336), the whole method unchanged. It reads the rollout through
+    # `self.memory.get_tensor_by_name` (skrl's memory: third-party; here an accessor over the fixture's tensors), passes the last
+    # next state through the (empty = identity) preprocessors and asks `self.option_value` for its value: the fixture's
+    # last_values. gamma / lam are the agent's Python floats.
+    ppoc, _ = extract("my_agents/ppoc.py", "PPOC", "compute_advantages_and_returns")
+    T = {"rewards": torch.from_numpy(d["rewards"]), "terminated": torch.from_numpy(d["terminated"]), "values": torch.from_numpy(d["values"]),
+         "next_states": torch.zeros(d["rewards"].shape[0], d["rewards"].shape[1], 6), "current_option": torch.zeros_like(torch.from_numpy(d["rewards"]))}
+    mem = types.SimpleNamespace(get_tensor_by_name=lambda name, idx=None: T[name] if idx is None else T[name][idx])
+    agent = types.SimpleNamespace(memory=mem, gamma=float(d["discount_factor"]), lam=float(d["lambda_coefficient"]),
+                                  _state_preprocessor=lambda x, **k: x, _value_preprocessor=lambda x, **k: x,
+                                  option_value=lambda inputs, options: (torch.from_numpy(d["last_values"]), None, None))
+    adv2, ret2 = ppoc(agent)
+    assert np.array_equal(adv2.numpy(), d["ppoc_advantages"]) and np.array_equal(ret2.numpy(), d["ppoc_returns"]), \
+        "make_golden.refmath_gae differs from the reference's PPOC.compute_advantages_and_returns"
     return {"rewards": d["rewards"], "values": d["values"], "last_values": d["last_values"], "terminated": d["terminated"],
             "discount_factor": d["discount_factor"], "lambda_coefficient": d["lambda_coefficient"],
-            "returns": returns.numpy(), "advantages": advantages.numpy()}
+            "returns": returns.numpy(), "advantages": advantages.numpy(),
+            "ppoc_advantages": adv2.numpy(), "ppoc_returns": ret2.numpy()}
 
 
 # ------------------------------------------------------------------ terrain ----------------------

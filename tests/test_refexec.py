@@ -134,6 +134,9 @@ def test_gae_against_the_executed_reference():
     np.testing.assert_allclose(adv, d["advantages"], rtol=1e-5, atol=1e-6)  # mean / std reductions: summation order
     ret, raw = ob.gae(0, d["rewards"], d["terminated"], d["values"], d["last_values"], g, l, False)
     assert np.array_equal(raw + d["values"], d["returns"])                   # returns = advantages + values (:352)
+    # PPOC.compute_advantages_and_returns (ppoc.py:305-336), the method itself executed: mode 1 of orc_gae / ois_gae, bit for bit
+    ret2, adv2 = ob.gae(1, d["rewards"], d["terminated"], d["values"], d["last_values"], g, l, False)
+    assert np.array_equal(adv2, d["ppoc_advantages"]) and np.array_equal(ret2, d["ppoc_returns"])
 
 
 HS, VS = 0.02, 0.006
