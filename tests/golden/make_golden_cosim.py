@@ -39,7 +39,7 @@ sys.path.insert(0, ROOT)
 sys.path.insert(0, HERE)
 
 import refexec_task as rt  # noqa: E402
-from make_golden_ref import SCRIPT_OVERRIDES, SUM_KEYS, VARIANT_FILES, _apply_overrides  # noqa: E402
+from make_golden_ref import SUM_KEYS, _apply_overrides  # noqa: E402
 
 F = torch.float32
 EVAL_KEYS = ["Smoothness", "Tracking error", "Desired velocity"]
