@@ -209,7 +209,8 @@ def test_algorithmic_flop_count_is_the_one_bench_quotes():
     assert len(rows) == len(spec_flops.SUBSTEP) and all(int(a) * int(b) == int(c) for a, b, c in rows)
     # the executed figure is keyed on the launched instantiation and quoted only on this checkout's kernel sources
     flop, valu, prov = bench.executed_flop_per_env_step("step_kernel<1,1,4,1>", 20)
-    if prov["status"].startswith("quoted"):
-        assert valu == 20 * 602 and 0.8 < flop / bench.algorithmic_flop_per_env_step() < 1.0
+    # profiles/r3_isa_census.json is regenerated (tools/isa_census.py --json, no GPU needed) whenever the kernel sources change
+    assert prov["status"].startswith("quoted"), prov
+    assert valu == 20 * 595 and 0.8 < flop / bench.algorithmic_flop_per_env_step() < 1.0
     flop2, _, prov2 = bench.executed_flop_per_env_step("step_kernel<9,9,9,9>", 20)
     assert flop2 == bench.FLOP_PER_ENV_STEP and prov2["status"].startswith("not quoted")

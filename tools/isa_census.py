@@ -18,7 +18,11 @@ def kernel_id(mangled):
     m = re.search(r"\d+(step_kernel\w*?)I((?:L[ib]\d+E)+)E", mangled)
     if not m:
         return None
-    return m.group(1) + "<" + ",".join(re.findall(r"L[ib](\d+)E", m.group(2))) + ">"
+    args = re.findall(r"L[ib](\d+)E", m.group(2))
+    # the last template argument of the three shells is FOLD (continuation launches of a level-curriculum rollout): ois_kernel_info
+    # names the shell an ois_step launches, i.e. without it
+    fold = args.pop() if len(args) == {"step_kernel": 5, "step_kernel_w2": 4, "step_kernel_terrain": 3}.get(m.group(1), -1) else "0"
+    return m.group(1) + "<" + ",".join(args) + ">" + ("+fold" if fold == "1" else "")
 
 
 def census(asm, want, quiet=False):
@@ -46,6 +50,11 @@ def census(asm, want, quiet=False):
             if not s or s[0] in ";.":
                 continue
             cur[2].append(s.split()[0])
+            if s.split()[0] == "s_cbranch_execz":
+                # the fall-through of an execz branch runs only while some lane took the `if`: its own pseudo-block, so that a rare
+                # path that the assembler printed inside the label of the main path is not counted as executed
+                blocks.append(cur)
+                cur = [cur[0] + "+execz", cur[1], []]
         blocks.append(cur)
         md = meta.get(name, {})
         if quiet:
