@@ -214,3 +214,20 @@ def test_algorithmic_flop_count_is_the_one_bench_quotes():
     assert valu == 20 * 595 and 0.8 < flop / bench.algorithmic_flop_per_env_step() < 1.0
     flop2, _, prov2 = bench.executed_flop_per_env_step("step_kernel<9,9,9,9>", 20)
     assert flop2 == bench.FLOP_PER_ENV_STEP and prov2["status"].startswith("not quoted")
+
+
+def test_census_ids_are_the_ids_ois_kernel_info_reports():
+    """tools/isa_census.py names a kernel by its template arguments without the trailing FOLD flag (`+fold` for the continuation
+    shells): the string ois_kernel_info reports for the shell an ois_step launches, which is what bench.py looks up."""
+    import json
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import isa_census
+    assert isa_census.kernel_id("_ZN12_GLOBAL__N_111step_kernelILi1ELb1ELi4ELb1ELb0EEEvN3ois9DevConstsE") == "step_kernel<1,1,4,1>"
+    assert isa_census.kernel_id("_ZN12_GLOBAL__N_111step_kernelILi2ELb1ELi4ELb0ELb1EEEvN3ois9DevConstsE") == "step_kernel<2,1,4,0>+fold"
+    assert isa_census.kernel_id("_ZN12_GLOBAL__N_114step_kernel_w2ILb1ELi4ELb1ELb0EEEvN3ois9DevConstsE") == "step_kernel_w2<1,4,1>"
+    assert isa_census.kernel_id("_ZN12_GLOBAL__N_119step_kernel_terrainILb1ELi4ELb0EEEvN3ois9DevConstsE") == "step_kernel_terrain<1,4>"
+    d = json.load(open(os.path.join(ROOT, "profiles", "r3_isa_census.json")))["kernels"]
+    for kid in ("step_kernel<1,1,4,1>", "step_kernel<1,1,4,0>", "step_kernel<2,1,4,1>", "step_kernel_w2<1,4,1>", "step_kernel_terrain<1,4>",
+                "step_kernel<1,1,4,1>+fold"):
+        assert kid in d and d[kid]["scratch_bytes"] <= (256 if "w2" in kid else 64), kid
+    assert d["step_kernel<1,1,4,0>"]["substep_valu"] - d["step_kernel<1,1,4,1>"]["substep_valu"] == 12   # the flat-plane shells
