@@ -33,7 +33,7 @@ PHYSICS_STRIDE = 20   # ORC_PHYSICS_STRIDE
 class ReplayHooks(C.Structure):
     """orc_test_hooks (oracle/ois_oracle.h): fixture replay of the reference's draws and of the simulator's outcome"""
     _fields_ = [("switch_u", C.POINTER(C.c_float)), ("reset_u", C.POINTER(C.c_float)), ("physics_in", C.POINTER(C.c_float)),
-                ("physics_out", C.POINTER(C.c_float))]
+                ("physics_out", C.POINTER(C.c_float)), ("level_z", C.POINTER(C.c_float)), ("levels", C.POINTER(C.c_int32))]
 
 
 def lib() -> C.CDLL:
@@ -231,17 +231,19 @@ class OracleEnv:
     def push_robots(self):
         self._check(self.L.orc_push_robots(self.h))
 
-    def set_hooks(self, switch_u=None, reset_u=None, physics_in=None, physics_out=None):
+    def set_hooks(self, switch_u=None, reset_u=None, physics_in=None, physics_out=None, level_z=None, levels=None):
         """orc_test_set_hooks: float32 arrays [N], [N, 12], [N, 20], [N, 20] that the env reads (writes: physics_out) at
         every reset / step until replaced; the arrays are kept alive here. No argument clears the hooks."""
         shapes = {"switch_u": (self.N,), "reset_u": (self.N, RESET_U_STRIDE), "physics_in": (self.N, PHYSICS_STRIDE),
-                  "physics_out": (self.N, PHYSICS_STRIDE)}
-        given = {"switch_u": switch_u, "reset_u": reset_u, "physics_in": physics_in, "physics_out": physics_out}
+                  "physics_out": (self.N, PHYSICS_STRIDE), "level_z": (self.N,), "levels": (self.N,)}
+        given = {"switch_u": switch_u, "reset_u": reset_u, "physics_in": physics_in, "physics_out": physics_out, "level_z": level_z,
+                 "levels": levels}
         h = ReplayHooks()
         for k, a in given.items():
             if a is not None:
-                assert a.dtype == np.float32 and a.flags.c_contiguous and a.shape == shapes[k], (k, a.shape, a.dtype)
-                setattr(h, k, fptr(a))
+                want = np.int32 if k == "levels" else np.float32
+                assert a.dtype == want and a.flags.c_contiguous and a.shape == shapes[k], (k, a.shape, a.dtype)
+                setattr(h, k, iptr(a) if k == "levels" else fptr(a))
         self._hooks = (h, given)
         self._check(self.L.orc_test_set_hooks(self.h, C.byref(h) if any(a is not None for a in given.values()) else None))
 

@@ -1368,7 +1368,9 @@ static int step_all(orc_env* e, int policy, const float* actions, float* reward_
       float u[4];
       draw4(e->seed, e->cfg.arena_offset + i, (uint32_t)stamp, PURPOSE_CMD, u);
       int level = e->terrain_on ? e->terrain_idx[4 * i] : 0; /* zeros without a terrain (KAMMA.py:223) */
-      orc_level_command(level, e->cmd_fraction[i], stamp, normal_det(u[0], u[1]), (double)e->cfg.decimation * (double)e->cfg.sim_dt,
+      if (e->hooks.levels) level = e->hooks.levels[i];
+      const float z = e->hooks.level_z ? e->hooks.level_z[i] : normal_det(u[0], u[1]);
+      orc_level_command(level, e->cmd_fraction[i], stamp, z, (double)e->cfg.decimation * (double)e->cfg.sim_dt,
                         (double)e->cfg.episode_length_s, &e->commands[4 * i], &e->commands[4 * i + 2]);
     }
   }
@@ -1574,7 +1576,8 @@ int orc_episode_info(orc_env* e) {
   I[OIS_EI_GAMMA2] = acc[P_G2];   /* :487 */
   /* :488 torch.mean(terrain_levels.float()) over ALL arenas; zeros without a terrain (:223) */
   int64_t lsum = 0;
-  if (e->terrain_on) for (int i = 0; i < e->N; ++i) lsum += e->terrain_idx[4 * i];
+  if (e->hooks.levels) for (int i = 0; i < e->N; ++i) lsum += e->hooks.levels[i];
+  else if (e->terrain_on) for (int i = 0; i < e->N; ++i) lsum += e->terrain_idx[4 * i];
   I[OIS_EI_TERRAIN_LEVEL] = (float)lsum / (float)e->N;
   I[OIS_EI_STEP] = (float)smax;
   I[OIS_EI_SMOOTHNESS] = (acc[P_SM] / cntf) / L;

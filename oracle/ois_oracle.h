@@ -74,7 +74,8 @@ int orc_set_threads(orc_env* env, int threads);
 /* Fixture replay (tests/golden/refexec_cosim_*.npz: the reference's own statements run in lock-step with this env).
  * The reference draws from torch's generator and steps PhysX; to compare step by step the env takes those three
  * things from the caller: the uniform of the stochastic switch (KAMMA.py:633), the draws of reset_idx (order of
- * orc_reset_draws; slot 8 = the standard normal of GridSampling), and the simulator's outcome. Arrays stay the
+ * orc_reset_draws; slot 8 = the standard normal of GridSampling), the simulator's outcome, and — for the per-level command
+ * curriculum — the normal draw and the terrain level of every arena. Arrays stay the
  * caller's and are read at every orc_reset / orc_step until cleared (NULL). physics rows: COM position 3,
  * quaternion 4 (w,x,y,z), linear velocity 3, angular velocity 3 (world), joint velocities 4, base-link position 3
  * (written only). */
@@ -85,6 +86,8 @@ typedef struct {
   const float* reset_u;    /* [N, ORC_RESET_U_STRIDE] */
   const float* physics_in; /* [N, ORC_PHYSICS_STRIDE]: replaces the outcome of the substeps */
   float* physics_out;      /* [N, ORC_PHYSICS_STRIDE]: receives it (before is_done / reset) */
+  const float* level_z;    /* [N] the standard normal behind each arena's per-level command re-draw (KAMMA.py:539, :561, :566) */
+  const int32_t* levels;   /* [N] terrain level per arena for that re-draw (self.terrain_levels without a terrain attached) */
 } orc_test_hooks;
 int orc_test_set_hooks(orc_env* env, const orc_test_hooks* hooks);
 

@@ -82,7 +82,17 @@ PATCHED = {"KAMMA_medium+terminal1.5": ("KAMMA_medium", {"task/env/learn/termina
            "KAMMA+config": ("KAMMA", {"task/env/control/stiffness": 0.05, "task/env/control/actionScale": 2.0,
                                       "task/env/control/decimation": 5, "task/env/learn/episodeLength_s": 4.0,
                                       "task/env/clipObservations": 5.0,
-                                      "task/env/randomCommandVelocityRanges/linear_x": [0.0, 0.6]})}
+                                      "task/env/randomCommandVelocityRanges/linear_x": [0.0, 0.6]}),
+           # the per-terrain-level command curriculum (terrain.curriculum: reset_idx skips its re-draw :490, the tail of
+           # post_physics_step re-draws the command of EVERY arena after get_observations :719-725, `fraction` :498 is re-snapshot for
+           # all arenas by any reset). Arenas on levels 1, 3, 4 and — while their `fraction` keeps torch.normal's sigma positive,
+           # i.e. as long as only synchronous timeouts reset them — 0 and 2
+           "KAMMA+curriculum": ("KAMMA", {"task/env/terrain/curriculum": True}),
+           # the same with robots falling alone: ANY reset re-snapshots `fraction` of every arena (:498) from running sums that are
+           # negative, which the generators of levels 0 and 2 cannot take (torch.normal raises on sigma < 0): levels 1, 3, 4 only
+           "KAMMA+curriculum_falls": ("KAMMA", {"task/env/terrain/curriculum": True})}
+# terrain_levels of the runs' arenas (the reference's are zeros without a terrain)
+CURRICULUM_LEVELS = {"KAMMA+curriculum": [1, 3, 4, 1, 3, 0, 2, 1], "KAMMA+curriculum_falls": [1, 3, 4, 4, 1, 3]}
 
 
 def _patch(cfg, patches):
@@ -118,6 +128,9 @@ class Cosim:
         self.reset_u = np.zeros((n, RESET_U_STRIDE), np.float32)
         self.switch_u = np.zeros(n, np.float32)
         self.grid_seed = None
+        self.level_z = np.zeros(n, np.float32)
+        self.levels = np.array((CURRICULUM_LEVELS.get(run_name, [0]) * n)[:n], np.int32)
+        self.t_index = -1
         co = self
 
         class Glue(Ref):
@@ -154,7 +167,10 @@ class Cosim:
 
             def sample_velocity_command(self, env_id):
                 i = int(env_id)
-                if getattr(self, "evalsampling", False) or self.curriculum:
+                if getattr(self, "evalsampling", False):
+                    return super().sample_velocity_command(env_id)
+                if self.curriculum:         # KAMMA.py:533-567: torch.normal is the reference's own, on the seed its z was recorded from
+                    torch.manual_seed(co.level_seed(i))
                     return super().sample_velocity_command(env_id)
                 if self.randsampling:       # :571 removed; :573-575 run on the draw
                     co.ns["x_vel"] = rf(self.command_x_range[0], self.command_x_range[1], self._u6[i]).clone()
@@ -178,8 +194,19 @@ class Cosim:
         t.clip_obs = run["task"]["env"].get("clipObservations", np.inf)         # rl_task.py:96
         t.cleanup()                                                             # rl_task.py:118
         t.num_dof = 4                                                           # KAMMA.py:399 (removed: self._robots.num_dof)
+        if t.curriculum:
+            t.terrain_levels = torch.from_numpy(self.levels.astype(np.int64))   # KAMMA.py:223 has zeros: no terrain to take levels from
         self.task = t
         self.gravity = np.array([0.0, 0.0, -1.0], np.float32)
+
+    def level_seed(self, i):
+        return 9000 + (self.t_index + 1) * self.n + i
+
+    def draw_level_z(self):
+        """the standard normal behind each arena's torch.normal of this step's re-draw, by replaying its seed"""
+        for i in range(self.n):
+            torch.manual_seed(self.level_seed(i))
+            self.level_z[i] = torch.randn(1)[0]
 
     # -- data the removed statements would have delivered ---------------------------------------------------------
     def quat_apply_all(self, quat, vec):
@@ -209,7 +236,7 @@ class Cosim:
     def start(self, seed):
         self.draw_reset(-1)
         self.first_reset_u = self.reset_u.copy()
-        self.orc.set_hooks(reset_u=self.reset_u)
+        self.orc.set_hooks(reset_u=self.reset_u, **(dict(levels=self.levels) if self.task.curriculum else {}))
         self.orc.reset(seed)
         self.task.post_reset()
         return self.snapshot()
@@ -232,12 +259,21 @@ class Cosim:
                "ac_right": T.ac_right.clone(), "torques": T.torques.clone(), "wheel_torqs": T.wheel_torqs.clone(),
                "guiding": T.guiding_reward.clone()}
         self.draw_reset(t_index)
-        self.orc.set_hooks(switch_u=self.switch_u, reset_u=self.reset_u, physics_out=self.S)
+        self.t_index = t_index
+        lv = {}
+        if T.curriculum:
+            self.draw_level_z()
+            lv = dict(level_z=self.level_z, levels=self.levels)
+        self.orc.set_hooks(switch_u=self.switch_u, reset_u=self.reset_u, physics_out=self.S, **lv)
         self.orc.step(actions)
         T.post_physics_step()   # its refresh_*_state_tensors calls bind the simulator's outcome (Glue)
         out = self.snapshot()
         out.update({k: v.numpy() for k, v in pre.items()})
-        out.update(actions=actions.copy(), switch_u=self.switch_u.copy(), reset_u=self.reset_u.copy(), physics=self.S.copy())
+        used = self.reset_u.copy()
+        used[~out["reset"].astype(bool)] = 0.0   # only a resetting arena reads its draws: the others' are not stored
+        out.update(actions=actions.copy(), switch_u=self.switch_u.copy(), reset_u=used, physics=self.S[:, :17].copy())
+        if T.curriculum:
+            out.update(level_z=self.level_z.copy(), levels=self.levels.copy())
         # the projection's 3-term sum is order dependent (1 ulp); both sides continue from the oracle's value
         orc_vfwd = torch.from_numpy(self.orc.buffer(A.BUF_POSE)[:, 3].copy())
         assert torch.allclose(T.v_forward_projected, orc_vfwd, rtol=2e-6, atol=2e-7), (T.v_forward_projected, orc_vfwd)
@@ -285,6 +321,8 @@ RUNS = {  # variant -> (arenas, steps, {step: [(event, arena)]}); two synchronou
     "KA_DDPG_1D_eval": (3, 104, {30: [("fall", 2)]}),
     "KAMMA_medium+terminal1.5": (4, 104, {33: [("fall", 1)], 50: [("oob", 2)]}),
     "KAMMA+config": (6, 170, {33: [("fall", 1)], 50: [("oob", 2)]}),
+    "KAMMA+curriculum": (8, 120, {}),
+    "KAMMA+curriculum_falls": (6, 140, {20: [("fall", 2)], 21: [("fall", 2)], 60: [("oob", 4)]}),
 }
 # sim_steps where the gamma schedule is in the interior (the trajectories above start at 0: gamma 1 - 2e-4)
 START_SIM_STEPS = {"KAMMA+config": 250000, "KAMMA": 150000, "KAMMA_medium": 420000, "KAMMA_medium+terminal1.5": 100000, "KAMMA_g1d_g21": 250000, "KAMMA_curr1": 200000, "KAMMA_curr2": 300000,
@@ -296,7 +334,8 @@ def run_variant(variant, n, T, seed, events):
     from options_in_simulation_amd import _abi
     co = Cosim(variant, n, seed)
     first = co.start(seed)
-    check_step(co.orc, co.cfg, first, f"{variant} post_reset", first=True)
+    drawn = bool(co.task.curriculum)
+    check_step(co.orc, co.cfg, first, f"{variant} post_reset", first=True, drawn_commands=drawn)
     if variant in START_SIM_STEPS:   # a run that has been training for a while: same value on both sides
         co.task.sim_steps[:] = START_SIM_STEPS[variant]
         co.orc.buffer(_abi.BUF_COUNTERS)[:, 1] = START_SIM_STEPS[variant]
@@ -314,7 +353,7 @@ def run_variant(variant, n, T, seed, events):
             assert co.orc.rew[0] == 0.0 and variant == "KAMMA_g11_g21"
             co.raised_at = t
             break
-        check_step(co.orc, co.cfg, out, f"{variant} step {t}")
+        check_step(co.orc, co.cfg, out, f"{variant} step {t}", drawn_commands=drawn)
         steps.append(out)
     return co, first, steps
 

@@ -23,12 +23,18 @@ G = os.path.join(os.path.dirname(__file__), "golden")
 VARIANTS = ["KAMMA", "KAMMA_medium", "KAMMA_g11_g21", "KAMMA_g1d_g21", "KAMMA_curr1", "KAMMA_curr2", "KAMMA_eval", "KA_DDPG_4D",
             "KA_DDPG_2D", "KA_DDPG_1D", "KA_DDPG_2D_eval", "KA_DDPG_1D_eval"]
 # runs of an env file with TASK_CFG leaves changed (make_golden_cosim.PATCHED; the fixture stores the env file and the patches)
-RUN_NAMES = VARIANTS + ["KAMMA_medium+terminal1.5", "KAMMA+config"]
+RUN_NAMES = VARIANTS + ["KAMMA_medium+terminal1.5", "KAMMA+config", "KAMMA+curriculum", "KAMMA+curriculum_falls"]
 
 
 @pytest.fixture(scope="module")
 def fixture():
     return np.load(os.path.join(G, "refexec_cosim.npz"))
+
+
+def _physics_rows(a):
+    """the fixture stores the 17 columns orc_test_hooks.physics_in reads (COM position, quaternion, velocities, joint velocities);
+    the hook's rows are 20 wide (the last three, the base-link position, are only ever written)"""
+    return np.ascontiguousarray(np.pad(a, ((0, 0), (0, 20 - a.shape[1]))), np.float32)
 
 
 def _variant(fixture, v):
@@ -50,24 +56,44 @@ def test_oracle_follows_the_reference_statements_step_by_step(fixture, variant):
         node[keys[-1]] = value
     cfg = build_config(task_cfg, variant=str(d["env_file"]), num_envs=n, seed=seed)
     env = OracleEnv(cfg)
-    env.set_hooks(reset_u=np.ascontiguousarray(d["first__reset_u"]))
+    env.set_hooks(reset_u=np.ascontiguousarray(d["first__reset_u"]),
+                  **(dict(levels=np.ascontiguousarray(d["levels"][0])) if "levels" in d else {}))
     env.reset(seed)
     first = {k[len("first__"):]: d[k] for k in d if k.startswith("first__")}
     first["extras_keys"] = d["extras_keys"]
-    check_step(env, cfg, first, f"{variant} post_reset", first=True)
+    drawn = "levels" in d      # the per-level command curriculum: commands out of torch.normal every step
+    assert drawn == (cfg.cmd_sampler == _abi.CMD_LEVEL)
+    check_step(env, cfg, first, f"{variant} post_reset", first=True, drawn_commands=drawn)
     if int(d["start_sim_steps"]):
         env.buffer(_abi.BUF_COUNTERS)[:, 1] = int(d["start_sim_steps"])
     per_step = [k for k in d if not k.startswith("first__") and k not in ("extras_keys", "components_keys", "start_sim_steps",
                                                                           "reference_raised_zero_division_at", "env_file", "task_cfg_patches_json")]
     for t in range(T):
+        lv = dict(level_z=np.ascontiguousarray(d["level_z"][t]), levels=np.ascontiguousarray(d["levels"][t])) if drawn else {}
         env.set_hooks(switch_u=np.ascontiguousarray(d["switch_u"][t]), reset_u=np.ascontiguousarray(d["reset_u"][t]),
-                      physics_in=np.ascontiguousarray(d["physics"][t]))
+                      physics_in=_physics_rows(d["physics"][t]), **lv)
         env.step(d["actions"][t])
         out = {k: d[k][t] for k in per_step}
         out["extras_keys"], out["components_keys"] = d["extras_keys"], d["components_keys"]
-        check_step(env, cfg, out, f"{variant} step {t}")
+        check_step(env, cfg, out, f"{variant} step {t}", drawn_commands=drawn)
     resets = d["reset"].sum()
-    if variant != "KAMMA_g11_g21":
+    if variant == "KAMMA+curriculum":
+        c = d["commands"]
+        assert (np.diff(c[:, :, 0], axis=0) != 0).mean() > 0.5         # re-drawn for every arena after every step (:719-725)
+        lv = d["levels"][0]
+        assert (c[:, lv == 0, 0] == 0).all() and (c[:, lv == 0, 2] > 0).all()     # level 0 returns (0.0, max(x_vel, 0.0)): the swapped pair (:541)
+        assert (c[:, lv != 0, 2] == 0).all()
+        t_reset = int(np.argmax(d["reset"].any(axis=1)))
+        assert d["reset"][t_reset].all()                                # the synchronous timeout: `fraction` 0 for every arena afterwards
+        assert (d["fraction"][t_reset] == 0).all() and (d["fraction"][t_reset - 1] == 0).all()
+    elif variant == "KAMMA+curriculum_falls":
+        t = 20                                                         # arena 2 falls alone
+        assert d["reset"][t].sum() == 1 and d["reset"][t, 2] == 1
+        others = [i for i in range(n) if i != 2]
+        assert (d["fraction"][t - 1] == 0).all()                       # still the snapshot of post_reset
+        assert (d["fraction"][t, others] < 0).all() and d["fraction"][t, 2] == 0   # re-snapshot for EVERY arena (:498), after :485 zeroed arena 2
+        assert np.array_equal(d["fraction"][t + 2], d["fraction"][t + 1])          # and kept until the next reset_idx call
+    elif variant != "KAMMA_g11_g21":
         assert resets > 0 and d["timeout"].sum() > 0 and (d["reset"].astype(int) - d["timeout"]).sum() > 0  # timeouts and falls / bounds
     if "terminal1.5" in variant:
         # KAMMA.py:801 `terminalReward * reset_buf * ~timeout_buf` on int64: a fall or bound violation costs -1.5, a timeout -3.0

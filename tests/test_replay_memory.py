@@ -362,7 +362,7 @@ def test_ring_equals_the_memory_the_references_own_chain_filled():
     mem = None
     for t in range(T1):
         env.set_hooks(switch_u=np.ascontiguousarray(d["step__switch_u"][t]), reset_u=np.ascontiguousarray(d["step__reset_u"][t]),
-                      physics_in=np.ascontiguousarray(d["step__physics"][t]))
+                      physics_in=np.ascontiguousarray(np.pad(d["step__physics"][t], ((0, 0), (0, 20 - d["step__physics"][t].shape[1]))), np.float32))
         env.step(d["step__actions"][t])
         if t == 0:
             mem = env.attach_replay(M)             # the reference records nothing for the wrapper's own first step
