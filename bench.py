@@ -52,7 +52,7 @@ HBM_PEAK_GBS = 8000.0             # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
 FP32_VECTOR_PEAK_TFLOPS = 157.3   # MI355X_MICROARCH.md
 FLOP_PER_ENV_STEP = 20 * 1440.0   # fallback only: the general packed kernel (profiles/*_isa_census.json keys the launched one)
 ARENAS_PER_GPU = 65536
-ROUND = "r3"                      # the profiles/<round>_* artefacts this checkout quotes
+ROUND = "r4"                      # the profiles/<round>_* artefacts this checkout quotes
 KERNEL_SOURCES = ("ois_kernels.hip", "ois_device.h", "ois_physics.h", "ois_physics_pk.h", "Makefile")
 
 

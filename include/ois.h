@@ -19,8 +19,11 @@
  *                                  (no reference counterpart; BASELINE.json configs 1/2)
  *   ois_buffer                  <- obs_buf / rew_buf / reset_buf / timeout_buf /
  *                                  wheel_torqs / commands / base_* tensors
+ *   ois_outputs_copy            <- the wrapper's per-step clones of obs / reward / terminated + zeros(truncated)
  *   ois_episode_info            <- extras["episode"] filled in reset_idx (KAMMA.py:480-488)
  *   ois_env0_diag               <- task.observed_components (KAMMA.py:840-867)
+ *   ois_logs_enable / _fetch    <- both of the above as the trainer reads them: after EVERY step, on the
+ *                                  host (src/my_trainers/base_KA_DDPG.py:184-212, 259-262)
  *   ois_stats_fetch             <- finished-episode return tracking of the agent base
  *                                  class (src/my_agents/base.py:305-341)
  *   ois_replay_*                <- FIFOMemory.add_samples as fed by record_transition
@@ -64,7 +67,9 @@ extern "C" {
  *    OIS_CMD_LEVEL, OIS_BUF_CMD_FRACTION, ois_profile_* */
 /* 5: ois_kernel_info; state blobs carry the flat-plane flag (version 4 blobs do not load); ois_config validation
  *    also refuses an unstable joint resistance and a negative depenetration velocity */
-#define OIS_ABI_VERSION 5
+/* 6: ois_logs_enable / ois_logs_fetch (the step's logs through pinned host memory); ois_episode_info and ois_stats_fetch are
+ *    one launch each; the workspace grew by one 256-byte slot (state blobs of version 5 do not load) */
+#define OIS_ABI_VERSION 6
 
 /* error codes */
 #define OIS_OK 0
@@ -288,6 +293,13 @@ int ois_profile_end(ois_env* env, double* kernel_ms_total, long long* launches);
 /* Device pointer + size of one buffer (aliases the workspace). */
 int ois_buffer(ois_env* env, int id, void** ptr_device, size_t* bytes);
 
+/* The step's return values as arrays of the CALLER's: the wrapper between the task and the trainer returns fresh tensors from
+ * every step() (clones of obs_buf / rew_buf / reset_buf and a new all-false `truncated`; skrl's wrapper, third-party; call site
+ * src/my_trainers/base_KA_DDPG.py:182). One launch: obs_out float [N,6], rew_out float [N], terminated_out / truncated_out
+ * uint8 [N] (truncated is filled with 0); any of them may be NULL. Device memory, obs_out 8-byte and rew_out 4-byte aligned. */
+int ois_outputs_copy(ois_env* env, float* obs_out, float* rew_out, uint8_t* terminated_out, uint8_t* truncated_out,
+                     void* stream);
+
 /* Per-arena domain randomisation (BASELINE.json config 4): mu ~ U(mu_lo, mu_hi) and plane
  * slope drawn from `slopes[n_slopes]` (tan of the incline about a random heading), both
  * from Philox keyed by the global arena id. n_slopes == 0 keeps the flat plane. */
@@ -306,8 +318,8 @@ int ois_kernel_info(const ois_env* env, char* out, size_t cap);
  * defines it and never calls it; here for scripts that do. */
 int ois_push_robots(ois_env* env, void* stream);
 
-/* Reduce the per-wave partial sums of the most recent reset event into OIS_BUF_EPISODE_INFO
- * (device). No host synchronisation. */
+/* Reduce the per-group records of the most recent reset event into OIS_BUF_EPISODE_INFO
+ * (device; one launch). No host synchronisation. */
 int ois_episode_info(ois_env* env, void* stream);
 
 /* Copy finished-episode statistics to the host (synchronises `stream`). */
@@ -315,6 +327,26 @@ int ois_stats_fetch(ois_env* env, ois_stats* host_out, int reset_after, void* st
 
 /* Copy the arena-0 diagnostics block to the host (synchronises `stream`). */
 int ois_env0_diag(ois_env* env, float* host_out /*[OIS_ENV0_DIAG_LEN]*/, void* stream);
+
+/* ---- the step's logs on the host, for a caller that reads them after every step ----
+ * The reference's trainer reads, after EVERY env.step(), the 26 values of task.observed_components and every value of
+ * infos["episode"] with .item() (src/my_trainers/base_KA_DDPG.py:184-212, 259-262; producers KAMMA.py:480-488, 840-867).
+ * Through ois_episode_info + a copy that is two launches, a blocking transfer and a drained stream per step.
+ *   ois_logs_fetch: the [OIS_EPISODE_INFO_LEN] extras["episode"] values (slots: ois_episode_info_slot) and the
+ *     [OIS_ENV0_DIAG_LEN] arena-0 diagnostics of the CURRENT state into two host arrays. If no finalisation of the current
+ *     state is in flight it enqueues one on `stream` (ONE launch, which also fills OIS_BUF_EPISODE_INFO); then it waits
+ *     until the kernel has published the values: the kernel writes them into a pinned, host-coherent block the library
+ *     allocates on first use (hipHostMalloc, 4 KiB — host memory; device memory stays the caller's) and stores a sequence
+ *     number behind them, the host polls that word. No stream synchronisation, no copy engine; work enqueued behind the
+ *     finalisation keeps running while the host reads.
+ *   ois_logs_enable(env, 1): from now on ois_step enqueues that finalisation itself, right behind the step kernel on the
+ *     step's stream, so that the fetch finds the values already published (or on their way) instead of starting work on a
+ *     drained stream. 0 switches it off again (a loop that does not read logs saves the launch). Not done for a step under
+ *     HIP-graph capture (the sequence number advances per call, not per replay); ois_rollout never does it.
+ * The fetch must be given the stream the finalisation was (or is to be) enqueued on. OIS_ESTATE under stream capture. */
+int ois_logs_enable(ois_env* env, int on);
+int ois_logs_fetch(ois_env* env, float* episode_info_host /*[OIS_EPISODE_INFO_LEN]*/,
+                   float* env0_diag_host /*[OIS_ENV0_DIAG_LEN]*/, void* stream);
 
 /* ---- device-resident FIFO transition memory written by the step kernel ----
  * Semantics of the train scripts' FIFOMemory (train_kaddpg_4d_nofifo_random_RLIL.py:105-206:

@@ -1,7 +1,7 @@
 """ctypes mirror of include/ois.h (struct layout, enums). Pure data, no library load."""
 import ctypes as C
 
-ABI_VERSION = 5
+ABI_VERSION = 6
 
 OK, EINVAL, ENOMEM, EHIP, ESTATE = 0, -1, -2, -3, -4
 

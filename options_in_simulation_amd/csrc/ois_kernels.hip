@@ -738,113 +738,165 @@ __global__ void randomize_params_kernel(DevConsts K, DevBuffers B, int N, float 
 }
 
 // extras["episode"] (KAMMA.py:480-488): deterministic two-level sum of the per-group records of
-// the most recent reset event (docs/SPEC.md §2.10). Level 1: one block per chunk of kChunkGroups
+// the most recent reset event (docs/SPEC.md §2.10). Level 1: one wave per chunk of kChunkGroups
 // consecutive groups sums, in group order, the records carrying the chunk's newest stamp;
-// level 2: one block sums, in chunk order, the partials of the chunks whose newest stamp is the
-// global newest. (A single block walking all groups took 0.66 ms at 65 536 arenas and 7.6 ms at
-// 524 288 — more than the policy step it reports on; the reference reads infos every step.)
+// level 2: the chunk partials whose newest stamp is the global newest are summed in chunk order.
+// ONE launch since round 4: the wave that takes the last ticket does level 2 (the others have published
+// their partial before they took theirs), and every load of a level is in flight before the first add —
+// the sums are chains of 64 dependent adds, not of 64 dependent round trips to L2 (two launches of
+// serial loads took 18.2 us at 65 536 arenas, the reference trainer reads infos after every step).
+// The same wave then leaves the 32 values + the 32 env-0 diagnostics of the step in the caller's pinned
+// host block and publishes a sequence number behind them (ois_logs_*): the host waits on a word in its
+// own memory instead of draining the stream through a blocking copy.
 constexpr int kChunkGroups = 64;  // 1024 arenas per chunk
 
-__global__ __launch_bounds__(64) void episode_partial_kernel(DevBuffers B, int ngroups, int N, float* __restrict__ part,
-                                                            int* __restrict__ cmax, long long* __restrict__ lvl) {
-  const int c = blockIdx.x, t = threadIdx.x;
-  const int g0 = c * kChunkGroups, g1 = min(g0 + kChunkGroups, ngroups);
-  int m = -1;
-  for (int g = g0; g < g1; ++g) m = max(m, B.stamps[g]);
-  if (t < 32) {
-    const bool is_gamma = t == 24 || t == 25;  // gamma1 / gamma2: identical in every record of one event
-    float a = is_gamma ? -__builtin_inff() : 0.0f;
-#pragma unroll 8
-    for (int g = g0; g < g1; ++g) {  // unconditional loads, predicated accumulate: the loads pipeline
-      const bool match = B.stamps[g] == m;
-      const float x = B.partials[(size_t)g * 32 + t];
-      const float y = is_gamma ? fmaxf(a, x) : a + x;
-      a = match ? y : a;
-    }
-    part[(size_t)c * 32 + t] = a;
-  }
-  if (t == 0) cmax[c] = m;
-  // :488 torch.mean(terrain_levels.float()) over ALL arenas: integer sums, exact and order-free
-  long long ls = 0;
-  if (B.ter.on) {
-    const int a1 = min(g1 * kGroup, N);
-    for (int i = g0 * kGroup + t; i < a1; i += 64) ls += B.terrain_idx[i].x;
-  }
-  for (int w = 32; w >= 1; w >>= 1) ls += __shfl_xor(ls, w, 64);
-  if (t == 0) lvl[c] = ls;
+OIS_DEV int wave_max_i(int x) {
+#pragma unroll
+  for (int w = 32; w >= 1; w >>= 1) { const int y = __shfl_xor(x, w, 64); x = y > x ? y : x; }
+  return x;
+}
+// the lane that took the last of `n` tickets sees every other block's global writes (release before the
+// ticket, acquire after it); the counter is back at 0 when the kernel ends
+OIS_DEV bool last_block(unsigned* ticket, unsigned n, int t) {
+  __threadfence();
+  unsigned k = 0;
+  if (t == 0) k = atomicAdd(ticket, 1u);
+  k = __shfl(k, 0, 64);
+  if (k != n - 1) return false;
+  __threadfence();
+  if (t == 0) *ticket = 0u;
+  return true;
 }
 
-__global__ __launch_bounds__(64) void episode_final_kernel(DevConsts K, DevBuffers B, int nchunks, int N,
-                                                          const float* __restrict__ part, const int* __restrict__ cmax,
-                                                          const long long* __restrict__ lvl) {
-  __shared__ float acc[32];
-  __shared__ long long tot_s;
-  const int t = threadIdx.x;
-  int smax = -1;
-  for (int c = 0; c < nchunks; ++c) smax = max(smax, cmax[c]);
-  if (t < 32) {
-    const bool is_gamma = t == 24 || t == 25;
-    float a = is_gamma ? -__builtin_inff() : 0.0f;
-#pragma unroll 8
-    for (int c = 0; c < nchunks; ++c) {
-      const bool match = cmax[c] == smax;
-      const float x = part[(size_t)c * 32 + t];
-      const float y = is_gamma ? fmaxf(a, x) : a + x;
-      a = match ? y : a;
-    }
-    acc[t] = a;
+// one level of the record sum for slot `t` (0..31; called by all 64 lanes, the upper half shadows the lower): the
+// up-to-64 rows at `rows`, stride 32 floats, of which row i counts when lane i's `stamp` equals `newest`; slots
+// 24 / 25 (gamma1 / gamma2, identical in every record of one event) are max-reduced. All loads first, then the adds
+// in row order.
+OIS_DEV float record_level(const float* __restrict__ rows, int nrows, int stamp, int newest, int t, float a) {
+  const bool is_gamma = t == 24 || t == 25;
+  float x[kChunkGroups];
+#pragma unroll
+  for (int i = 0; i < kChunkGroups; ++i) x[i] = rows[(size_t)(i < nrows ? i : nrows - 1) * 32 + t];
+#pragma unroll
+  for (int i = 0; i < kChunkGroups; ++i) {
+    const bool match = __builtin_amdgcn_readlane(stamp, i) == newest;  // lanes >= nrows carry INT_MIN: never the newest
+    const float y = is_gamma ? fmaxf(a, x[i]) : a + x[i];
+    a = match ? y : a;
   }
-  if (t == 32) {
-    long long tot = 0;
-    for (int c = 0; c < nchunks; ++c) tot += lvl[c];
-    tot_s = tot;
+  return a;
+}
+
+struct LogsArgs {
+  float* part;          // [nchunks][32] level-1 partials
+  int* cmax;            // [nchunks] newest stamp of each chunk
+  long long* lvl;       // [nchunks] terrain-level sums
+  unsigned* ticket;
+  float* host_block;    // pinned host memory: [32] episode info | [32] env-0 diagnostics | uint64 sequence; or null
+  unsigned long long seq;
+};
+
+__global__ __launch_bounds__(64) void logs_kernel(DevConsts K, DevBuffers B, int ngroups, int nchunks, int N, LogsArgs A) {
+  const int c = blockIdx.x, t = threadIdx.x;
+  constexpr int kNever = -2147483647 - 1;
+  {
+    const int g0 = c * kChunkGroups, n = min(kChunkGroups, ngroups - g0);
+    const int st = t < n ? B.stamps[g0 + t] : kNever;
+    const int m = wave_max_i(st);
+    const bool is_gamma = (t & 31) == 24 || (t & 31) == 25;
+    const float p = record_level(B.partials + (size_t)g0 * 32, n, st, m, t & 31, is_gamma ? -__builtin_inff() : 0.0f);
+    if (t < 32) A.part[(size_t)c * 32 + t] = p;
+    if (t == 0) A.cmax[c] = m;
+    // :488 torch.mean(terrain_levels.float()) over ALL arenas: integer sums, exact and order-free
+    if (B.ter.on) {
+      long long ls = 0;
+      const int a1 = min((g0 + n) * kGroup, N);
+      for (int i = g0 * kGroup + t; i < a1; i += 64) ls += B.terrain_idx[i].x;
+      for (int w = 32; w >= 1; w >>= 1) ls += __shfl_xor(ls, w, 64);
+      if (t == 0) A.lvl[c] = ls;
+    }
   }
-  __syncthreads();
-  if (t == 0) {
-    float* I = B.episode_info;
-    for (int k = 0; k < OIS_EPISODE_INFO_LEN; ++k) I[k] = 0.0f;
-    const float cnt = acc[0], L = K.episode_length_s;
-    I[OIS_EI_COUNT] = cnt;
-    for (int k = 0; k < 4; ++k) {
-      I[OIS_EI_R1 + k] = (acc[4 + k] / cnt) / L;              // :482-484
-      I[OIS_EI_SPARSE + k] = (acc[8 + k] / cnt) / L;
-      I[OIS_EI_R1_OVER_FINAL + k] = (acc[12 + k] / cnt) / L;
-    }
-    for (int k = 0; k < 3; ++k) {
-      I[OIS_EI_SPARSE_OVER_FINAL + k] = (acc[16 + k] / cnt) / L;
-      I[OIS_EI_SMOOTHNESS + k] = (acc[20 + k] / cnt) / L;
-    }
-    I[OIS_EI_GAMMA1] = acc[24];       // :486
-    I[OIS_EI_GAMMA2] = acc[25];       // :487
-    I[OIS_EI_TERRAIN_LEVEL] = (float)tot_s / (float)N;  // :488 (zeros without a terrain, :223)
-    I[OIS_EI_STEP] = (float)smax;
+  if (!last_block(A.ticket, (unsigned)nchunks, t)) return;
+  int sm = kNever;
+  for (int i = t; i < nchunks; i += 64) sm = max(sm, A.cmax[i]);
+  const int smax = wave_max_i(sm);
+  const bool is_gamma = (t & 31) == 24 || (t & 31) == 25;
+  float a = is_gamma ? -__builtin_inff() : 0.0f;
+  for (int c0 = 0; c0 < nchunks; c0 += kChunkGroups) {
+    const int n = min(kChunkGroups, nchunks - c0);
+    const int cm = t < n ? A.cmax[c0 + t] : kNever;
+    a = record_level(A.part + (size_t)c0 * 32, n, cm, smax, t & 31, a);
+  }
+  long long tot = 0;
+  if (B.ter.on) {
+    for (int i = t; i < nchunks; i += 64) tot += A.lvl[i];
+    for (int w = 32; w >= 1; w >>= 1) tot += __shfl_xor(tot, w, 64);
+  }
+  // record slot -> extras slot (include/ois.h ois_episode_info_slot): lane s < 32 produces I[s]
+  const int s = t & 31;
+  const int src = (s >= OIS_EI_R1 && s <= OIS_EI_OBSERVED_OVER_FINAL) ? s + 3
+                : (s >= OIS_EI_SMOOTHNESS && s <= OIS_EI_DESIRED_VELOCITY) ? s
+                : s == OIS_EI_GAMMA1 ? 24 : s == OIS_EI_GAMMA2 ? 25 : 0;
+  const float cnt = __shfl(a, 0, 64), v = __shfl(a, src, 64);
+  float out = 0.0f;
+  if ((s >= OIS_EI_R1 && s <= OIS_EI_OBSERVED_OVER_FINAL) || (s >= OIS_EI_SMOOTHNESS && s <= OIS_EI_DESIRED_VELOCITY))
+    out = (v / cnt) / K.episode_length_s;                            // :482-484
+  else if (s == OIS_EI_COUNT || s == OIS_EI_GAMMA1 || s == OIS_EI_GAMMA2) out = v;  // :486, :487
+  else if (s == OIS_EI_TERRAIN_LEVEL) out = (float)tot / (float)N;   // :488 (zeros without a terrain, :223)
+  else if (s == OIS_EI_STEP) out = (float)smax;
+  if (t < 32) B.episode_info[t] = out;
+  else out = B.env0_diag[t - 32];
+  if (A.host_block != nullptr) {
+    A.host_block[t] = out;
+    __threadfence_system();
+    if (t == 0) __hip_atomic_store(reinterpret_cast<unsigned long long*>(A.host_block + 64), A.seq, __ATOMIC_RELEASE,
+                                   __HIP_MEMORY_SCOPE_SYSTEM);
   }
 }
 
 // finished-episode statistics: the same two-level order over the per-group accumulators, in double
-// (sum of squared returns of millions of episodes: the variance is a difference of two large numbers)
-__global__ __launch_bounds__(64) void stats_partial_kernel(DevBuffers B, int ngroups, double* __restrict__ part8, int reset_after) {
-  const int c = blockIdx.x, t = threadIdx.x;
-  if (t >= 8) return;
-  const int g0 = c * kChunkGroups, g1 = min(g0 + kChunkGroups, ngroups);
-  double a = t < 4 ? 0.0 : -__builtin_inf();
-  for (int g = g0; g < g1; ++g) {
-    double* p = B.stat_acc + (size_t)g * 8 + t;
-    const double x = *p;
-    a = t < 4 ? a + x : fmax(a, x);
-    if (reset_after) *p = t < 4 ? 0.0 : -__builtin_inf();
+// (sum of squared returns of millions of episodes: the variance is a difference of two large numbers); one launch,
+// the loads of a level in flight together (the two launches of serial loads took 20 + 15 us)
+OIS_DEV double stat_level(const double* __restrict__ rows, int nrows, int t, double a) {
+  double x[kChunkGroups];
+#pragma unroll
+  for (int i = 0; i < kChunkGroups; ++i) x[i] = rows[(size_t)(i < nrows ? i : nrows - 1) * 8 + t];
+#pragma unroll
+  for (int i = 0; i < kChunkGroups; ++i) {
+    const double y = t < 4 ? a + x[i] : fmax(a, x[i]);
+    a = i < nrows ? y : a;
   }
-  part8[(size_t)c * 8 + t] = a;
+  return a;
 }
-__global__ __launch_bounds__(64) void stats_final_kernel(int nchunks, const double* __restrict__ part8, double* __restrict__ out8) {
-  const int t = threadIdx.x;
+__global__ __launch_bounds__(64) void stats_kernel(DevBuffers B, int ngroups, int nchunks, double* __restrict__ part8,
+                                                  double* __restrict__ out8, unsigned* ticket, int reset_after) {
+  const int c = blockIdx.x, t = threadIdx.x;
+  const int g0 = c * kChunkGroups, n = min(kChunkGroups, ngroups - g0);
+  if (t < 8) {
+    double* rows = B.stat_acc + (size_t)g0 * 8;
+    part8[(size_t)c * 8 + t] = stat_level(rows, n, t, t < 4 ? 0.0 : -__builtin_inf());
+    if (reset_after) for (int i = 0; i < n; ++i) rows[(size_t)i * 8 + t] = t < 4 ? 0.0 : -__builtin_inf();
+  }
+  if (!last_block(ticket, (unsigned)nchunks, t)) return;
   if (t >= 8) return;
   double a = t < 4 ? 0.0 : -__builtin_inf();
-  for (int c = 0; c < nchunks; ++c) {
-    const double x = part8[(size_t)c * 8 + t];
-    a = t < 4 ? a + x : fmax(a, x);
-  }
+  for (int c0 = 0; c0 < nchunks; c0 += kChunkGroups) a = stat_level(part8 + (size_t)c0 * 8, min(kChunkGroups, nchunks - c0), t, a);
   out8[t] = a;
+}
+
+// VecEnv.step hands the caller FRESH tensors (the wrappers clone obs / rew / reset_buf and make a new all-false
+// `truncated`): the four copies in one launch instead of three device-to-device copies and a fill
+__global__ __launch_bounds__(256) void outputs_kernel(DevBuffers B, int N, float* __restrict__ obs, float* __restrict__ rew,
+                                                      uint8_t* __restrict__ term, uint8_t* __restrict__ trunc) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= N) return;
+  if (obs) {
+    const float2* s = reinterpret_cast<const float2*>(B.obs + (size_t)i * 6);
+    float2* o = reinterpret_cast<float2*>(obs + (size_t)i * 6);
+    o[0] = s[0]; o[1] = s[1]; o[2] = s[2];
+  }
+  if (rew) rew[i] = B.rew[i];
+  if (term) term[i] = B.done[i];
+  if (trunc) trunc[i] = 0;
 }
 
 // ------------------------------------------------------------------ replay sampling ---
@@ -908,7 +960,7 @@ struct DeviceGuard {
 struct Layout {
   size_t off[OIS_BUF_COUNT_];
   size_t bytes[OIS_BUF_COUNT_];
-  size_t partials, stamps, stat_acc, stat_out, red_part, red_cmax, red_lvl, red_part8, reset_stamp, total;
+  size_t partials, stamps, stat_acc, stat_out, red_part, red_cmax, red_lvl, red_part8, red_ticket, reset_stamp, total;
   int nwaves, nchunks;
 };
 
@@ -942,6 +994,7 @@ Layout make_layout(int N) {
   L.red_cmax = o; o = align256(o + (size_t)L.nchunks * sizeof(int));
   L.red_lvl = o; o = align256(o + (size_t)L.nchunks * sizeof(long long));
   L.red_part8 = o; o = align256(o + (size_t)L.nchunks * 8 * sizeof(double));
+  L.red_ticket = o; o = align256(o + 2 * sizeof(unsigned));  // last-block tickets of logs_kernel / stats_kernel (0 between launches)
   L.reset_stamp = o; o = align256(o + 2 * sizeof(int32_t));
   L.total = o;
   return L;
@@ -1062,6 +1115,11 @@ struct ois_env {
   size_t prof_used;                 // pairs handed to launches since ois_profile_begin
   double prof_ms;                   // kernel time of pairs already folded in (pool wrap-around)
   long long prof_launches;
+  // ois_logs_*: the step's 32 + 32 log values in pinned host memory, published by logs_kernel
+  float* logs_host;              // hipHostMalloc'ed (coherent): [32] episode info | [32] env-0 diagnostics | uint64 sequence
+  unsigned long long logs_seq;   // sequence number of the last logs_kernel enqueued with the host block
+  bool logs_on;                  // ois_step enqueues logs_kernel behind the step kernel
+  bool logs_current;             // the last enqueued logs_kernel saw the current state
 };
 
 // Lanes per arena of the step kernel.
@@ -1229,6 +1287,7 @@ int ois_create(const ois_config* cfg, int device, void* workspace_device, size_t
   std::memset(&B.ter, 0, sizeof B.ter);
   e->rp_mem = nullptr; e->rp_head = 0; e->rp_filled = false;
   e->prof_on = false; e->prof_used = 0; e->prof_ms = 0.0; e->prof_launches = 0;
+  e->logs_host = nullptr; e->logs_seq = 0; e->logs_on = false; e->logs_current = false;
   // default per-arena parameters: mu = cfg.friction, flat plane n = +z
   hipError_t he = hipMemsetAsync(e->ws, 0, L.total, nullptr);
   if (he == hipSuccess) {
@@ -1248,6 +1307,7 @@ int ois_create(const ois_config* cfg, int device, void* workspace_device, size_t
 void ois_destroy(ois_env* env) {
   if (!env) return;
   for (hipEvent_t ev : env->prof_ev) (void)hipEventDestroy(ev);
+  if (env->logs_host) (void)hipHostFree(env->logs_host);
   delete env;
 }
 
@@ -1284,6 +1344,7 @@ int ois_reset(ois_env* e, uint64_t seed, void* stream) {
   HIP_TRY(hipGetLastError());
   e->reset_done = true;
   e->steps_done = 0.0;
+  e->logs_current = false;
   return OIS_OK;
 }
 
@@ -1365,6 +1426,7 @@ static int launch_kernel(ois_env* e, int k, int policy, const float* actions, fl
 #undef OIS_LAUNCH
   HIP_TRY(hipGetLastError());
   e->steps_done += (double)e->N * (double)k;
+  e->logs_current = false;
   if (e->B.rp_size > 0) {  // the kernel wrote rows rp_head .. rp_head + k - 1 (mod size)
     if (e->rp_head + k >= e->B.rp_size) e->rp_filled = true;
     e->rp_head = (e->rp_head + k) % e->B.rp_size;
@@ -1396,13 +1458,46 @@ static int launch_steps(ois_env* e, int k, int policy, const float* actions, flo
   return OIS_OK;
 }
 
+// extras["episode"] + the env-0 diagnostics of the current state: one launch (logs_kernel); with a host block attached
+// the kernel also publishes them there under the next sequence number
+static int enqueue_logs(ois_env* e, void* stream) {
+  LogsArgs A;
+  A.part = (float*)(e->ws + e->L.red_part);
+  A.cmax = (int*)(e->ws + e->L.red_cmax);
+  A.lvl = (long long*)(e->ws + e->L.red_lvl);
+  A.ticket = (unsigned*)(e->ws + e->L.red_ticket);
+  A.host_block = e->logs_host;
+  A.seq = e->logs_host ? e->logs_seq + 1 : 0;
+  hipLaunchKernelGGL(logs_kernel, dim3(e->L.nchunks), dim3(64), 0, (hipStream_t)stream, e->K, e->B, e->L.nwaves, e->L.nchunks, e->N, A);
+  HIP_TRY(hipGetLastError());
+  if (e->logs_host) { e->logs_seq += 1; e->logs_current = true; }
+  return OIS_OK;
+}
+static int logs_alloc(ois_env* e) {
+  void* p = nullptr;
+  // coherent (fine-grained) pinned memory: a store of the kernel is visible to the host when it lands, not at the kernel's end
+  HIP_TRY(hipHostMalloc(&p, 4096, hipHostMallocCoherent | hipHostMallocMapped | hipHostMallocPortable));
+  std::memset(p, 0, 4096);
+  e->logs_host = (float*)p;
+  e->logs_seq = 0;
+  e->logs_current = false;
+  return OIS_OK;
+}
+
 int ois_step(ois_env* e, const float* actions_device, void* stream) {
   if (!e) return fail(OIS_EINVAL, "null env");
   if (!actions_device) return fail(OIS_EINVAL, "null actions");
   if (!e->reset_done) return fail(OIS_ESTATE, "ois_step called before ois_reset");
   if (((uintptr_t)actions_device & (uintptr_t)(4 * e->K.action_dim - 1)) != 0)
     return fail(OIS_EINVAL, "actions must be aligned to action_dim * 4 bytes (one vector load per arena)");
-  return launch_steps(e, 1, OIS_POLICY_EXTERNAL, actions_device, nullptr, stream);
+  int rc = launch_steps(e, 1, OIS_POLICY_EXTERNAL, actions_device, nullptr, stream);
+  if (rc != OIS_OK || !e->logs_on) return rc;
+  // a caller that reads the step's logs after every step (ois_logs_enable): finalise and publish them right behind the
+  // step kernel, so that the read finds them in host memory instead of enqueueing work into a drained stream
+  hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+  if (hipStreamIsCapturing((hipStream_t)stream, &cap) == hipSuccess && cap != hipStreamCaptureStatusNone) return OIS_OK;  // the sequence number is per call, not per replay
+  OIS_ON_DEVICE(e->device);
+  return enqueue_logs(e, stream);
 }
 
 int ois_rollout(ois_env* e, int k, int policy, const float* actions_device, float* reward_sum_device, void* stream) {
@@ -1463,6 +1558,7 @@ int ois_terrain_attach(ois_env* e, const ois_terrain* t, const int16_t* heights_
   OIS_ON_DEVICE(e->device);
   hipStream_t s = (hipStream_t)stream;
   const size_t f4 = (size_t)e->N * 4 * sizeof(float);
+  e->logs_current = false;  // the terrain-level mean of extras["episode"] changes with the attachment
   if (!t) {  // detach: back to the per-arena plane, origins and indices cleared
     std::memset(&e->B.ter, 0, sizeof e->B.ter);
     e->K.cmd_sampler = e->cfg.cmd_sampler;
@@ -1545,18 +1641,68 @@ int ois_push_robots(ois_env* e, void* stream) {
   return OIS_OK;
 }
 
+int ois_outputs_copy(ois_env* e, float* obs_out, float* rew_out, uint8_t* terminated_out, uint8_t* truncated_out, void* stream) {
+  if (!e) return fail(OIS_EINVAL, "null env");
+  if (!e->reset_done) return fail(OIS_ESTATE, "ois_outputs_copy called before ois_reset");
+  if (((uintptr_t)obs_out & 7u) != 0 || ((uintptr_t)rew_out & 3u) != 0) return fail(OIS_EINVAL, "obs_out must be 8-byte, rew_out 4-byte aligned");
+  OIS_ON_DEVICE(e->device);
+  hipLaunchKernelGGL(outputs_kernel, dim3((e->N + 255) / 256), dim3(256), 0, (hipStream_t)stream, e->B, e->N, obs_out, rew_out,
+                     terminated_out, truncated_out);
+  HIP_TRY(hipGetLastError());
+  return OIS_OK;
+}
+
 int ois_episode_info(ois_env* e, void* stream) {
   if (!e) return fail(OIS_EINVAL, "null env");
   if (!e->reset_done) return fail(OIS_ESTATE, "ois_episode_info called before ois_reset");
   OIS_ON_DEVICE(e->device);
-  float* part = (float*)(e->ws + e->L.red_part);
-  int* cmax = (int*)(e->ws + e->L.red_cmax);
-  long long* lvl = (long long*)(e->ws + e->L.red_lvl);
-  hipLaunchKernelGGL(episode_partial_kernel, dim3(e->L.nchunks), dim3(64), 0, (hipStream_t)stream, e->B, e->L.nwaves, e->N, part,
-                     cmax, lvl);
-  hipLaunchKernelGGL(episode_final_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, e->K, e->B, e->L.nchunks, e->N, part, cmax,
-                     lvl);
-  HIP_TRY(hipGetLastError());
+  return enqueue_logs(e, stream);
+}
+
+int ois_logs_enable(ois_env* e, int on) {
+  if (!e) return fail(OIS_EINVAL, "null env");
+  if (on && !e->logs_host) {
+    OIS_ON_DEVICE(e->device);
+    int rc = logs_alloc(e);
+    if (rc != OIS_OK) return rc;
+  }
+  e->logs_on = on != 0;
+  return OIS_OK;
+}
+
+int ois_logs_fetch(ois_env* e, float* episode_info_out, float* env0_diag_out, void* stream) {
+  if (!e || !episode_info_out || !env0_diag_out) return fail(OIS_EINVAL, "null argument");
+  if (!e->reset_done) return fail(OIS_ESTATE, "ois_logs_fetch called before ois_reset");
+  OIS_ON_DEVICE(e->device);
+  if (!e->logs_host) {
+    int rc = logs_alloc(e);
+    if (rc != OIS_OK) return rc;
+  }
+  if (!e->logs_current) {
+    hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+    if (hipStreamIsCapturing((hipStream_t)stream, &cap) == hipSuccess && cap != hipStreamCaptureStatusNone)
+      return fail(OIS_ESTATE, "ois_logs_fetch waits on the host: not for use under stream capture");
+    int rc = enqueue_logs(e, stream);
+    if (rc != OIS_OK) return rc;
+  }
+  // the kernel stores the 64 values, then (system-scope release) the sequence number, into coherent pinned memory:
+  // the host polls its own memory. hipStreamQuery is only the way out if the kernel never gets there.
+  const unsigned long long want = e->logs_seq;
+  const unsigned long long* flag = reinterpret_cast<const unsigned long long*>(e->logs_host + 2 * OIS_EPISODE_INFO_LEN);
+  for (unsigned spins = 1;; ++spins) {
+    if (__atomic_load_n(flag, __ATOMIC_ACQUIRE) == want) break;
+    if ((spins & 0x3fffu) == 0u) {
+      const hipError_t q = hipStreamQuery((hipStream_t)stream);
+      if (q == hipSuccess) {
+        if (__atomic_load_n(flag, __ATOMIC_ACQUIRE) == want) break;
+        return fail(OIS_EHIP, "the stream drained without the logs kernel publishing (was ois_step given another stream?)");
+      }
+      if (q != hipErrorNotReady) HIP_TRY(q);
+    }
+    __builtin_ia32_pause();
+  }
+  std::memcpy(episode_info_out, e->logs_host, OIS_EPISODE_INFO_LEN * sizeof(float));
+  std::memcpy(env0_diag_out, e->logs_host + OIS_EPISODE_INFO_LEN, OIS_ENV0_DIAG_LEN * sizeof(float));
   return OIS_OK;
 }
 
@@ -1566,8 +1712,8 @@ int ois_stats_fetch(ois_env* e, ois_stats* out, int reset_after, void* stream) {
   OIS_ON_DEVICE(e->device);
   double* d = (double*)(e->ws + e->L.stat_out);
   double* part8 = (double*)(e->ws + e->L.red_part8);
-  hipLaunchKernelGGL(stats_partial_kernel, dim3(e->L.nchunks), dim3(64), 0, (hipStream_t)stream, e->B, e->L.nwaves, part8, reset_after);
-  hipLaunchKernelGGL(stats_final_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, e->L.nchunks, part8, d);
+  hipLaunchKernelGGL(stats_kernel, dim3(e->L.nchunks), dim3(64), 0, (hipStream_t)stream, e->B, e->L.nwaves, e->L.nchunks, part8, d,
+                     (unsigned*)(e->ws + e->L.red_ticket) + 1, reset_after);
   HIP_TRY(hipGetLastError());
   double h[8];
   HIP_TRY(hipMemcpyAsync(h, d, sizeof h, hipMemcpyDeviceToHost, (hipStream_t)stream));
@@ -1715,6 +1861,7 @@ int ois_load_state(ois_env* e, const void* host_blob, size_t bytes, void* stream
   HIP_TRY(hipMemcpyAsync(e->ws, (const char*)host_blob + sizeof h, e->L.total, hipMemcpyHostToDevice, (hipStream_t)stream));
   HIP_TRY(hipStreamSynchronize((hipStream_t)stream));
   e->reset_done = h.reset_done != 0;
+  e->logs_current = false;
   e->seed = h.seed;
   e->K.seed_lo = (uint32_t)(h.seed & 0xffffffffu);
   e->K.seed_hi = (uint32_t)(h.seed >> 32);

@@ -19,6 +19,7 @@ Three layers, bottom up:
 from __future__ import annotations
 
 import ctypes as C
+import math
 from typing import Any, Dict, Optional, Tuple
 
 import numpy as np
@@ -81,6 +82,10 @@ class NativeEnv:
             self._views[bid] = t.view(-1, cols) if cols else t
         self.policy_steps = 0
         self.epoch = 0  # bumped by everything that changes device state: the key of the host-side log caches
+        # the step's logs on the host (ois_logs_*): two 32-float arrays the library fills from its pinned block
+        self._logs_eager = False   # ois_step publishes the logs itself (a loop was seen reading them)
+        self._logs_unread = 0      # steps in a row whose logs nobody read while that was on
+        self._logs_next = None     # (array[64], its 32 0-dim tensor views) made ahead of the wait, see _logs_prepare
 
     # ---- lifetime ----
     def close(self):
@@ -123,10 +128,17 @@ class NativeEnv:
 
     def step(self, actions: torch.Tensor):
         a = self._check_actions(actions)
+        if self._logs_eager:  # a loop that stopped reading the logs stops paying for their launch
+            self._logs_unread = self._logs_unread + 1 if getattr(self, "_logs_epoch", -1) != self.epoch else 0
+            if self._logs_unread > 16:
+                _native.check(self.L.ois_logs_enable(self.h, 0))
+                self._logs_eager = False
         _native.check(self.L.ois_step(self.h, C.c_void_p(a.data_ptr()), _stream_ptr(self.device)))
         self.policy_steps += 1
         self.epoch += 1
         self._last_actions = a  # keep alive until the stream has consumed it
+        if self._logs_eager:
+            self._logs_prepare()  # while the GPU works: everything of the read that does not need the values
 
     def rollout(self, k: int, policy: int, actions: Optional[torch.Tensor] = None,
                 reward_sum: Optional[torch.Tensor] = None):
@@ -174,6 +186,18 @@ class NativeEnv:
         _native.check(self.L.ois_push_robots(self.h, _stream_ptr(self.device)))
         self.epoch += 1
 
+    def outputs_copy(self) -> Tuple[torch.Tensor, torch.Tensor, torch.Tensor, torch.Tensor]:
+        """fresh (obs [N,6], reward [N,1], terminated [N,1] bool, truncated [N,1] bool = False) of the current step in ONE
+        launch (ois_outputs_copy): what the wrapper's three clones and its zeros_like cost four launches for"""
+        N, dev = self.N, self.device
+        obs = torch.empty((N, 6), dtype=torch.float32, device=dev)
+        rew = torch.empty((N, 1), dtype=torch.float32, device=dev)
+        term = torch.empty((N, 1), dtype=torch.bool, device=dev)
+        trunc = torch.empty((N, 1), dtype=torch.bool, device=dev)
+        _native.check(self.L.ois_outputs_copy(self.h, obs.data_ptr(), rew.data_ptr(), term.data_ptr(), trunc.data_ptr(),
+                                              _stream_ptr(dev)))
+        return obs, rew, term, trunc
+
     def episode_info(self) -> torch.Tensor:
         """launch the finalisation kernel; returns the device vector (no host sync)."""
         _native.check(self.L.ois_episode_info(self.h, _stream_ptr(self.device)))
@@ -184,28 +208,42 @@ class NativeEnv:
         _native.check(self.L.ois_stats_fetch(self.h, C.byref(st), int(reset_after), _stream_ptr(self.device)))
         return st
 
-    def env0_diag(self) -> np.ndarray:
-        if getattr(self, "_logs_epoch", -1) == self.epoch:
-            return self._logs[1]
+    def env0_diag(self, direct: bool = False) -> np.ndarray:
+        """the 32-float arena-0 block of the current step; ``direct``: through ois_env0_diag (a blocking copy of the
+        device buffer) instead of the published host block"""
+        if not direct:
+            return self.host_logs()[1]
         out = np.zeros(_abi.ENV0_DIAG_LEN, np.float32)
         _native.check(self.L.ois_env0_diag(self.h, out.ctypes.data_as(C.POINTER(C.c_float)), _stream_ptr(self.device)))
         return out
 
-    def host_logs(self) -> Tuple[np.ndarray, np.ndarray]:
-        """(episode_info[32], env0_diag[32]) of the current step on the host with ONE
-        synchronisation: the finalisation kernels are enqueued, then the two adjacent 128-byte
-        blocks come over in a single copy. A trainer that reads both every step
-        (base_KA_DDPG.py:184-262) otherwise drains the pipeline twice."""
+    def host_logs(self) -> Tuple[np.ndarray, np.ndarray, Tuple[torch.Tensor, ...]]:
+        """(episode_info[32], env0_diag[32], the first as 32 0-dim CPU tensors) of the current step on the host (ois_logs_fetch): ONE finalisation
+        launch whose last wave writes both blocks into the library's pinned host memory and publishes a sequence
+        number behind them; the host polls that word — no blocking copy, no drained stream. The first read switches
+        on ``ois_logs_enable``: from then on ``step()`` enqueues the finalisation itself, so a trainer that reads
+        both every step (base_KA_DDPG.py:184-262) finds them published when it asks."""
         if getattr(self, "_logs_epoch", -1) != self.epoch:
-            info, diag = self.episode_info(), self._views[_abi.BUF_ENV0_DIAG]
-            base = self.workspace.data_ptr()
-            lo = min(info.data_ptr(), diag.data_ptr()) - base
-            hi = max(info.data_ptr(), diag.data_ptr()) - base + 4 * _abi.ENV0_DIAG_LEN
-            blob = self.workspace[lo:hi].cpu().numpy().view(np.float32)
-            i0, d0 = (info.data_ptr() - base - lo) // 4, (diag.data_ptr() - base - lo) // 4
-            self._logs = (blob[i0:i0 + _abi.EPISODE_INFO_LEN].copy(), blob[d0:d0 + _abi.ENV0_DIAG_LEN].copy())
+            if not self._logs_eager:
+                _native.check(self.L.ois_logs_enable(self.h, 1))
+                self._logs_eager, self._logs_unread = True, 0
+            if self._logs_next is None:
+                self._logs_prepare()
+            blob, tensors, p0, p1 = self._logs_next
+            self._logs_next = None
+            _native.check(self.L.ois_logs_fetch(self.h, p0, p1, _stream_ptr(self.device)))
+            self._logs = (blob[:_abi.EPISODE_INFO_LEN], blob[_abi.EPISODE_INFO_LEN:], tensors)
             self._logs_epoch = self.epoch
         return self._logs
+
+    def _logs_prepare(self):
+        """A fresh 64-float array for the next fetch (the dict of an earlier step may still be alive: its values keep
+        their own memory) and the 32 0-dim CPU tensors that view its first half — 19 us of tensor construction that a
+        reading loop would otherwise pay between the GPU finishing the step and the next policy launch. Made right
+        after the step was enqueued, i.e. while the host has nothing to do but wait."""
+        blob = np.empty(_abi.EPISODE_INFO_LEN + _abi.ENV0_DIAG_LEN, np.float32)
+        tensors = torch.from_numpy(blob[:_abi.EPISODE_INFO_LEN]).unbind(0)
+        self._logs_next = (blob, tensors, C.c_void_p(blob.ctypes.data), C.c_void_p(blob.ctypes.data + 4 * _abi.EPISODE_INFO_LEN))
 
     def attach_terrain(self, terrain, levels_types: np.ndarray, curriculum: Optional[bool] = None,
                        threshold_low: float = 0.3, threshold_high: float = 5.0, max_level: Optional[int] = None):
@@ -328,12 +366,10 @@ class _LazyEpisodeInfo(dict):
                                "dict(infos['episode']), before the next step() / reset() / load_state()")
         self._done = True
         if self._on_host:
-            vec = torch.from_numpy(self._native.host_logs()[0])  # shares its one copy with observed_components
-            self._native._infos_read = True  # tells observed_components to fetch both blocks at once from now on
+            vec = self._native.host_logs()[2]  # 32 0-dim CPU tensors viewing the fetched block; one fetch with observed_components
         else:
             vec = self._native.episode_info().clone()
-        for key, value in _abi.episode_info_items(vec, self._eval, self._single_gamma):
-            dict.__setitem__(self, key, value)
+        dict.update(self, _abi.episode_info_items(vec, self._eval, self._single_gamma))
 
     def __getitem__(self, k): self._materialize(); return dict.__getitem__(self, k)
     def __iter__(self): self._materialize(); return dict.__iter__(self)
@@ -354,30 +390,44 @@ class _SimConfigLike:
         self.task_config = config["task"] if "task" in config else config
 
 
+_OC_DIRECT = (("env0_desired_v", 0), ("env0_current_v", 1), ("env0_desired_omega", 2), ("env0_current_omega", 3),
+              ("env0_v_delta", 4), ("env0_omega_delta", 5), ("env0_linear_acc", 6), ("env0_angular_acc", 7),
+              ("env0_torque_apl_fl", 9), ("env0_torque_apl_rl", 10), ("env0_torque_apl_fr", 11), ("env0_torque_apl_rr", 12),
+              ("env0_exp_left", 13), ("env0_exp_right", 14), ("env0_policy_torque_fl", 15), ("env0_policy_torque_rl", 16),
+              ("env0_policy_torque_fr", 17), ("env0_policy_torque_rr", 18))
+_OC_PERC = (("env0_perc_r1", 20), ("env0_perc_r2", 21), ("env0_perc_r3", 22), ("env0_perc_dense", 23),
+            ("env0_perc_sparse", 24), ("env0_perc_observed", 25))
+_OC_ORDER = ("env0_desired_v", "env0_current_v", "env0_desired_omega", "env0_current_omega", "env0_v_delta", "env0_omega_delta",
+             "env0_linear_acc", "env0_angular_acc", "env0_episode_count", "env0_torque_apl_fl", "env0_torque_apl_rl",
+             "env0_torque_apl_fr", "env0_torque_apl_rr", "env0_exp_left", "env0_exp_right", "env0_policy_torque_fl",
+             "env0_policy_torque_rl", "env0_policy_torque_fr", "env0_policy_torque_rr", "env0_perc_r1", "env0_perc_r2",
+             "env0_perc_r3", "env0_perc_dense", "env0_perc_sparse", "env0_perc_observed", "env0_perc_guiding")
+
+
+def _div(num: float, den: float) -> float:
+    """IEEE double division as numpy does it (the reference divides Python floats and would raise on 0.0,
+    KAMMA_g11_g21.py:859; its sibling guards the denominator instead, KAMMA_g1d_g21.py:838-842)"""
+    if den != 0.0:
+        return num / den
+    if num != num or num == 0.0:
+        return float("nan")
+    return float("inf") if (num > 0.0) == (math.copysign(1.0, den) > 0.0) else float("-inf")
+
+
 def observed_components_from_diag(d) -> Dict[str, float]:
     """``task.observed_components`` (KAMMA.py:840-867) from the 32-float env-0 block the step kernel leaves
     (include/ois.h OIS_BUF_ENV0_DIAG): the reference builds the percentages from ``.item()`` values, i.e. in
-    Python doubles, left to right: ``100.0 * (1 - gamma2) * comp / rew``."""
-    d = np.asarray(d, np.float64)
-    g2, rew = d[19], d[27]
-
-    def perc(x, scale):
-        with np.errstate(divide="ignore", invalid="ignore"):
-            return float(np.float64(100.0) * scale * x / rew)
-    out = {
-        "env0_desired_v": d[0], "env0_current_v": d[1], "env0_desired_omega": d[2],
-        "env0_current_omega": d[3], "env0_v_delta": d[4], "env0_omega_delta": d[5],
-        "env0_linear_acc": d[6], "env0_angular_acc": d[7], "env0_episode_count": int(d[8]),
-        "env0_torque_apl_fl": d[9], "env0_torque_apl_rl": d[10], "env0_torque_apl_fr": d[11],
-        "env0_torque_apl_rr": d[12], "env0_exp_left": d[13], "env0_exp_right": d[14],
-        "env0_policy_torque_fl": d[15], "env0_policy_torque_rl": d[16],
-        "env0_policy_torque_fr": d[17], "env0_policy_torque_rr": d[18],
-        "env0_perc_r1": perc(d[20], 1 - g2), "env0_perc_r2": perc(d[21], 1 - g2),
-        "env0_perc_r3": perc(d[22], 1 - g2), "env0_perc_dense": perc(d[23], 1 - g2),
-        "env0_perc_sparse": perc(d[24], 1 - g2), "env0_perc_observed": perc(d[25], 1 - g2),
-        "env0_perc_guiding": perc(d[26], g2),
-    }
-    return {k: (v if isinstance(v, int) else float(v)) for k, v in out.items()}
+    Python doubles, left to right: ``100.0 * (1 - gamma2) * comp / rew``. Plain Python floats throughout: this
+    runs after every step of a trainer that logs (base_KA_DDPG.py:184-212)."""
+    v = d.tolist() if hasattr(d, "tolist") else [float(x) for x in d]  # float32 -> the same value as a double
+    g2, rew = v[19], v[27]
+    one_minus = 1 - g2
+    out = {k: v[i] for k, i in _OC_DIRECT}
+    out["env0_episode_count"] = int(v[8])
+    for k, i in _OC_PERC:
+        out[k] = _div(100.0 * one_minus * v[i], rew)
+    out["env0_perc_guiding"] = _div(100.0 * g2 * v[26], rew)
+    return {k: out[k] for k in _OC_ORDER}
 
 
 class TorqueDistributionTask:
@@ -475,10 +525,7 @@ class TorqueDistributionTask:
     @property
     def observed_components(self) -> Dict[str, float]:
         if self._diag_step != self.native.epoch:
-            # a loop that also reads infos["episode"] every step gets both blocks in one copy
-            combined = getattr(self.native, "_infos_read", False) and self.infos_on_host
-            d = (self.native.host_logs()[1] if combined else self.native.env0_diag()).astype(np.float64)
-            self._diag_cache = observed_components_from_diag(d)
+            self._diag_cache = observed_components_from_diag(self.native.host_logs()[1])  # one fetch with infos["episode"]
             self._diag_step = self.native.epoch
         return self._diag_cache
 
@@ -608,10 +655,11 @@ class VecEnv:
         if self._reset_once:
             raise RuntimeError("step() called before reset()")
         obs, rew, done, extras = self.task.step(actions)
-        self._obs = self._out(obs)
-        terminated = self._out(done).view(-1, 1)
-        truncated = self._truncated if not self.copy_outputs else torch.zeros_like(terminated)
-        return self._obs, self._out(rew).view(-1, 1), terminated, truncated, dict(extras)
+        if self.copy_outputs:  # fresh tensors, as the wrapper's clones are; one launch
+            self._obs, rew, terminated, truncated = self.task.native.outputs_copy()
+            return self._obs, rew, terminated, truncated, dict(extras)
+        self._obs = obs
+        return obs, rew.view(-1, 1), done.view(-1, 1), self._truncated, dict(extras)
 
     def render(self, *_, **__):
         return None

@@ -82,6 +82,24 @@ int main(void) {
   }
   if (st.episodes != (double)N || st.steps != (double)N * 105.0) { fprintf(stderr, "stats: %f episodes, %f steps\n", st.episodes, st.steps); return 1; }
 
+  /* the step's logs through pinned host memory (ois_logs_*): unpublished state -> the fetch enqueues the finalisation
+   * itself; with ois_logs_enable the step does, and the fetch only waits for the sequence number */
+  float ei[OIS_EPISODE_INFO_LEN], diag[OIS_ENV0_DIAG_LEN], ei_dev[OIS_EPISODE_INFO_LEN], diag_dev[OIS_ENV0_DIAG_LEN];
+  CHECK(ois_logs_fetch(env, ei, diag, stream));
+  if (ei[OIS_EI_COUNT] != 0.0f + N || ei[OIS_EI_STEP] != 99.0f) { fprintf(stderr, "logs: count %f at step %f\n", ei[OIS_EI_COUNT], ei[OIS_EI_STEP]); return 1; }
+  CHECK(ois_logs_enable(env, 1));
+  for (int t = 0; t < 3; ++t) {
+    CHECK(ois_step(env, d_act, stream));
+    CHECK(ois_logs_fetch(env, ei, diag, stream));
+    CHECK(ois_env0_diag(env, diag_dev, stream));
+    CHECK(ois_buffer(env, OIS_BUF_EPISODE_INFO, &p, &n));
+    HIP(hipMemcpy(ei_dev, p, sizeof ei_dev, hipMemcpyDeviceToHost));
+    if (memcmp(ei, ei_dev, sizeof ei) != 0 || memcmp(diag, diag_dev, sizeof diag) != 0) { fprintf(stderr, "published logs differ from the device buffers at step %d\n", t); return 1; }
+    if (diag[8] != 2.0f) { fprintf(stderr, "env-0 episode count %f\n", diag[8]); return 1; }
+  }
+  CHECK(ois_logs_enable(env, 0));
+  if (ois_logs_fetch(env, NULL, diag, stream) != OIS_EINVAL) { fprintf(stderr, "null logs output not refused\n"); return 1; }
+
   size_t sb = ois_state_bytes(env);
   void* blob = malloc(sb);
   CHECK(ois_save_state(env, blob, sb, stream));
@@ -89,7 +107,7 @@ int main(void) {
   CHECK(ois_load_state(env, blob, sb, stream));
   CHECK(ois_buffer(env, OIS_BUF_COUNTERS, &p, &n));
   HIP(hipMemcpy(h_cnt, p, n, hipMemcpyDeviceToHost));
-  if (h_cnt[1] != 105) { fprintf(stderr, "state not restored\n"); return 1; }
+  if (h_cnt[1] != 108) { fprintf(stderr, "state not restored\n"); return 1; }
 
   if (ois_rollout(env, 0, OIS_POLICY_ZERO, NULL, NULL, stream) != OIS_EINVAL) { fprintf(stderr, "k = 0 not refused\n"); return 1; }
   ois_destroy(env);

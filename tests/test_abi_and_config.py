@@ -209,7 +209,7 @@ def test_algorithmic_flop_count_is_the_one_bench_quotes():
     assert len(rows) == len(spec_flops.SUBSTEP) and all(int(a) * int(b) == int(c) for a, b, c in rows)
     # the executed figure is keyed on the launched instantiation and quoted only on this checkout's kernel sources
     flop, valu, prov = bench.executed_flop_per_env_step("step_kernel<1,1,4,1>", 20)
-    # profiles/r3_isa_census.json is regenerated (tools/isa_census.py --json, no GPU needed) whenever the kernel sources change
+    # profiles/r4_isa_census.json is regenerated (tools/isa_census.py --json, no GPU needed) whenever the kernel sources change
     assert prov["status"].startswith("quoted"), prov
     assert valu == 20 * 595 and 0.8 < flop / bench.algorithmic_flop_per_env_step() < 1.0
     flop2, _, prov2 = bench.executed_flop_per_env_step("step_kernel<9,9,9,9>", 20)
@@ -226,7 +226,7 @@ def test_census_ids_are_the_ids_ois_kernel_info_reports():
     assert isa_census.kernel_id("_ZN12_GLOBAL__N_111step_kernelILi2ELb1ELi4ELb0ELb1EEEvN3ois9DevConstsE") == "step_kernel<2,1,4,0>+fold"
     assert isa_census.kernel_id("_ZN12_GLOBAL__N_114step_kernel_w2ILb1ELi4ELb1ELb0EEEvN3ois9DevConstsE") == "step_kernel_w2<1,4,1>"
     assert isa_census.kernel_id("_ZN12_GLOBAL__N_119step_kernel_terrainILb1ELi4ELb0EEEvN3ois9DevConstsE") == "step_kernel_terrain<1,4>"
-    d = json.load(open(os.path.join(ROOT, "profiles", "r3_isa_census.json")))["kernels"]
+    d = json.load(open(os.path.join(ROOT, "profiles", "r4_isa_census.json")))["kernels"]
     for kid in ("step_kernel<1,1,4,1>", "step_kernel<1,1,4,0>", "step_kernel<2,1,4,1>", "step_kernel_w2<1,4,1>", "step_kernel_terrain<1,4>",
                 "step_kernel<1,1,4,1>+fold"):
         assert kid in d and d[kid]["scratch_bytes"] <= (256 if "w2" in kid else 64), kid

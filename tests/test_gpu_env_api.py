@@ -365,8 +365,9 @@ def test_example_loop_runs(tmp_path):
 
 
 def test_combined_host_logs_equal_the_separate_reads():
-    """task.observed_components and infos['episode'] share one device-to-host copy once a loop
-    reads both (NativeEnv.host_logs): same values as the two separate entry points"""
+    """task.observed_components and infos['episode'] come out of ONE published host block (NativeEnv.host_logs ->
+    ois_logs_fetch; from the first read on the step publishes it itself): same values as the two separate entry
+    points ois_episode_info + ois_env0_diag on the device buffers"""
     from options_in_simulation_amd import VecEnv
     env = VecEnv(num_envs=300, device="cuda:0", variant="KAMMA_eval", seed=9)
     env.reset()
@@ -378,15 +379,26 @@ def test_combined_host_logs_equal_the_separate_reads():
         ep = {k: float(v) for k, v in infos["episode"].items()}
         n = env.task.native
         direct_info = n.episode_info().cpu().numpy()
-        n._logs_step = -1                                # force the plain ois_env0_diag path
-        direct_diag = n.env0_diag()
+        direct_diag = n.env0_diag(direct=True)           # the plain ois_env0_diag copy of the device buffer
+        assert np.array_equal(n.host_logs()[1], direct_diag, equal_nan=True)
+        assert np.array_equal(n.host_logs()[0], direct_info, equal_nan=True)
         assert oc["env0_desired_v"] == float(direct_diag[0]) and oc["env0_episode_count"] == int(direct_diag[8])
         assert oc["env0_torque_apl_rr"] == float(direct_diag[12])
         for slot, key in _abi.EPISODE_INFO_KEYS.items():
             a, b = ep[key], float(direct_info[slot])
             assert a == b or (np.isnan(a) and np.isnan(b)), key
         assert all(v.device.type == "cpu" for v in infos["episode"].values())
-    assert getattr(env.task.native, "_infos_read", False)
+    n = env.task.native
+    assert n._logs_eager                                 # the loop read its logs: ois_step publishes them itself
+    for _ in range(18):                                  # ... and stops paying for that once nobody reads them
+        env.step(torch.rand((300, 4), device="cuda"))
+    assert not n._logs_eager
+    _, _, _, _, infos = env.step(torch.rand((300, 4), device="cuda"))
+    ep = {k: float(v) for k, v in infos["episode"].items()}
+    direct_info = n.episode_info().cpu().numpy()
+    for slot, key in _abi.EPISODE_INFO_KEYS.items():
+        assert ep[key] == float(direct_info[slot]) or (np.isnan(ep[key]) and np.isnan(direct_info[slot])), key
+    assert n._logs_eager
     env.close()
 
 

@@ -107,6 +107,48 @@ def test_eval_variants_zero_old_torques_of_every_arena_on_any_reset(variant, N):
     assert np.array_equal(rs.cpu().numpy(), ro)
 
 
+@pytest.mark.parametrize("N", [1, 1000, 66000, 140000])
+def test_one_launch_logging_reductions_against_the_oracle(N):
+    """extras["episode"] and the finished-episode statistics are one launch each since round 4 (logs_kernel / stats_kernel:
+    the wave with the last ticket does level 2). Same two-level order as the oracle, bit for bit: 1 chunk, 1 ragged chunk,
+    65 chunks (a second level-2 batch of one), 137 chunks (three batches); after post_reset (every group carries stamp 0),
+    after single falls (one group, one chunk), after two falls in different chunks of one step, and with short episodes after
+    the synchronous timeout. The block ois_logs_fetch publishes in pinned host memory == the device buffers == the oracle."""
+    cfg, dev, orc = make_pair(variant="KAMMA_medium", num_envs=N, seed=31, max_episode_length=6)  # timeout when episode_buf reaches 5
+    dev.reset(31); orc.reset(31)
+    rng = np.random.default_rng(8)
+    up = np.array([0.0, 1.0, 0.0, 0.0], np.float32)
+    falls = {1: [N // 2], 2: [0, N - 1], 3: [min(N - 1, 1024 * 64 + 5)]}
+
+    def check(where):
+        ei, diag = dev.host_logs()[:2]
+        np.testing.assert_array_equal(ei, orc.episode_info(), err_msg=where)
+        np.testing.assert_array_equal(ei, dev.buffer(_abi.BUF_EPISODE_INFO).cpu().numpy(), err_msg=where)
+        np.testing.assert_array_equal(diag, dev.buffer(_abi.BUF_ENV0_DIAG).cpu().numpy(), err_msg=where)
+        np.testing.assert_array_equal(diag, orc.buffer(_abi.BUF_ENV0_DIAG), err_msg=where)
+        np.testing.assert_array_equal(dev.episode_info().cpu().numpy(), ei, err_msg=where)  # ois_episode_info: the same kernel
+
+    check("post_reset")
+    assert dev.host_logs()[0][_abi.EI_COUNT] == N
+    for t in range(9):
+        for i in falls.get(t, ()):
+            orc.buffer(_abi.BUF_QUAT)[i] = up
+            dev.buffer(_abi.BUF_QUAT)[i] = torch.from_numpy(up).cuda()
+        a = rng.uniform(0, 1, size=(N, 4)).astype(np.float32)
+        dev.step(torch.from_numpy(a).cuda()); orc.step(a)
+        check(f"step {t}")
+        if t in falls:
+            assert dev.host_logs()[0][_abi.EI_COUNT] == len(set(falls[t]))
+        if t == 4 and N >= 1000:  # the synchronous timeout of everyone who did not fall on the way: every chunk carries the newest stamp
+            fallen = {i for ids in falls.values() for i in ids}
+            assert dev.host_logs()[0][_abi.EI_COUNT] == N - len(fallen) and dev.host_logs()[0][_abi.EI_STEP] == 5
+    for reset_after in (0, 1, 0):
+        sd, so = dev.stats(bool(reset_after)), orc.stats(bool(reset_after))
+        for f in ("episodes", "return_sum", "return_sqsum", "return_min", "return_max", "length_sum", "steps"):
+            assert getattr(sd, f) == getattr(so, f), (f, reset_after)
+    assert sd.episodes == 0
+
+
 def test_long_rollout_with_resets_and_extras():
     """250 steps: two timeouts (99-step episodes), extras['episode'] and episode statistics."""
     N = 333

@@ -24,4 +24,12 @@ def timeit(name, fn, n=50):
 
 timeit("ois_episode_info", lambda: env.episode_info())
 timeit("ois_stats_fetch", lambda: env.stats())
-timeit("ois_env0_diag", lambda: env.env0_diag())
+timeit("ois_env0_diag (blocking copy)", lambda: env.env0_diag(direct=True))
+
+
+def logs():
+    env.epoch += 1  # a new state as far as the host cache is concerned: every call fetches
+    env.host_logs()
+
+
+timeit("ois_logs_fetch (finalise + publish + wait, nothing else in flight)", logs)

@@ -3,7 +3,7 @@
 assembly with the Makefile's flags and prints, per kernel, registers / scratch / LDS and the VALU
 instruction count of the substep loop (the depth-2 loop of the fused rollout) by class.
     python tools/isa_census.py [kernel-name-substring ...]      default: step_kernelILi1ELb1ELi4
-    python tools/isa_census.py --json profiles/r3_isa_census.json      every step-kernel instantiation, keyed by the id
+    python tools/isa_census.py --json profiles/r4_isa_census.json      every step-kernel instantiation, keyed by the id
                                                                          ois_kernel_info reports, with the kernel-source hash
 """
 import os, re, subprocess, sys, tempfile
