@@ -363,7 +363,20 @@ def main(argv=None):
     # one process per GPU. OIS_DIST_BACKEND=gloo + fewer GPUs than ranks is only for rehearsing the
     # multi-process path on a 1-GPU box (ranks then share device 0; RCCL refuses duplicate GPUs).
     backend = os.environ.get("OIS_DIST_BACKEND", "nccl")
-    dev_index = local_rank % max(1, torch.cuda.device_count()) if backend == "gloo" else local_rank
+    # preflight, before anything initialises a GPU or joins a group: a rank per GPU needs a GPU per rank. Counting devices does
+    # not touch them. On failure every rank prints the table it would have run (rank -> device -> arenas) and exits non-zero —
+    # an exit, never a re-exec, and before the rendezvous, so that no rank is left waiting in init_process_group
+    ndev = torch.cuda.device_count()
+    if backend != "gloo" and ndev < world:
+        from options_in_simulation_amd.dist import shard_range
+        rows = [{"rank": r, "device": r, "present": r < ndev, "arena_offset": shard_range(args.arenas * world, r, world)[0],
+                 "arenas": args.arenas} for r in range(world)]
+        if rank == 0:
+            print(json.dumps({"error": f"--gpus {world} needs {world} visible GPUs, torch.cuda.device_count() = {ndev} "
+                                       f"(HIP_VISIBLE_DEVICES / ROCR_VISIBLE_DEVICES = {os.environ.get('HIP_VISIBLE_DEVICES') or os.environ.get('ROCR_VISIBLE_DEVICES')}); "
+                                       "OIS_DIST_BACKEND=gloo rehearses the ranks on fewer GPUs", "rank_table": rows}), file=sys.stderr, flush=True)
+        raise SystemExit(3)
+    dev_index = local_rank % max(1, ndev) if backend == "gloo" else local_rank
     torch.cuda.set_device(dev_index)
     device = torch.device("cuda", dev_index)
     comm_device = torch.device("cpu") if backend == "gloo" else device
@@ -428,7 +441,19 @@ def main(argv=None):
         fixed = [torch.rand((n_shard, cfg.action_dim), device=device, generator=torch.Generator(device).manual_seed(1 + i))
                  for i in range(shards)]
         streams = [torch.cuda.Stream(device) for _ in range(shards)] if shards > 1 else [None]
+        # reset, parameter draws and the fixed actions above were enqueued on the current stream; the shards' own streams do
+        # not order against it
+        for st in streams:
+            if st is not None:
+                st.wait_stream(torch.cuda.current_stream(device))
         return envs, obs_l, fixed, streams
+
+    def shard_stats(e, st, reset_after=True):
+        """ois_stats_fetch of a shard ON the stream its steps run on (the fetch synchronises that stream)"""
+        if st is None:
+            return e.stats(reset_after=reset_after)
+        with torch.cuda.stream(st):
+            return e.stats(reset_after=reset_after)
 
     # What a cold process gives, and the steady state before the contract's W warm-up steps. A SCRATCH set of environments of
     # the same configuration first does exactly the contract's W + K steps, timed (`cold_start`: clocks, hipBLASLt's kernel
@@ -458,9 +483,9 @@ def main(argv=None):
 
     loop(envs, obs_l, fixed_l, streams, args.warmup)
     if dist_on:  # warm the collective too
-        gather_stats(env.stats(reset_after=True), device)
-        for e in envs[1:]:
-            e.stats(reset_after=True)
+        gather_stats(shard_stats(env, streams[0]), device)
+        for e, st in zip(envs[1:], streams[1:]):
+            shard_stats(e, st)
     barrier()
     for e in envs:
         e.profile_begin()  # start / stop events on every step kernel's own dispatch packet
@@ -469,7 +494,7 @@ def main(argv=None):
     for s in range(args.steps):
         loop(envs, obs_l, fixed_l, streams, 1)
         if (s + 1) % args.log_interval == 0 or s + 1 == args.steps:
-            sts = [e.stats(reset_after=True) for e in envs]      # one tiny D2H per logging interval (and shard)
+            sts = [shard_stats(e, st) for e, st in zip(envs, streams)]      # one tiny D2H per logging interval (and shard)
             st = sts[0] if shards == 1 else merge_raw(sts)
             gathered = gather_stats(st, device) if dist_on else [st]
     barrier()

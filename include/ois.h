@@ -201,7 +201,8 @@ enum ois_buffer_id {
   OIS_BUF_COUNTERS = 11,   /* int32 [N,4]  episode_buf, sim_steps, episode_count, reserved */
   OIS_BUF_SUMS_A = 12,     /* float [N,4]  episode sums r1, r2, r3, dense */
   OIS_BUF_SUMS_B = 13,     /* float [N,4]  episode sums sparse, guiding, observed, final */
-  OIS_BUF_PARAMS = 14,     /* float [N,4]  per-arena mu, plane normal xyz (domain randomisation) */
+  OIS_BUF_PARAMS = 14,     /* float [N,4]  per-arena mu, plane normal xyz (domain randomisation). mu may be written in place;
+                              after writing NORMALS into it yourself call ois_params_dirty (the flat-plane kernels ignore them) */
   OIS_BUF_EPISODE_INFO = 15, /* float [OIS_EPISODE_INFO_LEN] written by ois_episode_info */
   OIS_BUF_ENV0_DIAG = 16,  /* float [OIS_ENV0_DIAG_LEN] arena-0 diagnostics of the last step */
   OIS_BUF_SUMS_C = 17,     /* float [N,4]  eval sums smoothness, tracking error, desired v, prev-torque scratch */
@@ -306,11 +307,16 @@ int ois_outputs_copy(ois_env* env, float* obs_out, float* rew_out, uint8_t* term
 int ois_randomize_params(ois_env* env, float mu_lo, float mu_hi, const float* slopes_host,
                          int n_slopes, void* stream);
 
+/* The caller wrote plane normals into OIS_BUF_PARAMS itself (its own domain randomisation): the environment leaves the
+ * flat-plane kernels, which take n = (0, 0, 1) without reading it (ois_kernel_info: plane=flat), for the general ones — until
+ * the next ois_randomize_params without slopes or ois_load_state of a flat blob. Friction (column 0) needs no such call. */
+int ois_params_dirty(ois_env* env);
+
 /* Which step-kernel instantiation ois_step / ois_rollout launch for this environment right now (measurement aid:
  * bench.py keys its per-kernel figures on it), e.g. "step_kernel<1,1,4,1> lanes_per_arena=1 packed iterations=4(unrolled)
  * plane=flat" (the template arguments: lanes per arena, packed, unrolled iterations, flat). plane=flat: no ois_randomize_params slopes since ois_create (or a blob saved so) and no terrain — the
  * kernel then takes the plane normal as (0, 0, 1) and does not read it from OIS_BUF_PARAMS; a caller that writes
- * normals into that buffer itself must go through ois_randomize_params, or set OIS_FLAT=0. */
+ * normals into that buffer itself says so with ois_params_dirty (or sets OIS_FLAT=0). */
 int ois_kernel_info(const ois_env* env, char* out, size_t cap);
 
 /* push_robots (KAMMA.py:729-733): the world linear velocity x, y of EVERY arena is replaced by U(-1, 1)

@@ -55,24 +55,30 @@ EPISODE_INFO_ZERO_KEYS = (
 )
 
 
-# the KA-DDPG files keep ONE assist factor and log it under one key (KA_DDPG_4D.py:487; 1D / 2D and their eval twins alike)
+# the KA-DDPG files keep ONE assist factor and log it under one key (KA_DDPG_4D.py:484; 1D / 2D and their eval twins alike)
 EPISODE_INFO_SINGLE_GAMMA_KEY = "gamma assist"
+
+
+def episode_info_layout(eval_keys: bool, single_gamma: bool):
+    """[(key, slot)] of extras["episode"] in the ORDER the reference's dict has (KAMMA.py:204-221, 470-488): the declared
+    episode sums (the four `... reward/Final reward` keys are declared and never written: slot 31, always 0; the eval
+    files declare three more, KAMMA_eval.py:224-226), then the four ratio keys reset_idx adds under new names, the assist
+    factor(s), terrain_level. One key set per variant: `vecenv` and the multi-rank merge of `dist` both build from this."""
+    out = [(EPISODE_INFO_KEYS[s], s) for s in range(1, 12)]
+    out += [(k, 31) for k in EPISODE_INFO_ZERO_KEYS]
+    if eval_keys:
+        out += [(k, s) for s, k in EPISODE_INFO_EVAL_KEYS.items()]
+    out += [(EPISODE_INFO_KEYS[s], s) for s in range(12, 16)]
+    out += [(EPISODE_INFO_SINGLE_GAMMA_KEY, 16)] if single_gamma else [(EPISODE_INFO_KEYS[16], 16), (EPISODE_INFO_KEYS[17], 17)]
+    out.append((EPISODE_INFO_KEYS[18], 18))
+    return out
 
 
 def episode_info_items(vec, eval_keys: bool, single_gamma: bool):
     """(key, value) pairs of extras["episode"] (KAMMA.py:480-488) from the 32-slot vector of OIS_BUF_EPISODE_INFO, in the
-    key set of the reference file the variant stands for: `vec` is anything indexable (numpy row, 1-D tensor)."""
-    for slot, key in EPISODE_INFO_KEYS.items():
-        if single_gamma and slot in (16, 17):
-            continue
+    key set and order of the reference file the variant stands for: `vec` is anything indexable (numpy row, 1-D tensor)."""
+    for key, slot in episode_info_layout(eval_keys, single_gamma):
         yield key, vec[slot]
-    if single_gamma:
-        yield EPISODE_INFO_SINGLE_GAMMA_KEY, vec[16]
-    for key in EPISODE_INFO_ZERO_KEYS:
-        yield key, vec[31]  # never written by the reference: 0
-    if eval_keys:
-        for slot, key in EPISODE_INFO_EVAL_KEYS.items():
-            yield key, vec[slot]
 
 
 class OisConfig(C.Structure):

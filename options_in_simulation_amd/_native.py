@@ -21,7 +21,7 @@ SYMBOLS = (
     "ois_load_state", "ois_replay_bytes", "ois_replay_attach", "ois_replay_buffer", "ois_replay_cursor",
     "ois_gae_scratch_bytes", "ois_gae", "ois_terrain_attach", "ois_height_scan", "ois_replay_sample",
     "ois_profile_begin", "ois_profile_end", "ois_minfield_bytes", "ois_push_robots", "ois_kernel_info",
-    "ois_logs_enable", "ois_logs_fetch", "ois_outputs_copy",
+    "ois_logs_enable", "ois_logs_fetch", "ois_outputs_copy", "ois_params_dirty",
 )
 
 _lib = None
@@ -70,6 +70,7 @@ def load() -> C.CDLL:
     L.ois_stats_fetch.argtypes = [vp, C.POINTER(_abi.OisStats), C.c_int, vp]
     L.ois_env0_diag.argtypes = [vp, fp, vp]
     L.ois_logs_enable.argtypes = [vp, C.c_int]
+    L.ois_params_dirty.argtypes = [vp]
     L.ois_logs_fetch.argtypes = [vp, vp, vp, vp]
     L.ois_outputs_copy.argtypes = [vp, vp, vp, vp, vp, vp]
     L.ois_state_bytes.argtypes = [vp]

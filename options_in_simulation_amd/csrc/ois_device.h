@@ -17,6 +17,7 @@
 // -fno-slp-vectorize, so results are bit-identical to the CPU oracle's.
 #pragma once
 #include <hip/hip_runtime.h>
+#include <stddef.h>
 #include <stdint.h>
 
 #include "../../include/ois.h"
@@ -28,27 +29,50 @@ namespace ois {
 constexpr int kGroup = 16;  // arenas per reduction group of the reset-event records (SPEC §2.10)
 
 // ---------------------------------------------------------------- kernel constants ----
-struct DevConsts {
-  // physics (docs/SPEC.md §3)
+// Three blocks of 32 / 32 / 48 dwords, by WHEN a policy step needs them. The step kernels are at the SGPR limit
+// (106) with the physics constants alone: a by-value argument that is first read after the 20 substeps is loaded at
+// kernel entry all the same, and then lives through the substep loop as v_writelane / v_readlane spill traffic
+// (179 + ~130 VALU instructions per single-step launch, round 4's census). So the step kernels take only `phys`
+// from the by-value argument and re-read `task` / `reset` from the kernarg segment where a phase starts
+// (kernarg_late below); every other kernel uses the by-value fields as usual.
+struct PhysK {   // the substeps (docs/SPEC.md §3): SGPR operands of the whole substep loop
   float dt, inv_dt, gdt, half_dt, im4, imq, J4x, J4y, J4z, dt_over_Is, dt_over_Iy, rw, rw_over_Is,
-      rw2_over_Is, beta_inv_dt, vdep, maxw, maxw2, damping, wlim, climit, wx, wy, cz, com_height;
+      rw2_over_Is, beta_inv_dt, vdep, maxw, maxw2, damping, wlim, climit, wx, wy, cz;
   float inv4wx, inv4wy;  // 1 / (4 wx), 1 / (4 wy): footprint-plane fit of the terrain contact (SPEC §3.8)
   int iters, nsub;
-  // task (KAMMA.py constants, see include/ois.h)
-  float Kp, Kp_omega, vehicle_mass, vehicle_inertia, policy_dt, action_scale, torque_clip, w1, w2,
-      w3, sparse_bonus, sparse_threshold, terminal_reward, max_sim_steps, gamma1_const,
-      gamma2_const, bounds, clip_obs, episode_length_s, eval_ramp_steps;
-  float cmd_x_lo, cmd_x_hi, cmd_y_lo, cmd_y_hi, cmd_yaw_lo, cmd_yaw_hi, cmd_x_span, cmd_y_span, cmd_yaw_span,
-      spawn_xy_range;
-  float init_pos[3], init_quat[4], init_lin_vel[3], init_ang_vel[3], init_dof_vel[4];
+  int pad_[4];
+};
+struct TaskK {   // pre_physics_step / post_physics_step of a policy step (KAMMA.py constants, see include/ois.h)
+  float Kp, Kp_omega, vehicle_mass, vehicle_inertia, policy_dt, action_scale, torque_clip, max_sim_steps,
+      gamma1_const, gamma2_const, w1, w2, w3, sparse_bonus, sparse_threshold, terminal_reward,
+      bounds, clip_obs, com_height;
   int action_dim, mix_mode, gamma1_mode, gamma2_mode, guiding_mode, cmd_sampler, eval_sums,
       max_episode_length, env0_reward_guard;
   uint32_t seed_lo, seed_hi;
   int64_t arena_offset;
+};
+struct ResetK {  // reset_idx and the per-level command generators: the paths a lane takes once per episode
+  float episode_length_s, eval_ramp_steps;
+  float cmd_x_lo, cmd_x_hi, cmd_y_lo, cmd_y_hi, cmd_yaw_lo, cmd_yaw_hi, cmd_x_span, cmd_y_span, cmd_yaw_span,
+      spawn_xy_range;
+  // scalars, no arrays: the step kernels hold this block as a LOCAL struct (kernarg_late), and one array member that the
+  // optimiser decides to index (a select chain over its elements is enough) keeps the whole struct in memory — a private
+  // array, which the backend promotes to LDS: +13 us per launch (tests/test_abi_and_config.py)
+  float init_pos0, init_pos1, init_pos2, init_quat0, init_quat1, init_quat2, init_quat3;
+  float init_lin_vel0, init_lin_vel1, init_lin_vel2, init_ang_vel0, init_ang_vel1, init_ang_vel2;
+  float init_dof_vel0, init_dof_vel1, init_dof_vel2, init_dof_vel3;
+  float cmd_thr_high;
   // per-level command generators (OIS_CMD_LEVEL): Python doubles of the reference kept as doubles
   double cmd_dt, cmd_episode_s;
-  float cmd_thr_high;
+  int pad_[14];
 };
+struct DevConsts {
+  PhysK phys;
+  TaskK task;
+  ResetK reset;
+};
+static_assert(sizeof(PhysK) == 128 && sizeof(TaskK) == 128 && sizeof(ResetK) == 192, "blocks of 16-dword scalar loads");
+static_assert(offsetof(DevConsts, task) == 128 && offsetof(DevConsts, reset) == 256 && sizeof(DevConsts) == 448, "kernarg offsets of kernarg_late");
 
 // height-field terrain (include/ois.h ois_terrain_attach); on == 0: the per-arena plane of `params`
 constexpr int kWideTile = -32768;  // DevTerrain::mb value of a tile whose heights do not fit base + 0..254
@@ -63,32 +87,109 @@ struct DevTerrain {
   float inv_hs, hs, vs, border, thr_lo, thr_hi;
 };
 
-// device pointers of one environment ([N][4] unless noted)
-struct DevBuffers {
-  float4 *pose, *quat, *linvel, *angvel, *wheel_vel, *commands, *sums_a, *sums_b, *sums_c, *params, *wheel_torqs;
-  uint2 *lam_n, *lam_l, *lam_t;  // [N] x 4 halves: warm-start impulses in binary16 (include/ois.h OIS_BUF_LAMBDA_*)
+// device pointers of one environment ([N][4] unless noted). Field ORDER matters: four blocks of 8 pointers
+// (16 dwords each), by when a step kernel needs them, re-read from the kernarg segment at that point (kernarg_late).
+struct RowPtrs {    // chassis rows a step stores in its epilogue
+  float4 *pose, *quat, *linvel, *angvel, *commands, *sums_a, *sums_b;
   int4* counters;
+};
+struct WheelPtrs {  // wheel rows, eval sums, terrain rows (epilogue)
+  float4 *wheel_vel, *wheel_torqs, *sums_c;
+  uint2 *lam_n, *lam_l, *lam_t;  // [N] x 4 halves: warm-start impulses in binary16 (include/ois.h OIS_BUF_LAMBDA_*)
+  float4* env_origins;           // terrain: per-arena tile origin (xyz)
+  int4* terrain_idx;             // (level, type) index
+};
+struct OutPtrs {    // what post_physics_step leaves: outputs and the reset-event records
   float* obs;        // [N][6]
   float* rew;        // [N]
   uint8_t* done;     // [N]
   uint8_t* timeout;  // [N]
+  float* env0_diag;  // [32]
   float* partials;   // [ngroups][32] per-group reset-event records
   int32_t* stamps;   // [ngroups]
   double* stat_acc;  // [ngroups][8] finished-episode accumulators, double
-  float* episode_info;  // [32]
-  float* env0_diag;     // [32]
-  // optional FIFO transition memory (include/ois.h ois_replay_*), rp_size = 0 when detached
+};
+struct AuxPtrs {    // optional FIFO transition memory (include/ois.h ois_replay_*), level curriculum, logs
   float *rp_states, *rp_actions, *rp_rewards, *rp_next;  // [M][N][6|4|1|6]
   uint8_t* rp_done;                                      // [M][N]
-  int rp_size;
-  // terrain: per-arena tile origin (xyz) and (level, type) index
+  int32_t* reset_stamp;  // the sim_steps value of the last step in which any arena reset (two slots by parity)
+  float* cmd_fraction;   // OIS_CMD_LEVEL: self.fraction [N]
+  float* episode_info;   // [32]
+};
+struct DevBuffers {
+  float4 *pose, *quat, *linvel, *angvel, *commands, *sums_a, *sums_b;
+  int4* counters;
+  float4 *wheel_vel, *wheel_torqs, *sums_c;
+  uint2 *lam_n, *lam_l, *lam_t;
   float4* env_origins;
   int4* terrain_idx;
-  DevTerrain ter;
-  // OIS_CMD_LEVEL: self.fraction [N] and the sim_steps value of the last step in which any arena reset
-  float* cmd_fraction;
+  float* obs;
+  float* rew;
+  uint8_t* done;
+  uint8_t* timeout;
+  float* env0_diag;
+  float* partials;
+  int32_t* stamps;
+  double* stat_acc;
+  float *rp_states, *rp_actions, *rp_rewards, *rp_next;
+  uint8_t* rp_done;
   int32_t* reset_stamp;
+  float* cmd_fraction;
+  float* episode_info;
+  float4* params;
+  int rp_size;  // 0 when no transition memory is attached
+  DevTerrain ter;
 };
+constexpr int kArgB = (int)sizeof(DevConsts);  // kernarg offset of the DevBuffers argument (second argument of every step shell)
+static_assert(sizeof(RowPtrs) == 64 && sizeof(WheelPtrs) == 64 && sizeof(OutPtrs) == 64 && sizeof(AuxPtrs) == 64, "16-dword blocks");
+static_assert(offsetof(DevBuffers, pose) == 0 && offsetof(DevBuffers, counters) == 56 && offsetof(DevBuffers, wheel_vel) == 64 &&
+              offsetof(DevBuffers, terrain_idx) == 120 && offsetof(DevBuffers, obs) == 128 && offsetof(DevBuffers, stat_acc) == 184 &&
+              offsetof(DevBuffers, rp_states) == 192 && offsetof(DevBuffers, episode_info) == 248 && alignof(DevBuffers) == 8 &&
+              alignof(DevConsts) == 8, "DevBuffers = RowPtrs | WheelPtrs | OutPtrs | AuxPtrs | ...");
+
+// A 16-dword block of the kernel's own arguments, read from the kernarg segment HERE (scalar load, waited for) instead of
+// being held from kernel entry: volatile, so neither hoisted nor merged with the entry loads. T is one of the blocks above.
+typedef int sgpr16_t __attribute__((ext_vector_type(16)));
+typedef uint64_t kernarg_t;  // the kernarg segment pointer as an integer (an SGPR pair)
+OIS_DEV kernarg_t kernarg_base() { return (kernarg_t)__builtin_amdgcn_kernarg_segment_ptr(); }
+// ... and the pointer itself is not held through the substep loop either (the loop is two scalar registers short, and the
+// allocator's choice of victim was a pair the loop READS: two reloads per substep): parked in two lanes of a vector register
+// across the substeps, by hand
+OIS_DEV int kernarg_park(kernarg_t p) {
+  int v;
+  asm volatile("v_writelane_b32 %0, %1, 0\n\tv_writelane_b32 %0, %2, 1" : "=&v"(v) : "s"((int)(uint32_t)p), "s"((int)(uint32_t)(p >> 32)));
+  return v;
+}
+OIS_DEV kernarg_t kernarg_unpark(int v) {
+  int lo, hi;
+  asm volatile("v_readlane_b32 %0, %2, 0\n\tv_readlane_b32 %1, %2, 1\n\ts_nop 4" : "=&s"(lo), "=&s"(hi) : "v"(v));
+  return (kernarg_t)(uint32_t)lo | ((kernarg_t)(uint32_t)hi << 32);
+}
+template <class T, int BYTE_OFFSET>
+OIS_DEV T kernarg_late(kernarg_t kp) {
+  static_assert(sizeof(T) == 64 && BYTE_OFFSET % 4 == 0, "one s_load_dwordx16");
+  sgpr16_t v;
+  asm volatile("s_load_dwordx16 %0, %1, %2\n\ts_waitcnt lgkmcnt(0)" : "=s"(v) : "s"(kp), "n"(BYTE_OFFSET));
+  return __builtin_bit_cast(T, v);
+}
+struct TaskHalves { sgpr16_t a, b; };
+OIS_DEV TaskK late_task(kernarg_t kp) {
+  static_assert(sizeof(TaskK) == 128, "");
+  TaskHalves h;
+  asm volatile("s_load_dwordx16 %0, %2, %3\n\ts_load_dwordx16 %1, %2, %4\n\ts_waitcnt lgkmcnt(0)"
+               : "=&s"(h.a), "=&s"(h.b) : "s"(kp), "n"((int)offsetof(DevConsts, task)), "n"((int)offsetof(DevConsts, task) + 64));
+  return __builtin_bit_cast(TaskK, h);
+}
+struct ResetThirds { sgpr16_t a, b, c; };
+OIS_DEV ResetK late_reset(kernarg_t kp) {
+  static_assert(sizeof(ResetK) == 192, "");
+  ResetThirds h;
+  asm volatile("s_load_dwordx16 %0, %3, %4\n\ts_load_dwordx16 %1, %3, %5\n\ts_load_dwordx16 %2, %3, %6\n\ts_waitcnt lgkmcnt(0)"
+               : "=&s"(h.a), "=&s"(h.b), "=&s"(h.c)
+               : "s"(kp), "n"((int)offsetof(DevConsts, reset)), "n"((int)offsetof(DevConsts, reset) + 64),
+                 "n"((int)offsetof(DevConsts, reset) + 128));
+  return __builtin_bit_cast(ResetK, h);
+}
 
 // ---------------------------------------------------------------- RNG -----------------
 // Philox4x32-10 (Salmon et al., SC'11; Random123 constants)
@@ -96,8 +197,10 @@ OIS_DEV void philox4x32_10(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, u
                            uint32_t k1, uint32_t o[4]) {
 #pragma unroll
   for (int r = 0; r < 10; ++r) {
-    uint32_t h0 = __umulhi(0xD2511F53u, c0), l0 = 0xD2511F53u * c0;
-    uint32_t h1 = __umulhi(0xCD9E8D57u, c2), l1 = 0xCD9E8D57u * c2;
+    // one v_mad_u64_u32 per product (both halves) instead of a v_mul_hi_u32 + v_mul_lo_u32 pair
+    const uint64_t p0 = (uint64_t)0xD2511F53u * c0, p1 = (uint64_t)0xCD9E8D57u * c2;
+    uint32_t h0 = (uint32_t)(p0 >> 32), l0 = (uint32_t)p0;
+    uint32_t h1 = (uint32_t)(p1 >> 32), l1 = (uint32_t)p1;
     uint32_t n0 = h1 ^ c1 ^ k0, n2 = h0 ^ c3 ^ k1;
     c0 = n0; c1 = l1; c2 = n2; c3 = l0;
     k0 += 0x9E3779B9u;
@@ -107,10 +210,10 @@ OIS_DEV void philox4x32_10(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, u
 }
 OIS_DEV float u01(uint32_t x) { return (float)(x >> 8) * 5.9604644775390625e-08f; }
 enum { PURPOSE_MASK = 0, PURPOSE_RESET_A = 1, PURPOSE_RESET_B = 2, PURPOSE_ACTION = 3, PURPOSE_PARAMS = 4, PURPOSE_RESET_C = 5, PURPOSE_CMD = 6, PURPOSE_PUSH = 7 };
-OIS_DEV void draw4(const DevConsts& K, int64_t gid, uint32_t step, uint32_t purpose, float u[4]) {
+OIS_DEV void draw4(const TaskK& T, int64_t gid, uint32_t step, uint32_t purpose, float u[4]) {
   uint32_t o[4];
   philox4x32_10((uint32_t)((uint64_t)gid & 0xffffffffu), (uint32_t)((uint64_t)gid >> 32), step, purpose,
-                K.seed_lo, K.seed_hi, o);
+                T.seed_lo, T.seed_hi, o);
   u[0] = u01(o[0]); u[1] = u01(o[1]); u[2] = u01(o[2]); u[3] = u01(o[3]);
 }
 
@@ -346,12 +449,15 @@ OIS_DEV void contrib_identity(ResetContrib& c) {
 
 // reset_idx for one arena (KAMMA.py:417-498). wheel0 = index of this lane's first wheel.
 template <int LPA>
-OIS_DEV void reset_arena(const DevConsts& K, int64_t gid, int wheel0, float gamma1, float gamma2, ArenaT<LPA>& S,
+OIS_DEV void reset_arena(const TaskK& T, const ResetK& Rk, int64_t gid, int wheel0, float gamma1, float gamma2, ArenaT<LPA>& S,
                          ResetContrib& rc) {
+  // by value, read at constant offsets HERE: behind the reference the optimiser folds the select chain below into one
+  // indexed load, which keeps the caller's local copy of the block in memory (see ResetK)
+  const float dv0 = Rk.init_dof_vel0, dv1 = Rk.init_dof_vel1, dv2 = Rk.init_dof_vel2, dv3 = Rk.init_dof_vel3;
   const float Sf = S.sb[3];                   // "Final reward" sum
   const float hg = 100.0f * (1.0f - gamma2);  // :470
   const float gg = 100.0f * gamma2;           // :475
-  const float L = K.episode_length_s;
+  const float L = Rk.episode_length_s;
   rc.s[0] = 1.0f; rc.s[1] = Sf * Sf; rc.s[2] = (float)S.ep_buf; rc.s[3] = 0.0f;
 #pragma unroll
   for (int k = 0; k < 4; ++k) {
@@ -369,62 +475,63 @@ OIS_DEV void reset_arena(const DevConsts& K, int64_t gid, int wheel0, float gamm
   for (int k = 0; k < 4; ++k) { S.sa[k] = 0.0f; S.sb[k] = 0.0f; S.sc[k] = 0.0f; }  // :485 (sc[3]: old-torque flag)
 
   float u[8];
-  draw4(K, gid, (uint32_t)S.sim_steps, PURPOSE_RESET_A, &u[0]);
-  draw4(K, gid, (uint32_t)S.sim_steps, PURPOSE_RESET_B, &u[4]);
-  const float r = K.spawn_xy_range;
-  const float px = K.init_pos[0] + rand_float(-r, r, u[0]);  // :422-424
-  const float py = K.init_pos[1] + rand_float(-r, r, u[1]);
-  const float pz = K.init_pos[2];
+  draw4(T, gid, (uint32_t)S.sim_steps, PURPOSE_RESET_A, &u[0]);
+  draw4(T, gid, (uint32_t)S.sim_steps, PURPOSE_RESET_B, &u[4]);
+  const float r = Rk.spawn_xy_range;
+  const float px = Rk.init_pos0 + rand_float(-r, r, u[0]);  // :422-424
+  const float py = Rk.init_pos1 + rand_float(-r, r, u[1]);
+  const float pz = Rk.init_pos2;
   const float ang = rand_float(0.0f, 6.28318530717958647692f, u[2]);  // :426
   float s, c;
   sincos_det(ang / 2.0f, s, c);
   const float qz[4] = {c, 0.0f, 0.0f, s};
-  quat_mul(qz, K.init_quat, S.q);  // :434
-  const float cx = rand_span(K.cmd_x_lo, K.cmd_x_span, u[3]);      // :448
-  const float cy = rand_span(K.cmd_y_lo, K.cmd_y_span, u[4]);      // :451
-  const float ch = rand_span(K.cmd_yaw_lo, K.cmd_yaw_span, u[5]);  // :454
+  const float iq[4] = {Rk.init_quat0, Rk.init_quat1, Rk.init_quat2, Rk.init_quat3};
+  quat_mul(qz, iq, S.q);  // :434
+  const float cx = rand_span(Rk.cmd_x_lo, Rk.cmd_x_span, u[3]);      // :448
+  const float cy = rand_span(Rk.cmd_y_lo, Rk.cmd_y_span, u[4]);      // :451
+  const float ch = rand_span(Rk.cmd_yaw_lo, Rk.cmd_yaw_span, u[5]);  // :454
   const float keep = sqrtf(cx * cx + cy * cy) > 0.25f ? 1.0f : 0.0f;  // :458
   S.cmd[1] = cy * keep;
   S.cmd[3] = ch * keep;
   const float cmd2_kept = S.cmd[2] * keep;  // :458 on the value commands[:, 2] had (only the level mode keeps it)
-  float x_vel = rand_span(K.cmd_x_lo, K.cmd_x_span, u[6]);  // :571 (u[7]: discarded omega draw :572)
-  if (K.cmd_sampler == OIS_CMD_BOX) {  // KAMMA_curr1.py:577-598
-    const float progress = fminf(1.0f, (float)S.sim_steps / K.max_sim_steps);
+  float x_vel = rand_span(Rk.cmd_x_lo, Rk.cmd_x_span, u[6]);  // :571 (u[7]: discarded omega draw :572)
+  if (T.cmd_sampler == OIS_CMD_BOX) {  // KAMMA_curr1.py:577-598
+    const float progress = fminf(1.0f, (float)S.sim_steps / T.max_sim_steps);
     const float factor = 0.1f + (1.0f - 0.1f) * progress;
-    const float xc = (K.cmd_x_lo + K.cmd_x_hi) / 2.0f;
-    const float xmin = xc - (xc - K.cmd_x_lo) * factor;
-    const float xmax = xc + (K.cmd_x_hi - xc) * factor;
+    const float xc = (Rk.cmd_x_lo + Rk.cmd_x_hi) / 2.0f;
+    const float xmin = xc - (xc - Rk.cmd_x_lo) * factor;
+    const float xmax = xc + (Rk.cmd_x_hi - xc) * factor;
     x_vel = rand_float(xmin, xmax, u[6]);
-  } else if (K.cmd_sampler == OIS_CMD_EVAL) {  // KAMMA_eval.py:545-550
-    const float progress = fminf(fmaxf((float)S.sim_steps / K.eval_ramp_steps, 0.0f), 1.0f);
+  } else if (T.cmd_sampler == OIS_CMD_EVAL) {  // KAMMA_eval.py:545-550
+    const float progress = fminf(fmaxf((float)S.sim_steps / Rk.eval_ramp_steps, 0.0f), 1.0f);
     x_vel = 1.0f + progress * (2.0f - 1.0f);
-  } else if (K.cmd_sampler == OIS_CMD_GRID) {  // KAMMA_curr2.py:602-640 (bimodal normal, sigma 0.05)
-    const float progress = fminf(1.0f, (float)S.sim_steps / K.max_sim_steps);
-    const float xc = (K.cmd_x_lo + K.cmd_x_hi) / 2.0f;
-    const float left = xc - progress * (xc - K.cmd_x_lo);
-    const float right = xc + progress * (K.cmd_x_hi - xc);
+  } else if (T.cmd_sampler == OIS_CMD_GRID) {  // KAMMA_curr2.py:602-640 (bimodal normal, sigma 0.05)
+    const float progress = fminf(1.0f, (float)S.sim_steps / T.max_sim_steps);
+    const float xc = (Rk.cmd_x_lo + Rk.cmd_x_hi) / 2.0f;
+    const float left = xc - progress * (xc - Rk.cmd_x_lo);
+    const float right = xc + progress * (Rk.cmd_x_hi - xc);
     float uc[4];
-    draw4(K, gid, (uint32_t)S.sim_steps, PURPOSE_RESET_C, uc);
+    draw4(T, gid, (uint32_t)S.sim_steps, PURPOSE_RESET_C, uc);
     const float mean = u[6] < 0.5f ? left : right;  // torch.rand(1) < 0.5 picks the side
     x_vel = mean + 0.05f * normal_det(uc[0], uc[1]);
   }
   S.cmd[0] = x_vel > 0.0f ? x_vel : 0.0f;  // :575, :495
   S.cmd[2] = 0.0f;                         // :574, :496
-  if (K.cmd_sampler == OIS_CMD_LEVEL) {    // `if not self.curriculum:` skips the re-draw (:490)
+  if (T.cmd_sampler == OIS_CMD_LEVEL) {    // `if not self.curriculum:` skips the re-draw (:490)
     S.cmd[0] = cx * keep;
     S.cmd[2] = cmd2_kept;
   }
   float R[9];
   rotmat(S.q, R);
-  S.p[0] = __builtin_fmaf(R[2], K.com_height, px);
-  S.p[1] = __builtin_fmaf(R[5], K.com_height, py);
-  S.p[2] = __builtin_fmaf(R[8], K.com_height, pz);
-#pragma unroll
-  for (int k = 0; k < 3; ++k) { S.v[k] = K.init_lin_vel[k]; S.w[k] = K.init_ang_vel[k]; }  // :435
+  S.p[0] = __builtin_fmaf(R[2], T.com_height, px);
+  S.p[1] = __builtin_fmaf(R[5], T.com_height, py);
+  S.p[2] = __builtin_fmaf(R[8], T.com_height, pz);
+  S.v[0] = Rk.init_lin_vel0; S.v[1] = Rk.init_lin_vel1; S.v[2] = Rk.init_lin_vel2;  // :435
+  S.w[0] = Rk.init_ang_vel0; S.w[1] = Rk.init_ang_vel1; S.w[2] = Rk.init_ang_vel2;
 #pragma unroll
   for (int k = 0; k < ArenaT<LPA>::WPL; ++k) {
     const int gk = wheel0 + k;  // :438
-    S.jv[k] = gk == 0 ? K.init_dof_vel[0] : (gk == 1 ? K.init_dof_vel[1] : (gk == 2 ? K.init_dof_vel[2] : K.init_dof_vel[3]));
+    S.jv[k] = gk == 0 ? dv0 : (gk == 1 ? dv1 : (gk == 2 ? dv2 : dv3));
     S.ln[k] = 0.0f; S.l1[k] = 0.0f; S.l2[k] = 0.0f;
   }
   S.ep_buf = 0;     // :462
@@ -447,22 +554,22 @@ OIS_DEV float group_reduce16(float x) {
 // Must be called by all 64 lanes of the wave (shuffles); only groups with a resetting arena
 // write. group = arena / 16.
 template <int LPA>
-OIS_DEV void group_record(const DevBuffers& B, int group, int lane, bool group_has_reset, const ResetContrib& rc,
-                          int stamp, bool count_stats) {
+OIS_DEV void group_record(float* partials, int32_t* stamps, double* stat_acc, int group, int lane, bool group_has_reset,
+                          const ResetContrib& rc, int stamp, bool count_stats) {
   float rs[kRecSum], rm[4];
 #pragma unroll
   for (int k = 0; k < kRecSum; ++k) rs[k] = group_reduce16<0, LPA>(rc.s[k]);
 #pragma unroll
   for (int k = 0; k < 4; ++k) rm[k] = group_reduce16<1, LPA>(rc.m[k]);
   if ((lane & (kGroup * LPA - 1)) == 0 && group_has_reset) {
-    float* P = B.partials + (size_t)group * 32;
+    float* P = partials + (size_t)group * 32;
 #pragma unroll
     for (int k = 0; k < kRecSum; ++k) P[k] = rs[k];
 #pragma unroll
     for (int k = 0; k < 4; ++k) P[24 + k] = rm[k];
-    B.stamps[group] = stamp;
+    stamps[group] = stamp;
     if (count_stats) {
-      double* A = B.stat_acc + (size_t)group * 8;
+      double* A = stat_acc + (size_t)group * 8;
       // A[0..3] = count, ret^2, len, ret ; A[6], A[7] = max(-ret), max(ret)
       A[0] += (double)rs[0]; A[1] += (double)rs[1]; A[2] += (double)rs[2]; A[3] += (double)rs[11];
       A[6] = fmax(A[6], (double)rm[2]); A[7] = fmax(A[7], (double)rm[3]);

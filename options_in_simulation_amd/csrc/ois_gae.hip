@@ -8,10 +8,21 @@
 //
 // Arithmetic: -ffp-contract=off, every operation rounded on its own, in the reference's
 // evaluation order (the oracle oracle/ois_oracle.c:orc_gae spells the same sequence).
+//
+// At the reference's own rollout lengths (ppo.py:23 rollouts = 16, ppoc.py:23: 20) the work is 27 MB at 65 536 arenas and the
+// launches cost more than the bytes: the scan is 4.5 us. So the normalisation is TWO launches, not three: every block of the
+// normalise kernel sums the per-wave moments itself (16 KB out of L2, the same fixed order as the separate moments kernel,
+// which stays for grids with more than kFoldParts waves). ONE launch was built and measured in round 4 (a lane keeps its T <= 32
+// advantages in registers across a grid-wide barrier, then writes them normalised) and is slower: the 8 XCDs' L2s are not
+// coherent with each other, a word crosses between them in ~2 us, and any barrier needs several such hops — 102 us with an
+// arrival counter (1024 same-address atomics serialise at the memory side), 43 us with per-wave flags under release / acquire
+// (an agent-scope release writes back the XCD's whole dirty L2), 24 us with relaxed agent-scope stores and explicit waits,
+// against 4 us for the hardware's own barrier, the end of a kernel (profiles/r4_gae_probe.json).
 #include <hip/hip_runtime.h>
 
 #include <cstdint>
 #include <cstdio>
+#include <cstdlib>
 
 #include "../../include/ois.h"
 
@@ -90,11 +101,9 @@ __global__ __launch_bounds__(kGaeBlock) void gae_scan_kernel(
   }
 }
 
-// mean and 1/(std + 1e-8) denominators of the normalisation: one block sums the per-wave
-// partials in a fixed order (strided accumulate, then a tree), std unbiased like torch.std.
-__global__ __launch_bounds__(kNormBlock) void gae_moments_kernel(size_t count, int nparts,
-                                                                const double* __restrict__ partials,
-                                                                float* __restrict__ mean_den) {
+// the moments of the normalisation from the per-wave partials: one fixed order (strided accumulate, then a tree), std unbiased
+// like torch.std. Called by all kNormBlock threads of a block; every thread returns the same pair.
+__device__ inline void moments_of(size_t count, int nparts, const double* __restrict__ partials, float& mean_f, float& den) {
   __shared__ double sh[2][kNormBlock];
   double s1 = 0.0, s2 = 0.0;
   for (int p = threadIdx.x; p < nparts; p += kNormBlock) { s1 += partials[2 * p]; s2 += partials[2 * p + 1]; }
@@ -104,23 +113,33 @@ __global__ __launch_bounds__(kNormBlock) void gae_moments_kernel(size_t count, i
     if ((int)threadIdx.x < w) { sh[0][threadIdx.x] += sh[0][threadIdx.x + w]; sh[1][threadIdx.x] += sh[1][threadIdx.x + w]; }
     __syncthreads();
   }
-  if (threadIdx.x == 0) {
-    const double n = (double)count;
-    const double mean = sh[0][0] / n;
-    double var = (sh[1][0] - n * mean * mean) / (n - 1.0);  // NaN for count == 1, like torch.std
-    if (var < 0.0) var = 0.0;
-    mean_den[0] = (float)mean;
-    mean_den[1] = (float)sqrt(var) + 1e-8f;
-  }
+  const double n = (double)count;
+  const double mean = sh[0][0] / n;
+  double var = (sh[1][0] - n * mean * mean) / (n - 1.0);  // NaN for count == 1, like torch.std
+  if (var < 0.0) var = 0.0;
+  mean_f = (float)mean;
+  den = (float)sqrt(var) + 1e-8f;
 }
 
-// advantages = (advantages - mean) / (std + 1e-8), in place, IEEE division
-__global__ __launch_bounds__(kNormBlock) void gae_normalize_kernel(size_t count, const float* __restrict__ mean_den,
-                                                                  float* __restrict__ adv) {
-  const float mean_f = mean_den[0], den = mean_den[1];
+__global__ __launch_bounds__(kNormBlock) void gae_moments_kernel(size_t count, int nparts, const double* __restrict__ partials,
+                                                                float* __restrict__ mean_den) {
+  float m, d;
+  moments_of(count, nparts, partials, m, d);
+  if (threadIdx.x == 0) { mean_den[0] = m; mean_den[1] = d; }
+}
+
+// advantages = (advantages - mean) / (std + 1e-8), in place, IEEE division. FOLD: the block sums the partials itself
+template <bool FOLD>
+__global__ __launch_bounds__(kNormBlock) void gae_normalize_kernel(size_t count, int nparts, const double* __restrict__ partials,
+                                                                  const float* __restrict__ mean_den, float* __restrict__ adv) {
+  float mean_f, den;
+  if (FOLD) moments_of(count, nparts, partials, mean_f, den);
+  else { mean_f = mean_den[0]; den = mean_den[1]; }
   const size_t stride = (size_t)gridDim.x * kNormBlock;
   for (size_t o = (size_t)blockIdx.x * kNormBlock + threadIdx.x; o < count; o += stride) adv[o] = (adv[o] - mean_f) / den;
 }
+
+constexpr int kFoldParts = 2048;  // up to this many per-wave partials (32 KB) every normalise block sums them itself
 
 int gae_blocks(int N) { return (N + kGaeBlock - 1) / kGaeBlock; }
 
@@ -158,8 +177,12 @@ int ois_gae(int mode, int T, int num_envs, const float* rewards, const uint8_t* 
     size_t nb = (count + kNormBlock - 1) / kNormBlock;
     if (nb > 2048) nb = 2048;  // 8 blocks per CU, grid-stride
     float* mean_den = (float*)(partials + 2 * (size_t)blocks);
-    hipLaunchKernelGGL(gae_moments_kernel, dim3(1), dim3(kNormBlock), 0, s, count, blocks, partials, mean_den);
-    hipLaunchKernelGGL(gae_normalize_kernel, dim3((unsigned)nb), dim3(kNormBlock), 0, s, count, mean_den, advantages_out);
+    if (blocks <= kFoldParts) {
+      hipLaunchKernelGGL(gae_normalize_kernel<true>, dim3((unsigned)nb), dim3(kNormBlock), 0, s, count, blocks, partials, mean_den, advantages_out);
+    } else {
+      hipLaunchKernelGGL(gae_moments_kernel, dim3(1), dim3(kNormBlock), 0, s, count, blocks, partials, mean_den);
+      hipLaunchKernelGGL(gae_normalize_kernel<false>, dim3((unsigned)nb), dim3(kNormBlock), 0, s, count, blocks, partials, mean_den, advantages_out);
+    }
   }
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) {

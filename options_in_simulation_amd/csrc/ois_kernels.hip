@@ -73,7 +73,7 @@ OIS_DEV void store_lambda(uint2* base, int arena, int h, const float* s) {
 }
 
 template <int LPA>
-OIS_DEV void load_arena(const DevConsts& K, const DevBuffers& B, int i, int h, ArenaT<LPA>& S) {
+OIS_DEV void load_arena(bool eval_sums, const DevBuffers& B, int i, int h, ArenaT<LPA>& S) {
   // issued in the order of first use (vector loads return in order, so a later row never holds up an
   // earlier one): controller inputs, then what the first substep reads, the episode sums last
   // (only read after the 20 substeps)
@@ -91,7 +91,7 @@ OIS_DEV void load_arena(const DevConsts& K, const DevBuffers& B, int i, int h, A
   load_lambda<LPA>(B.lam_n, i, h, S.ln);
   load_lambda<LPA>(B.lam_l, i, h, S.l1);
   load_lambda<LPA>(B.lam_t, i, h, S.l2);
-  if (K.eval_sums) {
+  if (eval_sums) {
     unpack(B.sums_c[i], S.sc);
     load_wheels<LPA>(B.wheel_torqs, i, h, S.wt);
   } else {
@@ -103,29 +103,34 @@ OIS_DEV void load_arena(const DevConsts& K, const DevBuffers& B, int i, int h, A
 }
 
 template <int LPA>
-OIS_DEV void store_arena(const DevConsts& K, const DevBuffers& B, int i, int h, const ArenaT<LPA>& S, bool cmd_dirty) {
+OIS_DEV void store_arena(bool eval_sums, const RowPtrs& R, const WheelPtrs& Wp, int i, int h, const ArenaT<LPA>& S, bool cmd_dirty) {
   if (h == 0) {  // chassis rows are replicated in the lane pair: one lane writes them
-    store_row(&B.pose[i], S.p[0], S.p[1], S.p[2], S.vfwd);
-    store_row(&B.quat[i], S.q[0], S.q[1], S.q[2], S.q[3]);
-    store_row(&B.linvel[i], S.v[0], S.v[1], S.v[2], S.prev_lin);
-    store_row(&B.angvel[i], S.w[0], S.w[1], S.w[2], S.prev_ang);
-    if (cmd_dirty) B.commands[i] = make_float4(S.cmd[0], S.cmd[1], S.cmd[2], S.cmd[3]);  // only reset_idx writes commands
-    store_row(&B.counters[i], S.ep_buf, S.sim_steps, S.ep_count, 0);
-    store_row(&B.sums_a[i], S.sa[0], S.sa[1], S.sa[2], S.sa[3]);
-    store_row(&B.sums_b[i], S.sb[0], S.sb[1], S.sb[2], S.sb[3]);
-    if (K.eval_sums) B.sums_c[i] = make_float4(S.sc[0], S.sc[1], S.sc[2], S.sc[3]);
+    store_row(&R.pose[i], S.p[0], S.p[1], S.p[2], S.vfwd);
+    store_row(&R.quat[i], S.q[0], S.q[1], S.q[2], S.q[3]);
+    store_row(&R.linvel[i], S.v[0], S.v[1], S.v[2], S.prev_lin);
+    store_row(&R.angvel[i], S.w[0], S.w[1], S.w[2], S.prev_ang);
+    if (cmd_dirty) R.commands[i] = make_float4(S.cmd[0], S.cmd[1], S.cmd[2], S.cmd[3]);  // only reset_idx writes commands
+    store_row(&R.counters[i], S.ep_buf, S.sim_steps, S.ep_count, 0);
+    store_row(&R.sums_a[i], S.sa[0], S.sa[1], S.sa[2], S.sa[3]);
+    store_row(&R.sums_b[i], S.sb[0], S.sb[1], S.sb[2], S.sb[3]);
+    if (eval_sums) Wp.sums_c[i] = make_float4(S.sc[0], S.sc[1], S.sc[2], S.sc[3]);
   }
-  store_wheels<LPA>(B.wheel_vel, i, h, S.jv);
-  store_lambda<LPA>(B.lam_n, i, h, S.ln);  // already binary16 values (rounded at the end of the policy step)
-  store_lambda<LPA>(B.lam_l, i, h, S.l1);
-  store_lambda<LPA>(B.lam_t, i, h, S.l2);
-  store_wheels<LPA>(B.wheel_torqs, i, h, S.wt);
+  store_wheels<LPA>(Wp.wheel_vel, i, h, S.jv);
+  store_lambda<LPA>(Wp.lam_n, i, h, S.ln);  // already binary16 values (rounded at the end of the policy step)
+  store_lambda<LPA>(Wp.lam_l, i, h, S.l1);
+  store_lambda<LPA>(Wp.lam_t, i, h, S.l2);
+  store_wheels<LPA>(Wp.wheel_torqs, i, h, S.wt);
 }
 
 // ------------------------------------------------------------------ the step kernel ---
 template <int LPA, bool PK, bool TER, int NIT, bool FLAT = false, bool FOLD = false>
-OIS_DEV void step_body(const DevConsts& K, const DevBuffers& B, const float* __restrict__ actions,
+OIS_DEV void step_body(const PhysK& K, const DevBuffers& B, const float* __restrict__ actions,
                        float* __restrict__ reward_sum, int N, int ksteps, int policy, int rp_head) {
+  // K: the physics constants only, by value. Everything else of the kernel's arguments that a LATER phase needs (task
+  // constants, reset constants, the pointers of the stores) is re-read from the kernarg segment where that phase starts
+  // (kernarg_late, ois_device.h) and never touched through the by-value argument: what is not live across the substep
+  // loop is not spilled around it.
+  // [phase: prologue: argument blocks, state rows in (per launch)]
   constexpr int W = 4 / LPA;
   const int tid = blockIdx.x * kBlock + threadIdx.x;
   const int lane = threadIdx.x & 63;
@@ -134,11 +139,13 @@ OIS_DEV void step_body(const DevConsts& K, const DevBuffers& B, const float* __r
   const int wheel0 = h * W;
   const bool valid = arena < N;
   const int la = valid ? arena : N - 1;  // tail lanes shadow the last arena and store nothing
-  const int64_t gid = K.arena_offset + la;
-  const int A = K.action_dim;
+  kernarg_t kp = kernarg_base();
+  const TaskK T0 = late_task(kp);  // the prologue's own copy
+  const int64_t gid = T0.arena_offset + la;
+  const bool eval_sums = T0.eval_sums != 0;
 
   ArenaT<LPA> S;
-  load_arena<LPA>(K, B, la, h, S);
+  load_arena<LPA>(eval_sums, B, la, h, S);
   // bit 8 of `policy`: this launch continues a rollout that is split into launches (OIS_CMD_LEVEL)
   const bool rsum_continue = (policy & 0x100) != 0;
   // bit 9: the per-level command re-draw that follows the PREVIOUS step of this rollout (level_command_kernel's work,
@@ -151,7 +158,7 @@ OIS_DEV void step_body(const DevConsts& K, const DevBuffers& B, const float* __r
   // KAMMA_eval.py:470: a reset_idx call zeroes old_torques of EVERY arena. Did any arena reset in the step before
   // this launch? (the stamp slot of this parity was written by that step or by an older one; launches of the
   // eval variants are single steps, launch_steps())
-  const bool old_zeroed = K.eval_sums && B.reset_stamp[S.sim_steps & 1] == S.sim_steps;
+  const bool old_zeroed = eval_sums && B.reset_stamp[S.sim_steps & 1] == S.sim_steps;
   // terrain tile of this arena (origin xyz; level / type for the curriculum)
   float tor[3] = {0.0f, 0.0f, 0.0f};
   int tlevel = 0, ttype = 0;
@@ -161,18 +168,21 @@ OIS_DEV void step_body(const DevConsts& K, const DevBuffers& B, const float* __r
     tor[0] = eo.x; tor[1] = eo.y; tor[2] = eo.z;
     tlevel = ti.x; ttype = ti.y;
   }
+  // [census: not in the bench configuration: continuation launch of a level-curriculum rollout]
   if constexpr (FOLD) if (fold_level) {
+    const ResetK Rk = late_reset(kp);
     const int sim = S.sim_steps;  // == episode_step_counter of the step just done
     float fr = B.cmd_fraction[la];
     if (B.reset_stamp[sim & 1] == sim) {  // some arena reset in that step: `fraction` of every arena is re-snapshot (:498)
-      fr = S.sa[0] / K.cmd_thr_high;
+      fr = S.sa[0] / Rk.cmd_thr_high;
       if (valid && h == 0) B.cmd_fraction[la] = fr;
     }
     float u[4];
-    draw4(K, gid, (uint32_t)sim, PURPOSE_CMD, u);
-    level_command(TER ? tlevel : 0, fr, sim, normal_det(u[0], u[1]), K.cmd_dt, K.cmd_episode_s, S.cmd[0], S.cmd[2]);
+    draw4(T0, gid, (uint32_t)sim, PURPOSE_CMD, u);
+    level_command(TER ? tlevel : 0, fr, sim, normal_det(u[0], u[1]), Rk.cmd_dt, Rk.cmd_episode_s, S.cmd[0], S.cmd[2]);
     cmd_dirty = true;
   }
+  // [census: end]
   // FIFO transition memory: "states" of the first appended row = the observation the caller saw
   float o_prev[6] = {0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f};
   if (B.rp_size > 0) {
@@ -184,6 +194,9 @@ OIS_DEV void step_body(const DevConsts& K, const DevBuffers& B, const float* __r
 
   for (int s = 0; s < ksteps; ++s) {
     const bool last = s == ksteps - 1;
+    const TaskK T = late_task(kp);  // pre_physics_step's copy: dead before the first substep
+    const int A = T.action_dim;
+    // [phase: actions in (per step)]
     // ---- actions -> this lane's wheels (KA_DDPG_2D.py:623-624, KA_DDPG_1D.py:600-603) ----
     float a4[4] = {0.0f, 0.0f, 0.0f, 0.0f};
     if (policy == OIS_POLICY_EXTERNAL) {
@@ -191,13 +204,15 @@ OIS_DEV void step_body(const DevConsts& K, const DevBuffers& B, const float* __r
       if (A == 4) { unpack(*reinterpret_cast<const float4*>(ap), a4); }
       else if (A == 2) { const float2 t = *reinterpret_cast<const float2*>(ap); a4[0] = a4[1] = t.x; a4[2] = a4[3] = t.y; }
       else { a4[0] = a4[1] = a4[2] = a4[3] = ap[0]; }
+    // [census: not in the bench configuration: in-kernel random policy]
     } else if (policy == OIS_POLICY_RANDOM) {
       float u[4];
-      draw4(K, gid, (uint32_t)S.sim_steps, PURPOSE_ACTION, u);
+      draw4(T, gid, (uint32_t)S.sim_steps, PURPOSE_ACTION, u);
       if (A == 4) { a4[0] = u[0]; a4[1] = u[1]; a4[2] = u[2]; a4[3] = u[3]; }
       else if (A == 2) { a4[0] = a4[1] = u[0]; a4[2] = a4[3] = u[1]; }
       else { a4[0] = a4[1] = a4[2] = a4[3] = u[0]; }
     }
+    // [census: end]
     float aw[W];
 #pragma unroll
     for (int k = 0; k < W; ++k) {
@@ -207,22 +222,23 @@ OIS_DEV void step_body(const DevConsts& K, const DevBuffers& B, const float* __r
       const float lo = a4[k & 3], hi = a4[(2 + k) & 3];
       aw[k] = (LPA == 1) ? lo : (h ? hi : lo);
     }
+    // [phase: pre_physics_step: controller, gamma, switch draw, mix, clip (per step)]
     // ---- pre_physics_step (KAMMA.py:596-656) ----
     const float current_v = S.vfwd;      // :607
     const float current_omega = S.w[2];  // :608
     const float vd = S.cmd[0] - current_v;      // :609
     const float od = S.cmd[2] - current_omega;  // :610
-    const float lin = K.Kp * (K.vehicle_mass * (vd / K.policy_dt));            // :617
-    const float ang = K.Kp_omega * (K.vehicle_inertia * (od / K.policy_dt));
+    const float lin = T.Kp * (T.vehicle_mass * (vd / T.policy_dt));            // :617
+    const float ang = T.Kp_omega * (T.vehicle_inertia * (od / T.policy_dt));
     const float ac_left = lin - ang, ac_right = lin + ang;                     // :617, :619
-    float gs = 1.0f - ((float)S.sim_steps / K.max_sim_steps);                  // :627-628
+    float gs = 1.0f - ((float)S.sim_steps / T.max_sim_steps);                  // :627-628
     gs = gs < 0.0f ? 0.0f : gs;
-    const float gamma1 = K.gamma1_mode == OIS_GAMMA_CONST ? K.gamma1_const : gs;
-    const float gamma2 = K.gamma2_mode == OIS_GAMMA_CONST ? K.gamma2_const : gs;
+    const float gamma1 = T.gamma1_mode == OIS_GAMMA_CONST ? T.gamma1_const : gs;
+    const float gamma2 = T.gamma2_mode == OIS_GAMMA_CONST ? T.gamma2_const : gs;
     float rnd = 0.0f;
-    if (K.mix_mode == OIS_MIX_SWITCH) {
+    if (T.mix_mode == OIS_MIX_SWITCH) {
       float u[4];
-      draw4(K, gid, (uint32_t)S.sim_steps, PURPOSE_MASK, u);  // torch.rand(num_envs, 1) :633
+      draw4(T, gid, (uint32_t)S.sim_steps, PURPOSE_MASK, u);  // torch.rand(num_envs, 1) :633
       rnd = u[0];
     }
     float torq[W], wt[W], pol[W], d2[W], w2s[W];
@@ -230,22 +246,23 @@ OIS_DEV void step_body(const DevConsts& K, const DevBuffers& B, const float* __r
     for (int k = 0; k < W; ++k) {
       const bool left = (LPA == 1) ? (k < 2) : (h == 0);
       const float crit = left ? ac_left : ac_right;  // :624 order fl, rl, fr, rr
-      pol[k] = aw[k] * K.action_scale;
+      pol[k] = aw[k] * T.action_scale;
       float t;
-      if (K.mix_mode == OIS_MIX_SWITCH) {
+      if (T.mix_mode == OIS_MIX_SWITCH) {
         const float mask = rnd < gamma1 ? 1.0f : 0.0f;  // :634
         t = mask * crit + (1.0f - mask) * pol[k];        // :635
       } else {
-        t = ((1.0f - gamma1) * aw[k]) * K.action_scale + gamma1 * crit;  // KA_DDPG_4D.py:631
+        t = ((1.0f - gamma1) * aw[k]) * T.action_scale + gamma1 * crit;  // KA_DDPG_4D.py:631
       }
       torq[k] = t;
-      wt[k] = clipf(t, -K.torque_clip, K.torque_clip);  // :649
-      const float d = (K.guiding_mode == OIS_GUIDE_EXECUTED ? wt[k] : pol[k]) - crit;
+      wt[k] = clipf(t, -T.torque_clip, T.torque_clip);  // :649
+      const float d = (T.guiding_mode == OIS_GUIDE_EXECUTED ? wt[k] : pol[k]) - crit;
       d2[k] = d * d;
       w2s[k] = wt[k] * wt[k];
     }
     const float guiding = -sqrtf(sum_wheels<LPA>(d2));  // :656 / KA_DDPG_4D.py:637
-    if (K.eval_sums) {  // KAMMA_eval.py:677-685
+    // [census: not in the bench configuration: eval variants]
+    if (T.eval_sums) {  // KAMMA_eval.py:677-685
       float e2[W];
 #pragma unroll
       for (int k = 0; k < W; ++k) {
@@ -257,12 +274,15 @@ OIS_DEV void step_body(const DevConsts& K, const DevBuffers& B, const float* __r
       S.sc[2] += S.cmd[0] / 10.0f;
       S.sc[3] = 1.0f;
     }
+    // [census: end]
 #pragma unroll
     for (int k = 0; k < W; ++k) S.wt[k] = wt[k];
 
+    // [phase: substeps (the first one exact, the loop; + body <-> world glue)]
     // ---- physics: decimation (:646-653) + controlFrequencyInv (:43) substeps ----
     float R[9];
     bool blown = false;
+    const int kp_parked = kernarg_park(kp);
     {
       PhysT<LPA> X;
       float wb[3];
@@ -290,6 +310,7 @@ OIS_DEV void step_body(const DevConsts& K, const DevBuffers& B, const float* __r
         substep<true, LPA, TER, NIT>(K, B.ter, wheel0, X);
         for (int i = 1; i < K.nsub; ++i) substep<false, LPA, TER, NIT>(K, B.ter, wheel0, X);
       }
+      // [phase: after the substeps: binary16 rounding, finite check, rotation back (per step)]
       // safety net: a non-finite outcome (diverged reciprocal refresh of a violently tumbling
       // robot) is discarded: pre-step pose at rest, reset as fallen (oracle step_arena, SPEC §3.9)
       // the impulses cross a policy-step boundary in binary16, inside a fused rollout too (SPEC 3.5);
@@ -306,17 +327,13 @@ OIS_DEV void step_body(const DevConsts& K, const DevBuffers& B, const float* __r
       for (int k = 0; k < W; ++k) cw[k] = fabsf(X.spin[k]) + fabsf(X.ln[k]) + fabsf(X.l1[k]) + fabsf(X.l2[k]);
       chk += sum_wheels<LPA>(cw);
       blown = !(chk < 3.0e38f);
-      if (blown) {
-#pragma unroll
-        for (int k = 0; k < 3; ++k) { X.p[k] = S.p[k]; X.v[k] = 0.0f; X.wb[k] = 0.0f; }
-#pragma unroll
-        for (int k = 0; k < 4; ++k) X.q[k] = S.q[k];
-#pragma unroll
-        for (int k = 0; k < W; ++k) { X.spin[k] = 0.0f; X.ln[k] = 0.0f; X.l1[k] = 0.0f; X.l2[k] = 0.0f; }
-      }
+      // A blown arena is reset below (reset |= blown), and reset_arena overwrites every state value the oracle restores or
+      // zeroes for it here (pose, velocities, wheel speeds, impulses: oracle step_arena). What its metrics still see of
+      // this step's outcome is the yaw rate alone (ang_acc, prev_ang): zeroed after the rotation. The rest may hold NaN
+      // until reset_arena runs; no other lane reads it. (The per-value restore cost 54 register moves on every step.)
       rotmat(X.q, R);
       rot(R, X.wb, S.w);  // body -> world with the final orientation
-      if (blown) { S.w[0] = 0.0f; S.w[1] = 0.0f; S.w[2] = 0.0f; }  // R may be non-finite if the pose was corrupted from outside
+      S.w[2] = blown ? 0.0f : S.w[2];
 #pragma unroll
       for (int k = 0; k < 3; ++k) { S.p[k] = X.p[k]; S.v[k] = X.v[k]; }
 #pragma unroll
@@ -328,36 +345,40 @@ OIS_DEV void step_body(const DevConsts& K, const DevBuffers& B, const float* __r
       }
     }
 
+    // [phase: post_physics_step: is_done, calculate_metrics (per step)]
     // ---- post_physics_step (:674-727) ----
+    kp = kernarg_unpark(kp_parked);
+    const TaskK T2 = late_task(kp);  // its own copy: nothing of the task constants is held across the substeps
     S.ep_buf += 1;     // :675
     S.sim_steps += 1;  // :676
     // base-link position for the bounds check (:758-759)
-    const float plx = __builtin_fmaf(-R[2], K.com_height, S.p[0]);
-    const float ply = __builtin_fmaf(-R[5], K.com_height, S.p[1]);
+    const float plx = __builtin_fmaf(-R[2], T2.com_height, S.p[0]);
+    const float ply = __builtin_fmaf(-R[5], T2.com_height, S.p[1]);
     // is_done (:736-764)
-    const bool timeout = S.ep_buf >= K.max_episode_length - 1;  // :740-744
+    const bool timeout = S.ep_buf >= T2.max_episode_length - 1;  // :740-744
     float pg[3];
     quat_apply(S.q, 0.0f, 0.0f, -1.0f, pg);                      // :749
     const bool fallen = pg[2] > 0.0f;                            // :753
-    const bool oob = (plx < -K.bounds) | (plx > K.bounds) | (ply < -K.bounds) | (ply > K.bounds);
+    const bool oob = (plx < -T2.bounds) | (plx > T2.bounds) | (ply < -T2.bounds) | (ply > T2.bounds);
     const bool reset = fallen | timeout | oob | blown;
     // calculate_metrics (:767-822)
-    const float lin_acc = (current_v - S.prev_lin) / K.policy_dt;  // :770
-    const float ang_acc = (S.w[2] - S.prev_ang) / K.policy_dt;     // :771
+    const float lin_acc = (current_v - S.prev_lin) / T2.policy_dt;  // :770
+    const float ang_acc = (S.w[2] - S.prev_ang) / T2.policy_dt;     // :771
     S.prev_lin = current_v;                                        // :774
     S.prev_ang = S.w[2];                                           // :775
     const float r1 = vd * vd + 5.0f * (od * od);                   // :779
     const float r2 = lin_acc * lin_acc + ang_acc * ang_acc;        // :781
     const float r3 = sum_wheels<LPA>(w2s);                         // :783
-    const float c1 = K.w1 * r1, c2 = K.w2 * r2, c3 = K.w3 * r3;
+    const float c1 = T2.w1 * r1, c2 = T2.w2 * r2, c3 = T2.w3 * r3;
     const float rdense = (c1 + c2) + c3;                           // :786
-    const float sparse = (fabsf(vd) < K.sparse_threshold && fabsf(od) < K.sparse_threshold) ? K.sparse_bonus : 0.0f;
+    const float sparse = (fabsf(vd) < T2.sparse_threshold && fabsf(od) < T2.sparse_threshold) ? T2.sparse_bonus : 0.0f;
     const float observed = rdense + sparse;                        // :795
     float rew = (1.0f - gamma2) * observed + gamma2 * guiding;     // :798
-    rew += (K.terminal_reward * (reset ? 1.0f : 0.0f)) * (timeout ? -2.0f : -1.0f);  // :801 (~ on an int64 tensor)
+    rew += (T2.terminal_reward * (reset ? 1.0f : 0.0f)) * (timeout ? -2.0f : -1.0f);  // :801 (~ on an int64 tensor)
     S.sa[0] += c1; S.sa[1] += c2; S.sa[2] += c3; S.sa[3] += rdense;               // :803-806
     S.sb[0] += sparse; S.sb[1] += guiding; S.sb[2] += observed; S.sb[3] += rew;   // :807-810
-    if (K.eval_sums) S.sc[1] += fabsf(vd) / 10.0f;                 // KAMMA_eval.py:840
+    if (T2.eval_sums) S.sc[1] += fabsf(vd) / 10.0f;                 // KAMMA_eval.py:840
+    // [phase: reset_idx (rare: a lane that resets)]
     // reset_idx (:417-498)
     ResetContrib rc;
     contrib_identity(rc);
@@ -371,50 +392,58 @@ OIS_DEV void step_body(const DevConsts& K, const DevBuffers& B, const float* __r
         tor[0] = o[0]; tor[1] = o[1]; tor[2] = o[2];  // :529
       }
     }
-    if (reset) reset_arena<LPA>(K, gid, wheel0, gamma1, gamma2, S, rc);
+    if (reset) {
+      const ResetK Rk = late_reset(kp);
+      reset_arena<LPA>(T2, Rk, gid, wheel0, gamma1, gamma2, S, rc);
+    }
     cmd_dirty |= reset;
     if (!valid) contrib_identity(rc);
+    // [phase: get_observations (per step)]
     // get_observations (:833); desired_* are views of commands -> post-reset values; clamp: rl_task.py:99
-    const float co = K.clip_obs;
+    const float co = T2.clip_obs;
     const float ob[6] = {clipf(S.cmd[0], -co, co), clipf(S.cmd[2], -co, co), clipf(vd, -co, co),
                          clipf(od, -co, co),       clipf(lin_acc, -co, co),  clipf(ang_acc, -co, co)};
     // KAMMA_g1d_g21.py:838-842: get_observations replaces a (nearly) zero rew_buf[0] by 1e-12 before it is
     // returned; the episode sums above already hold the unmodified value. Global arena 0: a sharded run equals the
     // unsharded one (the env-0 diagnostics below stay per environment, i.e. per shard)
-    if (K.env0_reward_guard && gid == 0 && fabs((double)rew) < 1e-12) rew = 1e-12f;
+    if (T2.env0_reward_guard && gid == 0 && fabs((double)rew) < 1e-12) rew = 1e-12f;
     rsum += rew;
+    // [phase: transition memory row (only with a memory attached)]
     // FIFO transition memory row (train_kaddpg_4d_nofifo_random_RLIL.py:147-156; executed action:
     // base_KA_DDPG.py:212)
     if (B.rp_size > 0 && valid) {
+      const AuxPtrs X = kernarg_late<AuxPtrs, kArgB + (int)offsetof(DevBuffers, rp_states)>(kp);
       const size_t row = (size_t)((rp_head + s) % B.rp_size) * N + arena;
 #pragma unroll
-      for (int k = 0; k < W; ++k) B.rp_actions[row * 4 + wheel0 + k] = wt[k] / K.action_scale;
+      for (int k = 0; k < W; ++k) X.rp_actions[row * 4 + wheel0 + k] = wt[k] / T2.action_scale;
       if (h == 0) {
 #pragma unroll
-        for (int k = 0; k < 6; ++k) { B.rp_states[row * 6 + k] = o_prev[k]; B.rp_next[row * 6 + k] = ob[k]; }
-        B.rp_rewards[row] = rew;
-        B.rp_done[row] = reset ? 1 : 0;
+        for (int k = 0; k < 6; ++k) { X.rp_states[row * 6 + k] = o_prev[k]; X.rp_next[row * 6 + k] = ob[k]; }
+        X.rp_rewards[row] = rew;
+        X.rp_done[row] = reset ? 1 : 0;
       }
     }
 #pragma unroll
     for (int k = 0; k < 6; ++k) o_prev[k] = ob[k];
+    // [phase: outputs and env-0 diagnostics (last step of a launch)]
     // outputs (only the last step of a rollout is observable)
     // (Sending the [N, 6] observation rows through an LDS tile so that they leave as whole 128-byte lines — one float4
     // per lane instead of three float2 at a 24-byte stride — was built and measured in round 3: 9.42 vs 8.96 us for a
     // one-substep launch back to back, 36.25 vs 35.88 behind a cache sweep (profiles/r3_ab_flat_transposed.txt): the
     // barrier and the LDS round trip cost more than the partial-line stores, which L2 merges anyway. Not kept.)
     if (last && valid) {
+      const OutPtrs O = kernarg_late<OutPtrs, kArgB + (int)offsetof(DevBuffers, obs)>(kp);
       if (h == 0) {
-        float* o = B.obs + (size_t)arena * 6;
+        float* o = O.obs + (size_t)arena * 6;
         *reinterpret_cast<float2*>(o) = make_float2(ob[0], ob[1]);
         *reinterpret_cast<float2*>(o + 2) = make_float2(ob[2], ob[3]);
         *reinterpret_cast<float2*>(o + 4) = make_float2(ob[4], ob[5]);
-        B.rew[arena] = rew;
-        B.done[arena] = reset ? 1 : 0;
-        B.timeout[arena] = timeout ? 1 : 0;
+        O.rew[arena] = rew;
+        O.done[arena] = reset ? 1 : 0;
+        O.timeout[arena] = timeout ? 1 : 0;
       }
       if (arena == 0) {  // task.observed_components ingredients (:840-867)
-        float* d = B.env0_diag;
+        float* d = O.env0_diag;
         for (int k = 0; k < W; ++k) {
           const int gk = wheel0 + k;
           const int ti = gk < 2 ? 9 + gk : 11 + (gk - 2);  // torque_apl fl rl | fr rr at 9,10,11,12
@@ -426,68 +455,91 @@ OIS_DEV void step_body(const DevConsts& K, const DevBuffers& B, const float* __r
           d[6] = lin_acc; d[7] = ang_acc; d[8] = (float)S.ep_count;
           d[13] = ac_left; d[14] = ac_right;
           d[19] = gamma2; d[20] = c1; d[21] = c2; d[22] = c3; d[23] = rdense; d[24] = sparse; d[25] = observed;
-          d[26] = guiding; d[27] = rew; d[28] = gamma1;
+          d[26] = guiding; d[28] = gamma1;
+          // the percentages of observed_components divide by this value: the guard of KAMMA_g1d_g21.py:838-842 for the arena
+          // that LOGS, i.e. local arena 0 of every environment (on a shard, too, whose rew_buf[0] is not global arena 0's)
+          d[27] = (T2.env0_reward_guard && fabs((double)rew) < 1e-12) ? 1e-12f : rew;
         }
       }
     }
+    // [phase: projection tail (per step)]
     // tail of post_physics_step (:701-710) on the possibly reset state
     S.vfwd = forward_projection(S.q, S.v);
+    // [phase: reset-event records (rare: a wave with a resetting lane)]
     // per-group record of the reset event (extras["episode"], episode statistics)
     const unsigned long long m = __ballot(do_reset);
     if (m != 0ull) {
-      group_record<LPA>(B, arena / kGroup, lane, group_any<LPA>(m, lane), rc, S.sim_steps, true);
+      const OutPtrs O = kernarg_late<OutPtrs, kArgB + (int)offsetof(DevBuffers, obs)>(kp);
+      group_record<LPA>(O.partials, O.stamps, O.stat_acc, arena / kGroup, lane, group_any<LPA>(m, lane), rc, S.sim_steps, true);
       // any reset_idx call re-snapshots `fraction` of every arena (KAMMA.py:498): tell level_command_kernel
       // and zeroes old_torques of every arena (KAMMA_eval.py:470): tell the next step. Two slots by the parity of
       // the step count: a wave of the NEXT parity's launch never reads the slot this launch writes
-      if ((K.cmd_sampler == OIS_CMD_LEVEL || K.eval_sums) && lane == 0) B.reset_stamp[S.sim_steps & 1] = S.sim_steps;
+      if ((T2.cmd_sampler == OIS_CMD_LEVEL || T2.eval_sums) && lane == 0) {
+        const AuxPtrs X = kernarg_late<AuxPtrs, kArgB + (int)offsetof(DevBuffers, rp_states)>(kp);
+        X.reset_stamp[S.sim_steps & 1] = S.sim_steps;
+      }
     }
   }
+  // [phase: epilogue: state rows out (per launch)]
   if (valid) {
-    store_arena<LPA>(K, B, arena, h, S, cmd_dirty);
+    // the pointers of the stores come from the kernarg segment now, not from kernel entry through the substep loop
+    const RowPtrs Rp = kernarg_late<RowPtrs, kArgB + (int)offsetof(DevBuffers, pose)>(kp);
+    const WheelPtrs Wp = kernarg_late<WheelPtrs, kArgB + (int)offsetof(DevBuffers, wheel_vel)>(kp);
+    store_arena<LPA>(eval_sums, Rp, Wp, arena, h, S, cmd_dirty);
     if (reward_sum != nullptr && h == 0) reward_sum[arena] = rsum;
     if constexpr (TER) {
       if (B.ter.curriculum) {
-        B.env_origins[arena] = make_float4(tor[0], tor[1], tor[2], 0.0f);
-        B.terrain_idx[arena] = make_int4(tlevel, ttype, 0, 0);
+        Wp.env_origins[arena] = make_float4(tor[0], tor[1], tor[2], 0.0f);
+        Wp.terrain_idx[arena] = make_int4(tlevel, ttype, 0, 0);
       }
     }
   }
 }
 
-// Kernel shells around the same body. The plane kernel exists twice:
-//  * step_kernel     — the compiler's own register budget: 256 VGPRs + ~30 AGPRs of spill space,
-//    no scratch; one wave fills a SIMD. Launched while the arenas give at most one wave per SIMD
-//    anyway (N <= 65 536 on the 1024 SIMDs of an MI355X).
-//  * step_kernel_w2  — held to 256 registers (amdgpu_waves_per_eu(2, 2)): ~24 registers of cold
-//    per-step state go to scratch instead and two waves fit on a SIMD. Launched above that size
-//    (measured per policy step, packed: 60.9 -> 56.3 us at 131 072 arenas, 241 -> 219 at 524 288;
-//    scalar 92.9 -> 65.8 at 131 072).
-// At 65 536 arenas the two are equal in an env-only loop (38.3 vs 39.2 us per launch), but behind
-// the actor's GEMMs the scratch traffic of the second is cold: 59.3 vs 39.6 us per launch under
-// rocprofv3 (profiles/r1_waves_ab.txt), hence the size rule. OIS_STEP_WAVES=1|2 overrides it.
-// The terrain kernels lose 2-4 % under the limit (59-110 spills) and always keep the default.
+// Kernel shells around the same body. The plane kernel exists twice, and since round 4 the two differ in ONE thing,
+// how many waves the hardware may put on a SIMD (the body needs 224-238 registers in both, no scratch, no spill space):
+//  * step_kernel     — claims a register block > 256 of the SIMD's 512 (one_wave_per_simd below): one wave per SIMD,
+//    guaranteed. Launched while the arenas give at most one wave per SIMD anyway (N <= 65 536 on the 1024 SIMDs of an
+//    MI355X; the lane-pair kernel: N <= 32 768).
+//  * step_kernel_w2  — no claim: two waves fit a SIMD. Launched above that size (OIS_STEP_WAVES=1|2 overrides the rule).
+// Why the claim: a launch of 1024 waves that MAY double up does — not back to back, but behind the policy's kernels, whose
+// last waves are still draining when the launch starts: the dispatcher fills the CUs that are free with two waves per SIMD
+// and the launch takes 52 us instead of 36 (bench.py's actor loop, same binary, profiles/r4_ab_occupancy.txt). Rounds 1-3
+// had this by accident (264 registers) and had measured the same effect on the then-256-register w2 shell as "cold scratch
+// behind the GEMMs" (59 vs 40 us, profiles/r1_waves_ab.txt). The terrain kernels need 258-260 registers by themselves.
 //  * FLAT (the packed, 4-iteration shells only): every arena stands on the default plane n = (0, 0, 1) — no
 //    ois_randomize_params slopes since ois_create, no terrain: the host's knowledge (ois_env::flat) — so the
 //    substeps take n_b and n.p from R and p directly (-12 instructions per substep, ois_physics_pk.h).
 //  * FOLD (the packed, 4-iteration shells only): the continuation launches of a rollout under the per-level command
 //    curriculum, whose prologue re-draws the commands that follow the previous step (level_command_kernel's work).
+// Claims (without executing anything) an accumulation register high enough that the kernel's register block is > 256 of
+// the SIMD's 512: the hardware then cannot put a second wave of this kernel on a SIMD.
+template <int LPA>
+OIS_DEV void one_wave_per_simd() {
+  if (LPA == 1) asm volatile("" ::: "a63");   // 228 + 64
+  else asm volatile("" ::: "a95");            // the lane-pair body needs 176: + 96
+}
+
 template <int LPA, bool PK, int NIT, bool FLAT = false, bool FOLD = false>
 __global__ __launch_bounds__(kBlock) void step_kernel(DevConsts K, DevBuffers B, const float* __restrict__ actions,
                                                       float* __restrict__ reward_sum, int N, int ksteps, int policy,
                                                       int rp_head) {
-  step_body<LPA, PK, false, NIT, FLAT, FOLD>(K, B, actions, reward_sum, N, ksteps, policy, rp_head);
+#ifndef OIS_NO_OCCUPANCY_CLAIM
+  one_wave_per_simd<LPA>();
+#endif
+  step_body<LPA, PK, false, NIT, FLAT, FOLD>(K.phys, B, actions, reward_sum, N, ksteps, policy, rp_head);
 }
 template <bool PK, int NIT, bool FLAT = false, bool FOLD = false>
 __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(2, 2)))
 void step_kernel_w2(DevConsts K, DevBuffers B, const float* __restrict__ actions, float* __restrict__ reward_sum, int N,
                     int ksteps, int policy, int rp_head) {
-  step_body<1, PK, false, NIT, FLAT, FOLD>(K, B, actions, reward_sum, N, ksteps, policy, rp_head);
+  step_body<1, PK, false, NIT, FLAT, FOLD>(K.phys, B, actions, reward_sum, N, ksteps, policy, rp_head);
 }
 template <bool PK, int NIT, bool FOLD = false>
 __global__ __launch_bounds__(kBlock) void step_kernel_terrain(DevConsts K, DevBuffers B, const float* __restrict__ actions,
                                                               float* __restrict__ reward_sum, int N, int ksteps, int policy,
                                                               int rp_head) {
-  step_body<1, PK, true, NIT, false, FOLD>(K, B, actions, reward_sum, N, ksteps, policy, rp_head);
+  step_body<1, PK, true, NIT, false, FOLD>(K.phys, B, actions, reward_sum, N, ksteps, policy, rp_head);
 }
 
 // ------------------------------------------------------------------ get_heights -------
@@ -518,8 +570,8 @@ __global__ __launch_bounds__(256) void height_scan_kernel(DevConsts K, DevBuffer
     float R[9];
     rotmat(q, R);
     // base-link position in the world = arena-local COM - R com + tile origin
-    const float pwx = __builtin_fmaf(-R[2], K.com_height, po.x) + eo.x;
-    const float pwy = __builtin_fmaf(-R[5], K.com_height, po.y) + eo.y;
+    const float pwx = __builtin_fmaf(-R[2], K.task.com_height, po.x) + eo.x;
+    const float pwy = __builtin_fmaf(-R[5], K.task.com_height, po.y) + eo.y;
     float nrm = sqrtf(qu.x * qu.x + qu.w * qu.w);  // quat_apply_yaw: x, y zeroed, then normalize (:895-899)
     nrm = fmaxf(nrm, 1e-9f);
     rec[t] = make_float4(pwx, pwy, qu.x / nrm, qu.w / nrm);
@@ -646,17 +698,17 @@ __global__ __launch_bounds__(kBlock) void reset_kernel(DevConsts K, DevBuffers B
   S.vfwd = S.prev_lin = S.prev_ang = S.mu = 0.0f;
   S.ep_buf = S.sim_steps = S.ep_count = 0;
   // gamma_assist1/2 hold their constructor values here (KAMMA.py:192-193: ones)
-  const float g1 = K.gamma1_mode == OIS_GAMMA_CONST ? K.gamma1_const : 1.0f;
-  const float g2 = K.gamma2_mode == OIS_GAMMA_CONST ? K.gamma2_const : 1.0f;
+  const float g1 = K.task.gamma1_mode == OIS_GAMMA_CONST ? K.task.gamma1_const : 1.0f;
+  const float g2 = K.task.gamma2_mode == OIS_GAMMA_CONST ? K.task.gamma2_const : 1.0f;
   ResetContrib rc;
-  reset_arena<1>(K, K.arena_offset + la, 0, g1, g2, S, rc);
+  reset_arena<1>(K.task, K.reset, K.task.arena_offset + la, 0, g1, g2, S, rc);
   if (!valid) contrib_identity(rc);
   if ((lane & (kGroup - 1)) == 0 && valid) {  // clear the finished-episode accumulators of this group
     double* Acc = B.stat_acc + (size_t)(arena / kGroup) * 8;
     for (int k = 0; k < 4; ++k) { Acc[k] = 0.0; Acc[4 + k] = -__builtin_inf(); }
   }
   const unsigned long long m = __ballot(valid);
-  group_record<1>(B, arena / kGroup, lane, group_any<1>(m, lane), rc, 0, false);
+  group_record<1>(B.partials, B.stamps, B.stat_acc, arena / kGroup, lane, group_any<1>(m, lane), rc, 0, false);
   if (valid) {
     // params are owned by ois_create / ois_randomize_params: keep them
     B.pose[arena] = make_float4(S.p[0], S.p[1], S.p[2], S.vfwd);
@@ -687,14 +739,14 @@ __global__ __launch_bounds__(256) void level_command_kernel(DevConsts K, DevBuff
   const int sim = B.counters[i].y;  // == episode_step_counter: policy steps since post_reset
   float fr = B.cmd_fraction[i];
   if (B.reset_stamp[sim & 1] == sim) {
-    fr = B.sums_a[i].x / K.cmd_thr_high;
+    fr = B.sums_a[i].x / K.reset.cmd_thr_high;
     B.cmd_fraction[i] = fr;
   }
   float u[4];
-  draw4(K, K.arena_offset + i, (uint32_t)sim, PURPOSE_CMD, u);
+  draw4(K.task, K.task.arena_offset + i, (uint32_t)sim, PURPOSE_CMD, u);
   const int level = B.ter.on ? B.terrain_idx[i].x : 0;  // zeros without a terrain (KAMMA.py:223)
   float cx, cw;
-  level_command(level, fr, sim, normal_det(u[0], u[1]), K.cmd_dt, K.cmd_episode_s, cx, cw);
+  level_command(level, fr, sim, normal_det(u[0], u[1]), K.reset.cmd_dt, K.reset.cmd_episode_s, cx, cw);
   float4 c = B.commands[i];
   c.x = cx; c.z = cw;
   B.commands[i] = c;
@@ -705,7 +757,7 @@ __global__ __launch_bounds__(256) void push_robots_kernel(DevConsts K, DevBuffer
   const int i = blockIdx.x * 256 + threadIdx.x;
   if (i >= N) return;
   float u[4];
-  draw4(K, K.arena_offset + i, (uint32_t)B.counters[i].y, PURPOSE_PUSH, u);
+  draw4(K.task, K.task.arena_offset + i, (uint32_t)B.counters[i].y, PURPOSE_PUSH, u);
   float4 v = B.linvel[i];
   v.x = rand_float(-1.0f, 1.0f, u[0]);
   v.y = rand_float(-1.0f, 1.0f, u[1]);
@@ -723,7 +775,7 @@ __global__ void randomize_params_kernel(DevConsts K, DevBuffers B, int N, float 
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= N) return;
   float u[4];
-  draw4(K, K.arena_offset + i, 0u, PURPOSE_PARAMS, u);
+  draw4(K.task, K.task.arena_offset + i, 0u, PURPOSE_PARAMS, u);
   float nx = 0.0f, ny = 0.0f, nz = 1.0f;
   if (n_slopes > 0) {
     int idx = (int)(u[1] * (float)n_slopes);
@@ -839,7 +891,7 @@ __global__ __launch_bounds__(64) void logs_kernel(DevConsts K, DevBuffers B, int
   const float cnt = __shfl(a, 0, 64), v = __shfl(a, src, 64);
   float out = 0.0f;
   if ((s >= OIS_EI_R1 && s <= OIS_EI_OBSERVED_OVER_FINAL) || (s >= OIS_EI_SMOOTHNESS && s <= OIS_EI_DESIRED_VELOCITY))
-    out = (v / cnt) / K.episode_length_s;                            // :482-484
+    out = (v / cnt) / K.reset.episode_length_s;                            // :482-484
   else if (s == OIS_EI_COUNT || s == OIS_EI_GAMMA1 || s == OIS_EI_GAMMA2) out = v;  // :486, :487
   else if (s == OIS_EI_TERRAIN_LEVEL) out = (float)tot / (float)N;   // :488 (zeros without a terrain, :223)
   else if (s == OIS_EI_STEP) out = (float)smax;
@@ -1031,56 +1083,60 @@ int validate(const ois_config* c) {
 // same derivation, same float operations as the oracle's derive() (docs/SPEC.md §3.0)
 void derive(const ois_config* c, DevConsts* K) {
   std::memset(K, 0, sizeof *K);
-  K->dt = c->sim_dt;
-  K->inv_dt = 1.0f / c->sim_dt;
-  K->gdt = c->gravity * c->sim_dt;
-  K->half_dt = 0.5f * c->sim_dt;
-  K->im4 = 4.0f / c->body_mass;
-  K->imq = 0.25f * K->im4;  // exact: the inverse mass seen by the average over the 4 contacts
-  K->J4x = 4.0f / c->body_inertia[0];
-  K->J4y = 4.0f / c->body_inertia[1];
-  K->J4z = 4.0f / c->body_inertia[2];
-  K->dt_over_Is = c->sim_dt / c->wheel_spin_inertia;
-  K->dt_over_Iy = c->sim_dt / c->body_inertia[1];
-  K->rw = c->wheel_radius;
-  K->rw_over_Is = c->wheel_radius / c->wheel_spin_inertia;
-  K->rw2_over_Is = (c->wheel_radius * c->wheel_radius) / c->wheel_spin_inertia;
-  K->beta_inv_dt = c->baumgarte * K->inv_dt;
-  K->vdep = c->max_depenetration_velocity;
-  K->maxw = c->max_angular_velocity;
-  K->maxw2 = c->max_angular_velocity * c->max_angular_velocity;
-  K->damping = c->wheel_damping;
-  K->wlim = c->wheel_limit_velocity;
-  K->climit = c->wheel_limit_damping;
-  K->wx = c->wheel_pos[0];
-  K->wy = c->wheel_pos[1];
-  K->cz = c->wheel_pos[2] - c->com_height;
-  K->com_height = c->com_height;
-  K->inv4wx = 1.0f / (4.0f * c->wheel_pos[0]);
-  K->inv4wy = 1.0f / (4.0f * c->wheel_pos[1]);
-  K->iters = c->solver_iterations;
-  K->nsub = c->decimation + c->extra_substeps;
-  K->Kp = c->Kp; K->Kp_omega = c->Kp_omega; K->vehicle_mass = c->vehicle_mass; K->vehicle_inertia = c->vehicle_inertia;
-  K->policy_dt = c->policy_dt; K->action_scale = c->action_scale; K->torque_clip = c->torque_clip;
-  K->w1 = c->w1; K->w2 = c->w2; K->w3 = c->w3; K->sparse_bonus = c->sparse_bonus; K->sparse_threshold = c->sparse_threshold;
-  K->terminal_reward = c->terminal_reward; K->max_sim_steps = c->max_sim_steps;
-  K->gamma1_const = c->gamma1_const; K->gamma2_const = c->gamma2_const; K->bounds = c->bounds; K->clip_obs = c->clip_obs;
-  K->episode_length_s = c->episode_length_s; K->eval_ramp_steps = c->eval_ramp_steps;
-  K->cmd_x_lo = c->cmd_x_lo; K->cmd_x_hi = c->cmd_x_hi; K->cmd_y_lo = c->cmd_y_lo; K->cmd_y_hi = c->cmd_y_hi;
-  K->cmd_yaw_lo = c->cmd_yaw_lo; K->cmd_yaw_hi = c->cmd_yaw_hi; K->spawn_xy_range = c->spawn_xy_range;
-  K->cmd_x_span = c->cmd_x_span; K->cmd_y_span = c->cmd_y_span; K->cmd_yaw_span = c->cmd_yaw_span;
-  for (int k = 0; k < 3; ++k) { K->init_pos[k] = c->init_pos[k]; K->init_lin_vel[k] = c->init_lin_vel[k]; K->init_ang_vel[k] = c->init_ang_vel[k]; }
-  for (int k = 0; k < 4; ++k) { K->init_quat[k] = c->init_quat[k]; K->init_dof_vel[k] = c->init_dof_vel[k]; }
-  K->action_dim = c->action_dim; K->mix_mode = c->mix_mode; K->gamma1_mode = c->gamma1_mode; K->gamma2_mode = c->gamma2_mode;
-  K->guiding_mode = c->guiding_mode; K->cmd_sampler = c->cmd_sampler; K->eval_sums = c->eval_sums;
-  K->max_episode_length = c->max_episode_length;
-  K->env0_reward_guard = c->env0_reward_guard;
-  K->seed_lo = (uint32_t)(c->seed & 0xffffffffu);
-  K->seed_hi = (uint32_t)(c->seed >> 32);
-  K->arena_offset = c->arena_offset;
-  K->cmd_dt = (double)c->decimation * (double)c->sim_dt;  // self.dt, a Python double (KAMMA.py:260)
-  K->cmd_episode_s = (double)c->episode_length_s;
-  K->cmd_thr_high = c->curriculum_threshold_high;
+  K->phys.dt = c->sim_dt;
+  K->phys.inv_dt = 1.0f / c->sim_dt;
+  K->phys.gdt = c->gravity * c->sim_dt;
+  K->phys.half_dt = 0.5f * c->sim_dt;
+  K->phys.im4 = 4.0f / c->body_mass;
+  K->phys.imq = 0.25f * K->phys.im4;  // exact: the inverse mass seen by the average over the 4 contacts
+  K->phys.J4x = 4.0f / c->body_inertia[0];
+  K->phys.J4y = 4.0f / c->body_inertia[1];
+  K->phys.J4z = 4.0f / c->body_inertia[2];
+  K->phys.dt_over_Is = c->sim_dt / c->wheel_spin_inertia;
+  K->phys.dt_over_Iy = c->sim_dt / c->body_inertia[1];
+  K->phys.rw = c->wheel_radius;
+  K->phys.rw_over_Is = c->wheel_radius / c->wheel_spin_inertia;
+  K->phys.rw2_over_Is = (c->wheel_radius * c->wheel_radius) / c->wheel_spin_inertia;
+  K->phys.beta_inv_dt = c->baumgarte * K->phys.inv_dt;
+  K->phys.vdep = c->max_depenetration_velocity;
+  K->phys.maxw = c->max_angular_velocity;
+  K->phys.maxw2 = c->max_angular_velocity * c->max_angular_velocity;
+  K->phys.damping = c->wheel_damping;
+  K->phys.wlim = c->wheel_limit_velocity;
+  K->phys.climit = c->wheel_limit_damping;
+  K->phys.wx = c->wheel_pos[0];
+  K->phys.wy = c->wheel_pos[1];
+  K->phys.cz = c->wheel_pos[2] - c->com_height;
+  K->task.com_height = c->com_height;
+  K->phys.inv4wx = 1.0f / (4.0f * c->wheel_pos[0]);
+  K->phys.inv4wy = 1.0f / (4.0f * c->wheel_pos[1]);
+  K->phys.iters = c->solver_iterations;
+  K->phys.nsub = c->decimation + c->extra_substeps;
+  K->task.Kp = c->Kp; K->task.Kp_omega = c->Kp_omega; K->task.vehicle_mass = c->vehicle_mass; K->task.vehicle_inertia = c->vehicle_inertia;
+  K->task.policy_dt = c->policy_dt; K->task.action_scale = c->action_scale; K->task.torque_clip = c->torque_clip;
+  K->task.w1 = c->w1; K->task.w2 = c->w2; K->task.w3 = c->w3; K->task.sparse_bonus = c->sparse_bonus; K->task.sparse_threshold = c->sparse_threshold;
+  K->task.terminal_reward = c->terminal_reward; K->task.max_sim_steps = c->max_sim_steps;
+  K->task.gamma1_const = c->gamma1_const; K->task.gamma2_const = c->gamma2_const; K->task.bounds = c->bounds; K->task.clip_obs = c->clip_obs;
+  K->reset.episode_length_s = c->episode_length_s; K->reset.eval_ramp_steps = c->eval_ramp_steps;
+  K->reset.cmd_x_lo = c->cmd_x_lo; K->reset.cmd_x_hi = c->cmd_x_hi; K->reset.cmd_y_lo = c->cmd_y_lo; K->reset.cmd_y_hi = c->cmd_y_hi;
+  K->reset.cmd_yaw_lo = c->cmd_yaw_lo; K->reset.cmd_yaw_hi = c->cmd_yaw_hi; K->reset.spawn_xy_range = c->spawn_xy_range;
+  K->reset.cmd_x_span = c->cmd_x_span; K->reset.cmd_y_span = c->cmd_y_span; K->reset.cmd_yaw_span = c->cmd_yaw_span;
+  K->reset.init_pos0 = c->init_pos[0]; K->reset.init_pos1 = c->init_pos[1]; K->reset.init_pos2 = c->init_pos[2];
+  K->reset.init_quat0 = c->init_quat[0]; K->reset.init_quat1 = c->init_quat[1]; K->reset.init_quat2 = c->init_quat[2]; K->reset.init_quat3 = c->init_quat[3];
+  K->reset.init_lin_vel0 = c->init_lin_vel[0]; K->reset.init_lin_vel1 = c->init_lin_vel[1]; K->reset.init_lin_vel2 = c->init_lin_vel[2];
+  K->reset.init_ang_vel0 = c->init_ang_vel[0]; K->reset.init_ang_vel1 = c->init_ang_vel[1]; K->reset.init_ang_vel2 = c->init_ang_vel[2];
+  K->reset.init_dof_vel0 = c->init_dof_vel[0]; K->reset.init_dof_vel1 = c->init_dof_vel[1];
+  K->reset.init_dof_vel2 = c->init_dof_vel[2]; K->reset.init_dof_vel3 = c->init_dof_vel[3];
+  K->task.action_dim = c->action_dim; K->task.mix_mode = c->mix_mode; K->task.gamma1_mode = c->gamma1_mode; K->task.gamma2_mode = c->gamma2_mode;
+  K->task.guiding_mode = c->guiding_mode; K->task.cmd_sampler = c->cmd_sampler; K->task.eval_sums = c->eval_sums;
+  K->task.max_episode_length = c->max_episode_length;
+  K->task.env0_reward_guard = c->env0_reward_guard;
+  K->task.seed_lo = (uint32_t)(c->seed & 0xffffffffu);
+  K->task.seed_hi = (uint32_t)(c->seed >> 32);
+  K->task.arena_offset = c->arena_offset;
+  K->reset.cmd_dt = (double)c->decimation * (double)c->sim_dt;  // self.dt, a Python double (KAMMA.py:260)
+  K->reset.cmd_episode_s = (double)c->episode_length_s;
+  K->reset.cmd_thr_high = c->curriculum_threshold_high;
 }
 
 }  // namespace
@@ -1338,8 +1394,8 @@ int ois_reset(ois_env* e, uint64_t seed, void* stream) {
   if (!e) return fail(OIS_EINVAL, "null env");
   OIS_ON_DEVICE(e->device);
   e->seed = seed;
-  e->K.seed_lo = (uint32_t)(seed & 0xffffffffu);
-  e->K.seed_hi = (uint32_t)(seed >> 32);
+  e->K.task.seed_lo = (uint32_t)(seed & 0xffffffffu);
+  e->K.task.seed_hi = (uint32_t)(seed >> 32);
   hipLaunchKernelGGL(reset_kernel, dim3(e->grid), dim3(kBlock), 0, (hipStream_t)stream, e->K, e->B, e->N);
   HIP_TRY(hipGetLastError());
   e->reset_done = true;
@@ -1398,7 +1454,7 @@ static int launch_kernel(ois_env* e, int k, int policy, const float* actions, fl
   } while (0)
   // instantiations: lanes per arena (2 = experiment), packed wheel pairs, height-field terrain
   // (ois_terrain_attach refuses LPA = 2), solver iterations unrolled (the default 4) or run-time
-  const bool it4 = e->K.iters == 4;
+  const bool it4 = e->K.phys.iters == 4;
   const bool flat = e->flat && e->packed && it4 && !e->B.ter.on;  // the FLAT shells exist for the default configuration
   if ((policy & 0x200) != 0) {  // continuation launch of a level-curriculum rollout (can_fold() said these shells exist)
     if (e->B.ter.on) OIS_LAUNCH((step_kernel_terrain<true, 4, true>), 1);
@@ -1435,8 +1491,8 @@ static int launch_kernel(ois_env* e, int k, int policy, const float* actions, fl
 }
 
 static int launch_steps(ois_env* e, int k, int policy, const float* actions, float* reward_sum, void* stream) {
-  const bool level = e->K.cmd_sampler == OIS_CMD_LEVEL;
-  if (!level && !(e->K.eval_sums && k > 1)) return launch_kernel(e, k, policy, actions, reward_sum, stream);
+  const bool level = e->K.task.cmd_sampler == OIS_CMD_LEVEL;
+  if (!level && !(e->K.task.eval_sums && k > 1)) return launch_kernel(e, k, policy, actions, reward_sum, stream);
   // per-level command curriculum: the commands of all arenas are re-drawn between two policy steps
   // from a quantity that depends on every arena of the step before (level_command_kernel), so a
   // rollout is k launches of one step. The eval variants' Smoothness
@@ -1445,9 +1501,9 @@ static int launch_steps(ois_env* e, int k, int policy, const float* actions, flo
   // The command launch is only needed for what the caller can see: inside a rollout the NEXT step's launch does that work
   // in its prologue (bit 9, the FOLD shells of step_body), so a rollout of k steps is k + 1 launches instead of 2 k. The FOLD
   // shells exist for the packed, 4-iteration configuration (the default); any other keeps the launch pairs.
-  const bool fold = level && e->packed && e->K.iters == 4;
+  const bool fold = level && e->packed && e->K.phys.iters == 4;
   for (int s = 0; s < k; ++s) {
-    const float* a = (policy == OIS_POLICY_EXTERNAL) ? actions + (size_t)s * e->N * e->K.action_dim : actions;
+    const float* a = (policy == OIS_POLICY_EXTERNAL) ? actions + (size_t)s * e->N * e->K.task.action_dim : actions;
     int rc = launch_kernel(e, 1, policy | (s > 0 ? 0x100 : 0) | ((fold && s > 0) ? 0x200 : 0), a, reward_sum, stream);
     if (rc != OIS_OK) return rc;
     if (level && (!fold || s == k - 1)) {
@@ -1488,7 +1544,7 @@ int ois_step(ois_env* e, const float* actions_device, void* stream) {
   if (!e) return fail(OIS_EINVAL, "null env");
   if (!actions_device) return fail(OIS_EINVAL, "null actions");
   if (!e->reset_done) return fail(OIS_ESTATE, "ois_step called before ois_reset");
-  if (((uintptr_t)actions_device & (uintptr_t)(4 * e->K.action_dim - 1)) != 0)
+  if (((uintptr_t)actions_device & (uintptr_t)(4 * e->K.task.action_dim - 1)) != 0)
     return fail(OIS_EINVAL, "actions must be aligned to action_dim * 4 bytes (one vector load per arena)");
   int rc = launch_steps(e, 1, OIS_POLICY_EXTERNAL, actions_device, nullptr, stream);
   if (rc != OIS_OK || !e->logs_on) return rc;
@@ -1505,7 +1561,7 @@ int ois_rollout(ois_env* e, int k, int policy, const float* actions_device, floa
   if (k < 1 || k > (1 << 20)) return fail(OIS_EINVAL, "k out of range");
   if (policy < OIS_POLICY_ZERO || policy > OIS_POLICY_EXTERNAL) return fail(OIS_EINVAL, "unknown policy");
   if (policy == OIS_POLICY_EXTERNAL && !actions_device) return fail(OIS_EINVAL, "EXTERNAL policy needs actions");
-  if (policy == OIS_POLICY_EXTERNAL && ((uintptr_t)actions_device & (uintptr_t)(4 * e->K.action_dim - 1)) != 0)
+  if (policy == OIS_POLICY_EXTERNAL && ((uintptr_t)actions_device & (uintptr_t)(4 * e->K.task.action_dim - 1)) != 0)
     return fail(OIS_EINVAL, "actions must be aligned to action_dim * 4 bytes (one vector load per arena)");
   if (!e->reset_done) return fail(OIS_ESTATE, "ois_rollout called before ois_reset");
   return launch_steps(e, k, policy, actions_device, reward_sum_device, stream);
@@ -1526,8 +1582,8 @@ int ois_randomize_params(ois_env* e, float mu_lo, float mu_hi, const float* slop
   float* tbl = (float*)(e->ws + e->L.stat_out);  // scratch shared with ois_stats_fetch
   if (n_slopes > 0) HIP_TRY(hipMemcpyAsync(tbl, slopes_host, (size_t)n_slopes * sizeof(float), hipMemcpyHostToDevice, (hipStream_t)stream));
   DevConsts K = e->K;  // keyed by the CONFIG seed: arena parameters do not change with ois_reset(seed)
-  K.seed_lo = (uint32_t)(e->cfg.seed & 0xffffffffu);
-  K.seed_hi = (uint32_t)(e->cfg.seed >> 32);
+  K.task.seed_lo = (uint32_t)(e->cfg.seed & 0xffffffffu);
+  K.task.seed_hi = (uint32_t)(e->cfg.seed >> 32);
   hipLaunchKernelGGL(randomize_params_kernel, dim3((e->N + 255) / 256), dim3(256), 0, (hipStream_t)stream, K, e->B, e->N,
                      mu_lo, mu_hi, tbl, n_slopes);
   HIP_TRY(hipGetLastError());
@@ -1536,9 +1592,15 @@ int ois_randomize_params(ois_env* e, float mu_lo, float mu_hi, const float* slop
   return OIS_OK;
 }
 
+int ois_params_dirty(ois_env* e) {
+  if (!e) return fail(OIS_EINVAL, "null env");
+  e->flat = false;
+  return OIS_OK;
+}
+
 int ois_kernel_info(const ois_env* e, char* out, size_t cap) {
   if (!e || !out || cap == 0) return fail(OIS_EINVAL, "null argument");
-  const bool it4 = e->K.iters == 4;
+  const bool it4 = e->K.phys.iters == 4;
   const bool flat = e->flat && e->packed && it4 && !e->B.ter.on;
   const int nit = it4 ? 4 : 0, pk = e->packed ? 1 : 0;
   char id[64];
@@ -1548,7 +1610,7 @@ int ois_kernel_info(const ois_env* e, char* out, size_t cap) {
   else std::snprintf(id, sizeof id, "step_kernel<1,%d,%d,%d>", pk, nit, flat ? 1 : 0);
   std::snprintf(out, cap, "%s lanes_per_arena=%d %s iterations=%s plane=%s%s", id, e->B.ter.on ? 1 : e->lpa,
                 e->packed ? "packed" : "scalar", it4 ? "4(unrolled)" : "runtime", e->B.ter.on ? "height-field" : (flat ? "flat" : "per-arena"),
-                e->K.cmd_sampler == OIS_CMD_LEVEL ? " +level_command_kernel" : "");
+                e->K.task.cmd_sampler == OIS_CMD_LEVEL ? " +level_command_kernel" : "");
   return OIS_OK;
 }
 
@@ -1561,7 +1623,7 @@ int ois_terrain_attach(ois_env* e, const ois_terrain* t, const int16_t* heights_
   e->logs_current = false;  // the terrain-level mean of extras["episode"] changes with the attachment
   if (!t) {  // detach: back to the per-arena plane, origins and indices cleared
     std::memset(&e->B.ter, 0, sizeof e->B.ter);
-    e->K.cmd_sampler = e->cfg.cmd_sampler;
+    e->K.task.cmd_sampler = e->cfg.cmd_sampler;
     pick_lpa(e);
     HIP_TRY(hipMemsetAsync(e->B.env_origins, 0, f4, s));
     HIP_TRY(hipMemsetAsync(e->B.terrain_idx, 0, f4, s));
@@ -1615,9 +1677,9 @@ int ois_terrain_attach(ois_env* e, const ois_terrain* t, const int16_t* heights_
   T.thr_lo = t->threshold_low; T.thr_hi = t->threshold_high;
   e->tdesc = *t;
   // terrain.curriculum also switches the commands to the per-level generators (KAMMA.py:533, 719)
-  e->K.cmd_sampler = t->curriculum ? OIS_CMD_LEVEL : e->cfg.cmd_sampler;
+  e->K.task.cmd_sampler = t->curriculum ? OIS_CMD_LEVEL : e->cfg.cmd_sampler;
   pick_lpa(e);
-  if (t->curriculum && !(e->K.cmd_thr_high > 0.0f)) e->K.cmd_thr_high = 10.0f;
+  if (t->curriculum && !(e->K.reset.cmd_thr_high > 0.0f)) e->K.reset.cmd_thr_high = 10.0f;
   return OIS_OK;
 }
 
@@ -1834,7 +1896,7 @@ int ois_save_state(ois_env* e, void* host_blob, size_t bytes, void* stream) {
   h.magic = 0x3053494fu /* "OIS0" */; h.abi = OIS_ABI_VERSION; h.num_envs = e->N; h.reset_done = e->reset_done ? 1 : 0;
   h.seed = e->seed; h.steps_done = e->steps_done; h.payload = e->L.total;
   h.config_hash = fnv1a(&e->cfg, sizeof e->cfg); h.terrain_hash = terrain_hash(e);
-  h.rp_size = e->B.rp_size; h.rp_head = e->rp_head; h.rp_filled = e->rp_filled ? 1 : 0; h.cmd_sampler = e->K.cmd_sampler;
+  h.rp_size = e->B.rp_size; h.rp_head = e->rp_head; h.rp_filled = e->rp_filled ? 1 : 0; h.cmd_sampler = e->K.task.cmd_sampler;
   h.plane_flat = e->flat ? 1 : 0;
   std::memcpy(host_blob, &h, sizeof h);
   HIP_TRY(hipMemcpyAsync((char*)host_blob + sizeof h, e->ws, e->L.total, hipMemcpyDeviceToHost, (hipStream_t)stream));
@@ -1863,8 +1925,8 @@ int ois_load_state(ois_env* e, const void* host_blob, size_t bytes, void* stream
   e->reset_done = h.reset_done != 0;
   e->logs_current = false;
   e->seed = h.seed;
-  e->K.seed_lo = (uint32_t)(h.seed & 0xffffffffu);
-  e->K.seed_hi = (uint32_t)(h.seed >> 32);
+  e->K.task.seed_lo = (uint32_t)(h.seed & 0xffffffffu);
+  e->K.task.seed_hi = (uint32_t)(h.seed >> 32);
   e->steps_done = h.steps_done;
   e->rp_head = h.rp_head; e->rp_filled = h.rp_filled != 0;
   e->flat = e->flat_allowed && h.plane_flat != 0;  // the params rows came with the blob

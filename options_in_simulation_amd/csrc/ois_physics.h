@@ -93,7 +93,7 @@ struct Footprints {
   int px[4], py[4];
 };
 template <bool FRESH, int LPA>
-OIS_DEV void terrain_footprints(const DevConsts& K, const DevTerrain& T, const PhysT<LPA>& S, const float* R, Footprints& F) {
+OIS_DEV void terrain_footprints(const PhysK& K, const DevTerrain& T, const PhysT<LPA>& S, const float* R, Footprints& F) {
   const float* origin = S.to;
   const float* p = S.p;
 #pragma unroll
@@ -121,7 +121,7 @@ OIS_DEV void footprints_store(PhysT<LPA>& S, const Footprints& F) {
 }
 // plane through the stored footprints: unit normal n (world), off[k] = n . footprint_k
 template <int LPA>
-OIS_DEV void terrain_plane(const DevConsts& K, const PhysT<LPA>& S, float* n, float* off) {
+OIS_DEV void terrain_plane(const PhysK& K, const PhysT<LPA>& S, float* n, float* off) {
   const float* h = S.fh;
   const float g1 = ((h[0] + h[2]) - (h[1] + h[3])) * K.inv4wx;  // front - rear (order fl, rl, fr, rr)
   const float g2 = ((h[0] + h[1]) - (h[2] + h[3])) * K.inv4wy;  // left - right
@@ -146,7 +146,7 @@ OIS_DEV float average4(const float (&c)[4 / LPA]) { return 0.25f * sum_wheels<LP
 // NIT: solver iterations known at compile time (the loop is fully unrolled: no taken branch,
 // scheduling across iteration boundaries) or 0 = K.iters at run time
 template <bool EXACT, int LPA, bool TER = false, int NIT = 0>
-OIS_DEV void substep(const DevConsts& K, const DevTerrain& T, int wheel0, PhysT<LPA>& S) {
+OIS_DEV void substep(const PhysK& K, const DevTerrain& T, int wheel0, PhysT<LPA>& S) {
   static_assert(!TER || LPA == 1, "the terrain contact needs all 4 wheels in one lane");
   constexpr int W = 4 / LPA;
 #define OIS_WH _Pragma("unroll") for (int k = 0; k < W; ++k)

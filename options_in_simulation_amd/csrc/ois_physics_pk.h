@@ -57,7 +57,7 @@ OIS_DEV f2 newton_rcp2(f2 m, f2 k) {
 // the host knows): n_b is the third row of R and n.p is p_z; the 12 instructions that multiply by the zero components of n
 // are not issued (SPEC 3.2: the same IEEE values, a zero may carry the other sign).
 template <bool EXACT, bool TER = false, int NIT = 0, bool FLAT = false>
-OIS_DEV void substep_pk(const DevConsts& K, const DevTerrain& T, PhysT<1>& S) {
+OIS_DEV void substep_pk(const PhysK& K, const DevTerrain& T, PhysT<1>& S) {
   static_assert(!(FLAT && TER), "the height field has its own plane");
 #define OIS_PR _Pragma("unroll") for (int j = 0; j < 2; ++j)
   float R[9];
@@ -244,7 +244,7 @@ OIS_DEV void substep_pk(const DevConsts& K, const DevTerrain& T, PhysT<1>& S) {
 OIS_DEV float sum_side(f2 c) { return side_sum<2>(c.x + c.y); }
 
 template <bool EXACT, int NIT = 0, bool FLAT = false>
-OIS_DEV void substep_pk2(const DevConsts& K, int wheel0, PhysT<2>& S) {
+OIS_DEV void substep_pk2(const PhysK& K, int wheel0, PhysT<2>& S) {
   float R[9];
   rotmat(S.q, R);
   float vb[3], nb[3], wb[3] = {S.wb[0], S.wb[1], S.wb[2]};

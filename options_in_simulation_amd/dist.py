@@ -69,12 +69,15 @@ def merge_stats(parts: List[_abi.OisStats]) -> dict:
             "return_std": var ** 0.5, "length_mean": sum(p.length_sum for p in parts) / n}
 
 
-def gather_episode_info(info, num_envs: int, device=None, group=None) -> Dict[str, float]:
+def gather_episode_info(info, num_envs: int, device=None, group=None, eval_keys: bool = True,
+                        single_gamma: bool = False) -> Dict[str, float]:
     """Global ``extras["episode"]`` (KAMMA.py:480-488) from the per-rank vectors of
     ``ois_episode_info`` with ONE all-gather of 33 floats per rank: the per-key means of the
     most recent reset event are re-weighted by each rank's count of resetting arenas (ranks whose
     newest event is older than the global newest do not contribute), ``terrain_level`` by the
-    ranks' arena counts, gamma is taken from a contributing rank."""
+    ranks' arena counts, gamma is taken from a contributing rank. Keys and their order: ``_abi.episode_info_layout`` for
+    the variant (``single_gamma``: the KA-DDPG files log one ``"gamma assist"``, KA_DDPG_4D.py:484; ``eval_keys``: the three
+    sums of the eval files) — the same dict a single-rank ``infos["episode"]`` has."""
     vec = torch.as_tensor(info, dtype=torch.float64).flatten().cpu()
     mine = torch.cat([vec[:_abi.EPISODE_INFO_LEN], torch.tensor([float(num_envs)], dtype=torch.float64)])
     if dist.is_available() and dist.is_initialized():
@@ -90,14 +93,14 @@ def gather_episode_info(info, num_envs: int, device=None, group=None) -> Dict[st
     cnt = torch.where(step == step.max(), rows[:, _abi.EI_COUNT], torch.zeros_like(step))
     total = float(cnt.sum())
     merged: Dict[str, float] = {}
-    keys = dict(_abi.EPISODE_INFO_KEYS)
-    keys.update(_abi.EPISODE_INFO_EVAL_KEYS)
     lead = int(torch.argmax(cnt))
-    for slot, key in keys.items():
-        if key in ("gamma_1 action assist", "gamma_2 reward assist"):
+    for key, slot in _abi.episode_info_layout(eval_keys, single_gamma):
+        if slot in (16, 17):
             merged[key] = float(rows[lead, slot])
-        elif key == "terrain_level":
+        elif slot == _abi.EI_TERRAIN_LEVEL:
             merged[key] = float((rows[:, slot] * rows[:, -1]).sum() / rows[:, -1].sum())
+        elif slot == 31:
+            merged[key] = 0.0
         else:
             merged[key] = float((rows[:, slot] * cnt).sum() / total) if total > 0 else float("nan")
     merged["count"] = total

@@ -181,6 +181,11 @@ class NativeEnv:
         ptr = s.ctypes.data_as(C.POINTER(C.c_float)) if s.size else None
         _native.check(self.L.ois_randomize_params(self.h, mu_lo, mu_hi, ptr, int(s.size), _stream_ptr(self.device)))
 
+    def params_written(self):
+        """call after writing plane NORMALS into ``buffer(BUF_PARAMS)`` yourself: the flat-plane kernels do not read
+        them (ois_params_dirty; friction, column 0, needs no call)"""
+        _native.check(self.L.ois_params_dirty(self.h))
+
     def push_robots(self):
         """push_robots (KAMMA.py:729-733): linear velocity x, y of every arena <- U(-1, 1)"""
         _native.check(self.L.ois_push_robots(self.h, _stream_ptr(self.device)))

@@ -1323,7 +1323,9 @@ static float step_arena(orc_env* e, int i, const float* act /*[A]*/, uint8_t* rs
     for (int k = 0; k < 4; ++k) { d[9 + k] = torques[k]; d[15 + k] = c->action_scale * a4[k]; }
     d[13] = ac_left; d[14] = ac_right;
     d[19] = gamma2; d[20] = mo.comp1; d[21] = mo.comp2; d[22] = mo.comp3; d[23] = mo.rdense; d[24] = mo.rsparse;
-    d[25] = mo.robs; d[26] = guiding; d[27] = mo.rew; d[28] = gamma1;
+    d[25] = mo.robs; d[26] = guiding; d[28] = gamma1;
+    /* the divisor of the env-0 percentages: guarded for the arena that logs = local arena 0 of every environment, shards too */
+    d[27] = (c->env0_reward_guard && fabs((double)mo.rew) < 1e-12) ? 1e-12f : mo.rew;
   }
   *g1_out = gamma1; *g2_out = gamma2;
   return mo.rew;

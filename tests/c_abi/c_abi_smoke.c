@@ -22,8 +22,13 @@
     if (e_ != hipSuccess) { fprintf(stderr, "%s: %s\n", #x, hipGetErrorString(e_)); return 1; }       \
   } while (0)
 
-int main(void) {
+int main(int argc, char** argv) {
   const int N = 1000;
+  const int device = argc > 1 ? atoi(argv[1]) : 0; /* the ordinal the environment lives on (workspace, stream, actions) */
+  int ndev = 0;
+  HIP(hipGetDeviceCount(&ndev));
+  if (device < 0 || device >= ndev) { fprintf(stderr, "device %d of %d\n", device, ndev); return 1; }
+  HIP(hipSetDevice(device));
   ois_config cfg;
   CHECK(ois_config_default(&cfg));
   cfg.num_envs = N;
@@ -36,7 +41,8 @@ int main(void) {
   hipStream_t stream;
   HIP(hipStreamCreate(&stream));
   ois_env* env = NULL;
-  CHECK(ois_create(&cfg, 0, ws, bytes, &env));
+  if (ois_create(&cfg, ndev, ws, bytes, &env) != OIS_EINVAL) { fprintf(stderr, "device ordinal out of range not refused\n"); return 1; }
+  CHECK(ois_create(&cfg, device, ws, bytes, &env));
   if (ois_step(env, (const float*)ws, stream) != OIS_ESTATE) { fprintf(stderr, "step before reset not refused\n"); return 1; }
   CHECK(ois_reset(env, 5, stream));
   char info[256];
@@ -113,6 +119,6 @@ int main(void) {
   ois_destroy(env);
   HIP(hipFree(d_act)); HIP(hipFree(d_sum)); HIP(hipFree(ws));
   free(h_act); free(h_obs); free(h_cnt); free(h_sum); free(blob);
-  printf("c abi ok: %d arenas, %.0f episodes, mean return %.3f\n", N, st.episodes, st.return_sum / st.episodes);
+  printf("c abi ok: %d arenas, %.0f episodes, mean return %.3f on device %d\n", N, st.episodes, st.return_sum / st.episodes, device);
   return 0;
 }

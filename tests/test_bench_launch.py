@@ -78,3 +78,20 @@ def test_world_size_mismatch_is_an_error_not_a_silent_run():
                          env=_clean_env(RANK="0", LOCAL_RANK="0", WORLD_SIZE="1", OIS_BENCH_DRYRUN="1"),
                          capture_output=True, text=True, timeout=300)
     assert res.returncode != 0 and "WORLD_SIZE" in (res.stderr + res.stdout)
+
+
+def test_fewer_gpus_than_ranks_fails_before_the_rendezvous():
+    """`--gpus N` with RCCL on a box with fewer than N visible GPUs: every rank exits non-zero BEFORE it joins the process group
+    (a lone rank 0 started here would otherwise wait for its peers until the rendezvous times out) and rank 0 says which rank
+    would have used which device and arenas. Here: no GPU at all, world size 2, only rank 0 started."""
+    import time
+    t0 = time.time()
+    res = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1"],
+                         env=_clean_env(RANK="0", LOCAL_RANK="0", WORLD_SIZE="2", MASTER_ADDR="127.0.0.1", MASTER_PORT="29533"),
+                         capture_output=True, text=True, timeout=300)
+    assert res.returncode == 3 and time.time() - t0 < 120
+    err = json.loads([l for l in res.stderr.splitlines() if l.startswith("{")][-1])
+    assert "needs 2 visible GPUs" in err["error"] and "device_count() = 0" in err["error"]
+    assert [(r["rank"], r["device"], r["present"], r["arena_offset"], r["arenas"]) for r in err["rank_table"]] == \
+        [(0, 0, False, 0, 65536), (1, 1, False, 65536, 65536)]
+    assert not [l for l in res.stdout.splitlines() if l.startswith("{")]

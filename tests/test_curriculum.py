@@ -232,6 +232,72 @@ def test_level_curriculum_without_terrain_and_task_surface():
     env.close()
 
 
+@pytest.mark.gpu
+@pytest.mark.parametrize("N,waves", [(64, None), (40000, None), (70000, None), (40000, "2")], ids=["lane-pair", "one-lane", "two-waves", "one-lane-forced-w2"])
+@pytest.mark.parametrize("ground", ["flat", "slopes"])
+def test_level_curriculum_rollouts_on_the_plane_fold_shells(N, waves, ground, monkeypatch):
+    """the per-level command curriculum WITHOUT a terrain — the only one the reference's TASK_CFG can express —
+    in fused rollouts: k > 1 makes launch_steps() set bit 9 (the continuation-launch flag), i.e. the six plane FOLD shells
+    (step_kernel<1|2, true, 4, flat|general, true>, step_kernel_w2<true, 4, *, true>) do the previous step's command re-draw
+    in their prologue. Against the oracle, bit for bit, every state buffer + the reward sums: EXTERNAL and RANDOM policy; an
+    arena falling in the FIRST step of a rollout (the next launch's fold must take the fraction re-snapshot from S.sa[0] of
+    every arena), another falling one step before a rollout (the stamp of the other parity), a synchronous timeout inside a
+    rollout (6-step episodes); flat and after ois_randomize_params with slopes (the general shells)."""
+    from options_in_simulation_amd.vecenv import NativeEnv
+    if waves:
+        monkeypatch.setenv("OIS_STEP_WAVES", waves)
+    cfg = build_config(variant="KAMMA_medium", num_envs=N, seed=13, max_sim_steps=300.0, cmd_sampler=_abi.CMD_LEVEL, max_episode_length=7)
+    dev, orc = NativeEnv(cfg, "cuda:0"), OracleEnv(cfg)
+    if ground == "slopes":
+        sl = [-0.3, -0.2, 0.0, 0.2, 0.3]
+        dev.randomize_params(0.5, 1.0, sl); orc.randomize_params(0.5, 1.0, sl)
+    info = dev.kernel_info()
+    assert ("plane=flat" in info) == (ground == "flat") and "+level_command_kernel" in info
+    assert info.startswith("step_kernel<2," if N == 64 else ("step_kernel_w2<" if (N > 65536 or waves == "2") else "step_kernel<1,"))
+    dev.reset(13); orc.reset(13)
+    same_state(dev, orc, "post_reset")
+    rng = np.random.default_rng(4)
+    up = np.array([0.0, 1.0, 0.0, 0.0], np.float32)
+
+    def fall(i):
+        orc.buffer(_abi.BUF_QUAT)[i] = up
+        dev.buffer(_abi.BUF_QUAT)[i] = torch.from_numpy(up).cuda()
+
+    # 1. EXTERNAL actions, an arena falling in the first step of the rollout
+    fall(N // 3)
+    acts = rng.uniform(0, 1, (4, N, 4)).astype(np.float32)
+    rs = torch.zeros(N, device="cuda:0")
+    dev.rollout(4, _abi.POLICY_EXTERNAL, torch.from_numpy(acts).cuda(), reward_sum=rs)
+    ref = orc.rollout(4, _abi.POLICY_EXTERNAL, acts, want_reward_sum=True)
+    same_state(dev, orc, "external rollout with a fall in its first step")
+    assert np.array_equal(rs.cpu().numpy(), ref) and orc.buffer(_abi.BUF_CMD_FRACTION).any()
+    # 2. a single step in which an arena falls, then a RANDOM-policy rollout that crosses the synchronous timeout
+    fall(N - 1)
+    a = rng.uniform(0, 1, (N, 4)).astype(np.float32)
+    dev.step(torch.from_numpy(a).cuda()); orc.step(a)
+    same_state(dev, orc, "single step with a fall")
+    rs = torch.zeros(N, device="cuda:0")
+    dev.rollout(5, _abi.POLICY_RANDOM, reward_sum=rs)
+    ref = orc.rollout(5, _abi.POLICY_RANDOM, None, want_reward_sum=True)
+    same_state(dev, orc, "random rollout across the timeout")
+    assert np.array_equal(rs.cpu().numpy(), ref)
+    cnt = orc.buffer(_abi.BUF_COUNTERS)
+    assert (cnt[:, 2] >= 2).all(), "every arena has finished an episode inside the rollouts"
+    # 3. rollouts == single steps (the fold changes launches, not results)
+    blob = dev.save_state()
+    acts = rng.uniform(0, 1, (3, N, 4)).astype(np.float32)
+    dev.rollout(3, _abi.POLICY_EXTERNAL, torch.from_numpy(acts).cuda())
+    fused = {b: dev.buffer(b).clone() for b in STATE}
+    dev.load_state(blob)
+    for k in range(3):
+        dev.step(torch.from_numpy(acts[k]).cuda())
+    for b in STATE:
+        assert torch.equal(dev.buffer(b), fused[b]), b
+    orc.rollout(3, _abi.POLICY_EXTERNAL, acts)
+    same_state(dev, orc, "single steps after load_state")
+    dev.close()
+
+
 def test_eval_sampling_refuses_a_curriculum_terrain():
     """the *_eval files test `evalsampling` before `curriculum` (KAMMA_eval.py:544): with both set the per-step re-draw of
     KAMMA.py:719-725 would hand out the eval ramp, which nothing here implements: refused, not silently different"""

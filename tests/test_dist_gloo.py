@@ -69,10 +69,8 @@ def test_two_rank_sharded_run_matches_single_process(tmp_path):
     assert merged[4] == total * steps and merged[5] == 99.0
     # the merged extras of the two shards = the extras of the unsharded run (same reset event)
     ei = full.episode_info()
-    ref = {key: float(ei[slot]) for slot, key in _abi.EPISODE_INFO_KEYS.items()}
+    ref = {key: float(ei[slot]) for key, slot in _abi.episode_info_layout(True, False)}   # the key set a single-rank infos["episode"] has
     ref["count"], ref["step"] = float(ei[_abi.EI_COUNT]), float(ei[_abi.EI_STEP])
-    for slot, key in _abi.EPISODE_INFO_EVAL_KEYS.items():
-        ref[key] = float(ei[slot])
     got = dict(zip(sorted(ref), np.load(tmp_path / "info.npy")))
     assert got["count"] == ref["count"] > 0 and got["step"] == ref["step"]
     for key in ref:
@@ -89,6 +87,18 @@ def test_gather_without_process_group_is_identity():
     vec = np.zeros(_abi.EPISODE_INFO_LEN); vec[_abi.EI_COUNT], vec[_abi.EI_STEP], vec[8], vec[16] = 4, 99, -2.5, 0.75
     one = gather_episode_info(vec, 16)
     assert one["rew_Final reward"] == -2.5 and one["gamma_1 action assist"] == 0.75 and one["count"] == 4 and one["step"] == 99
+    # the KA-DDPG files log ONE key "gamma assist" (KA_DDPG_4D.py:484): a sharded run's merged dict has the key set
+    # and ORDER of the single-rank infos["episode"] of its variant, which is the reference's dict order (KAMMA.py:204-221, 480-488)
+    ka = gather_episode_info(vec, 16, eval_keys=False, single_gamma=True)
+    assert ka["gamma assist"] == 0.75 and "gamma_1 action assist" not in ka and "gamma_2 reward assist" not in ka
+    assert list(ka)[:-2] == [k for k, _ in _abi.episode_info_layout(False, True)] and list(ka)[-2:] == ["count", "step"]
+    order = [k for k, _ in _abi.episode_info_layout(True, False)]
+    assert order[:3] == ["rew_r1: Tracking error reward (squared errors)", "rew_r2: Convergence reward (squared accelerations)",
+                         "rew_r3: Torque penalty (sum of squared torques)"]
+    assert order[11:15] == list(_abi.EPISODE_INFO_ZERO_KEYS) and order[15:18] == ["rew_Smoothness", "rew_Tracking error", "rew_Desired velocity"]
+    assert order[18:22] == ["rew_Dense/Final reward", "rew_Sparse/Final reward", "rew_Guiding/Final reward", "rew_Observed/Final reward"]
+    assert order[22:] == ["gamma_1 action assist", "gamma_2 reward assist", "terrain_level"]
+    assert [k for k, _ in _abi.episode_info_layout(False, True)][-2:] == ["gamma assist", "terrain_level"]
 
 
 def test_merge_stats_std_at_half_a_million_episodes():
@@ -167,10 +177,8 @@ def test_two_product_shards_on_gloo_match_the_unsharded_product_run(tmp_path):
     assert merged[3] == st.return_min and merged[4] == st.return_max
     assert merged[5] == total * steps and merged[6] == 99.0
     ei = full.episode_info().cpu().numpy()
-    ref = {key: float(ei[slot]) for slot, key in _abi.EPISODE_INFO_KEYS.items()}
+    ref = {key: float(ei[slot]) for key, slot in _abi.episode_info_layout(True, False)}   # the key set a single-rank infos["episode"] has
     ref["count"], ref["step"] = float(ei[_abi.EI_COUNT]), float(ei[_abi.EI_STEP])
-    for slot, key in _abi.EPISODE_INFO_EVAL_KEYS.items():
-        ref[key] = float(ei[slot])
     got = dict(zip(sorted(ref), np.load(tmp_path / "info.npy")))
     assert got["count"] == ref["count"] == total and got["step"] == ref["step"] == 198
     for key in ref:
@@ -200,6 +208,7 @@ def _run_shards(make, variant, total, bounds, steps, seed, falls, **kw):
         out.append({k: np.concatenate([e.get(bid) for e in envs]) for k, bid in
                     (("sums_c", _abi.BUF_SUMS_C), ("rew", _abi.BUF_REW), ("done", _abi.BUF_DONE), ("commands", _abi.BUF_COMMANDS),
                      ("fraction", _abi.BUF_CMD_FRACTION), ("pose", _abi.BUF_POSE))})
+        out[-1]["diag_rew"] = np.array([e.get(_abi.BUF_ENV0_DIAG)[27] for e in envs])   # the divisor of each environment's env-0 percentages
     return out
 
 
@@ -257,8 +266,7 @@ def test_level_curriculum_fraction_is_per_environment_on_the_oracle():
 
 
 def test_env0_reward_guard_goes_by_global_arena_id_on_the_oracle():
-    total, steps = 8, 60
-    kw = dict(max_sim_steps=40.0)   # gamma1 reaches 0 quickly... the guard needs rew == 0: gamma2 = 1 and unclipped expert torques
+    total, steps = 8, 60   # the guard needs rew == 0: gamma2 = 1 (constant in this variant) and an unclipped expert torque executed
     whole = _run_shards(_OrcShard, "KAMMA_g1d_g21", total, [(0, total)], steps, 3, {})
     split = _run_shards(_OrcShard, "KAMMA_g1d_g21", total, [(0, 4), (4, total)], steps, 3, {})
     guarded = [t for t in range(steps) if whole[t]["rew"][0] == np.float32(1e-12)]
@@ -266,7 +274,15 @@ def test_env0_reward_guard_goes_by_global_arena_id_on_the_oracle():
     for t in range(steps):
         assert np.array_equal(whole[t]["rew"], split[t]["rew"]), t          # shard-invariant
         assert not (split[t]["rew"][4] == np.float32(1e-12))                # local arena 0 of shard 1 is global arena 4: not guarded
-    del kw
+    # ... while the env-0 DIAGNOSTICS are per environment, and so is the guard of their divisor: the arena that logs on
+    # shard 1 is global arena 4, whose reward is exactly 0 on some steps; observed_components must not divide by it
+    zero4 = [t for t in range(steps) if whole[t]["rew"][4] == 0.0]
+    assert zero4, "arena 4's reward is never exactly 0: lengthen the run"
+    for t in zero4:
+        assert split[t]["diag_rew"][1] == np.float32(1e-12) and split[t]["rew"][4] == 0.0
+    from options_in_simulation_amd.vecenv import observed_components_from_diag
+    d = np.zeros(32, np.float32); d[27], d[19], d[20] = split[zero4[0]]["diag_rew"][1], 1.0, -0.5
+    assert all(np.isfinite(v) for v in observed_components_from_diag(d).values())
 
 
 @pytest.mark.gpu

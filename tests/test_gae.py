@@ -82,8 +82,10 @@ def test_kernel_matches_fixture_and_oracle_bit_exact():
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("T,N", [(1, 1), (7, 300), (16, 65536), (96, 4099)])
+@pytest.mark.parametrize("T,N", [(1, 1), (2, 1), (7, 300), (16, 65536), (16, 4099), (20, 65536), (32, 40000), (33, 5000), (96, 4099), (16, 200000)])
 def test_kernel_vs_oracle_sizes(T, N):
+    """incl. the reference's rollouts of 16 and 20 steps at 65 536 arenas, a ragged last wave, and both normalisation paths: the
+    normalise kernel summing the per-wave moments itself (<= 2048 waves) and the separate moments kernel (200 000 arenas)"""
     from options_in_simulation_amd import compute_advantages_and_returns, compute_gae
     rng = np.random.default_rng(T * 1000 + N)
     r = rng.normal(size=(T, N, 1)).astype(np.float32)

@@ -416,9 +416,13 @@ def test_c_abi_from_plain_c(tmp_path):
     subprocess.run(["gcc", "-std=c11", "-O1", "-D__HIP_PLATFORM_AMD__", "-I/opt/rocm/include", "-I" + os.path.join(root, "include"),
                     "-o", exe, os.path.join(root, "tests", "c_abi", "c_abi_smoke.c"), "-L" + libdir, "-lois_hip", "-L/opt/rocm/lib",
                     "-lamdhip64", "-Wl,-rpath," + libdir, "-Wl,-rpath,/opt/rocm/lib", "-lm"], check=True, capture_output=True)
-    res = subprocess.run([exe], capture_output=True, text=True, timeout=120)
-    assert res.returncode == 0, res.stdout + res.stderr
-    assert "c abi ok: 1000 arenas, 1000 episodes" in res.stdout
+    means = []
+    for device in range(torch.cuda.device_count()):  # every ordinal this box has: one today, eight on the scaling node
+        res = subprocess.run([exe, str(device)], capture_output=True, text=True, timeout=120)
+        assert res.returncode == 0, res.stdout + res.stderr
+        assert "c abi ok: 1000 arenas, 1000 episodes" in res.stdout and res.stdout.strip().endswith(f"on device {device}")
+        means.append(res.stdout.split("mean return")[1].split()[0])
+    assert len(set(means)) == 1  # the same numbers on every GPU
 
 
 # ---------------------------------------------------------------------------------------------------------------------

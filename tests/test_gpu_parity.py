@@ -34,11 +34,11 @@ EXACT_BUFS = [_abi.BUF_COUNTERS, _abi.BUF_DONE, _abi.BUF_TIMEOUT]
 RTOL, ATOL = 1e-5, 1e-6
 
 
-def make_pair(**kw):
+def make_pair(device="cuda:0", **kw):
     from options_in_simulation_amd.vecenv import NativeEnv
     from oracle.binding import OracleEnv
     cfg = build_config(**kw)
-    return cfg, NativeEnv(cfg, "cuda:0"), OracleEnv(cfg)
+    return cfg, NativeEnv(cfg, device), OracleEnv(cfg)
 
 
 def compare(dev, orc, where="", exact_float=False):
@@ -214,6 +214,36 @@ def test_sharding_invariance():
     for bid in STATE_BUFS + EXACT_BUFS:
         assert torch.equal(full.buffer(bid)[N // 2:] if full.buffer(bid).shape[0] == N else full.buffer(bid),
                            half.buffer(bid) if half.buffer(bid).shape[0] == N // 2 else full.buffer(bid))
+
+
+def test_caller_written_plane_normals_after_params_dirty():
+    """OIS_BUF_PARAMS is writable, but the flat-plane kernels take n = (0, 0, 1) without reading it. A caller that
+    does its own domain randomisation by writing normals says so (ois_params_dirty -> the general kernels); friction alone
+    (column 0) needs no call. Kernel == oracle, which always honours the written rows."""
+    N = 300
+    cfg, dev, orc = make_pair(variant="KAMMA_medium", num_envs=N, seed=17)
+    rng = np.random.default_rng(6)
+    prm = np.zeros((N, 4), np.float32)
+    prm[:, 0] = rng.uniform(0.5, 1.0, N)
+    prm[:, 3] = 1.0
+    dev.buffer(_abi.BUF_PARAMS).copy_(torch.from_numpy(prm)); orc.buffer(_abi.BUF_PARAMS)[:] = prm
+    assert "plane=flat" in dev.kernel_info()          # friction only: still the flat shells
+    dev.reset(17); orc.reset(17)
+    a = rng.uniform(0, 1, (N, 4)).astype(np.float32)
+    for t in range(4):
+        dev.step(torch.from_numpy(a).cuda()); orc.step(a)
+    compare(dev, orc, "own friction", exact_float=True)
+    sl = rng.choice([-0.3, 0.0, 0.2], N).astype(np.float32)
+    th = rng.uniform(0, np.pi, N).astype(np.float32)
+    inv = (1.0 / np.sqrt(sl * sl + 1.0)).astype(np.float32)
+    prm[:, 1], prm[:, 2], prm[:, 3] = -(sl * np.cos(th)) * inv, -(sl * np.sin(th)) * inv, inv
+    dev.buffer(_abi.BUF_PARAMS).copy_(torch.from_numpy(prm)); orc.buffer(_abi.BUF_PARAMS)[:] = prm
+    dev.params_written()
+    assert "plane=per-arena" in dev.kernel_info()
+    for t in range(6):
+        dev.step(torch.from_numpy(a).cuda()); orc.step(a)
+    compare(dev, orc, "own normals", exact_float=True)
+    assert not np.array_equal(orc.buffer(_abi.BUF_POSE)[:, 2], np.full(N, orc.buffer(_abi.BUF_POSE)[0, 2]))
 
 
 def test_save_load_state_roundtrip():
@@ -512,6 +542,42 @@ def test_host_log_caches_follow_reset_and_load_state():
     _, _, _, _, infos = env.step(a)
     assert "rew_Final reward" in infos["episode"]
     env.close()
+
+
+def test_every_device_ordinal_of_the_box():
+    """What a multi-GPU node must not be the first to run: on EVERY ordinal torch sees (one on the test box, eight on the
+    scaling node — the round-end GPUTEST then covers them all) the step parity against the oracle, the partition
+    invariance of a shard living on that device against the whole on device 0, the published host logs, and the caller's
+    current device left alone."""
+    from options_in_simulation_amd.vecenv import NativeEnv
+    ndev = torch.cuda.device_count()
+    assert ndev >= 1
+    N = 200
+    full = NativeEnv(build_config(variant="KAMMA_medium", num_envs=N, seed=5), "cuda:0")
+    full.reset(5)
+    rng = np.random.default_rng(3)
+    acts = rng.uniform(0, 1, size=(6, N, 4)).astype(np.float32)
+    for a in acts:
+        full.step(torch.from_numpy(a).to("cuda:0"))
+    for d in range(ndev):
+        dev_name = f"cuda:{d}"
+        torch.cuda.set_device(0)
+        cfg, dev, orc = make_pair(device=dev_name, variant="KAMMA_medium", num_envs=N, seed=11, max_sim_steps=60.0)
+        dev.reset(11); orc.reset(11)
+        for t, a in enumerate(acts):
+            dev.step(torch.from_numpy(a).to(dev_name)); orc.step(a)
+            compare(dev, orc, f"{dev_name} step {t}", exact_float=True)
+        np.testing.assert_array_equal(dev.host_logs()[0], orc.episode_info())
+        assert dev.buffer(_abi.BUF_OBS).device.index == d and torch.cuda.current_device() == 0
+        half = NativeEnv(build_config(variant="KAMMA_medium", num_envs=N // 2, seed=5, arena_offset=N // 2), dev_name)
+        half.reset(5)
+        for a in acts:
+            half.step(torch.from_numpy(a[N // 2:]).to(dev_name))
+        for bid in STATE_BUFS + EXACT_BUFS:
+            assert torch.equal(full.buffer(bid)[N // 2:].cpu(), half.buffer(bid).cpu()), (dev_name, bid)
+        s1 = dev.stats()
+        assert s1.steps == 6 * N
+        dev.close(); half.close()
 
 
 def test_entry_points_restore_the_callers_device():

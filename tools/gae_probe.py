@@ -37,16 +37,34 @@ def timeit(fn, iters):
     return e0.elapsed_time(e1) * 1e3 / iters  # us
 
 
+def direct(r, d, v, lv, normalize):
+    """ois_gae itself with preallocated outputs (the wrapper's three allocations cost more host time than the kernel runs)"""
+    import ctypes as C
+    from options_in_simulation_amd import _native
+    L = _native.load()
+    T, N = r.shape[0], r.shape[1]
+    ret, adv = torch.empty_like(r), torch.empty_like(r)
+    nb = L.ois_gae_scratch_bytes(N)
+    scratch = torch.empty(nb // 8, dtype=torch.float64, device=r.device)
+    d8 = d.view(torch.uint8)
+    stream = torch.cuda.current_stream().cuda_stream
+    return lambda: L.ois_gae(0, T, N, r.data_ptr(), d8.data_ptr(), v.data_ptr(), lv.data_ptr(), 0.99, 0.95, int(normalize),
+                             ret.data_ptr(), adv.data_ptr(), scratch.data_ptr(), nb, stream)
+
+
 out = []
-for T, N in [(16, 65536), (96, 65536), (1024, 65536), (16, 524288)]:
+for T, N in [(16, 65536), (20, 65536), (32, 65536), (96, 65536), (1024, 65536), (16, 524288)]:
     r = torch.randn((T, N, 1), device="cuda"); v = torch.randn((T, N, 1), device="cuda")
     lv = torch.randn((N, 1), device="cuda"); d = torch.rand((T, N, 1), device="cuda") < 0.05
-    us_raw = timeit(lambda: compute_gae(r, d, v, lv, normalize=False), 50)
-    us_norm = timeit(lambda: compute_gae(r, d, v, lv), 50)
+    us_raw = timeit(direct(r, d, v, lv, False), 200)
+    us_norm = timeit(direct(r, d, v, lv, True), 200)
+    us_wrapped = timeit(lambda: compute_gae(r, d, v, lv), 50)
     us_ref = timeit(lambda: torch_loop(r, d, v, lv), 3 if T > 100 else 10)
     n = T * N
     out.append({"T": T, "N": N, "us_scan": round(us_raw, 1), "GBps_scan": round(17 * n / us_raw / 1e3, 1),
-                "us_scan_plus_normalize": round(us_norm, 1), "GBps_total": round(25 * n / us_norm / 1e3, 1),
+                "us_scan_plus_normalize": round(us_norm, 1), "launches_normalized": 2 if N <= 2048 * 64 else 3,
+                "GBps_total": round(25 * n / us_norm / 1e3, 1),
+                "us_through_the_python_wrapper": round(us_wrapped, 1),
                 "us_torch_loop": round(us_ref, 1), "speedup_vs_torch_loop": round(us_ref / us_norm, 1)})
     print(json.dumps(out[-1]), flush=True)
 json.dump(out, open("gpurun_out/gae_probe.json", "w"), indent=1)

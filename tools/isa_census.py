@@ -4,7 +4,13 @@ assembly with the Makefile's flags and prints, per kernel, registers / scratch /
 instruction count of the substep loop (the depth-2 loop of the fused rollout) by class.
     python tools/isa_census.py [kernel-name-substring ...]      default: step_kernelILi1ELb1ELi4
     python tools/isa_census.py --json profiles/r4_isa_census.json      every step-kernel instantiation, keyed by the id
-                                                                         ois_kernel_info reports, with the kernel-source hash
+                                                                         ois_kernel_info reports, with the kernel-source hash,
+                                                                         + the phase table of the headline instantiation
+    python tools/isa_census.py --phases [kernel-name-substring]        where the instructions of ONE policy step are: every
+        instruction of the kernel attributed — through the line table (-gline-tables-only: same code) and its inlined-at
+        chain — to the phase of step_body it was written in (the `// [phase: ...]` markers of csrc/ois_kernels.hip), the
+        substep loop apart; regions the bench configuration does not execute (`// [census: not in the bench configuration]`,
+        phases marked rare / only) listed but not summed
 """
 import os, re, subprocess, sys, tempfile
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -96,9 +102,90 @@ def census(asm, want, quiet=False):
     return out
 
 
+def phase_table(want="step_kernelILi1ELb1ELi4ELb1ELb0"):
+    """{phase: {...}} for the first kernel whose mangled name contains `want` + the executed totals of a launch of k steps"""
+    src_path = os.path.join(CSRC, "ois_kernels.hip")
+    src = open(src_path).read().split("\n")
+    phases, skips, cur_skip = [], [], None  # (first line, name); (first line, last line, why)
+    body0 = next(i for i, l in enumerate(src, 1) if "OIS_DEV void step_body(" in l)
+    body1 = next(i for i, l in enumerate(src, 1) if i > body0 and l.startswith("// Kernel shells around the same body"))
+    for i, l in enumerate(src, 1):
+        m = re.search(r"// \[phase: (.*)\]\s*$", l)
+        if m and body0 < i < body1:
+            phases.append((i, m.group(1)))
+        m = re.search(r"// \[census: not in the bench configuration: (.*)\]", l)
+        if m:
+            cur_skip = (i, m.group(1))
+        if "// [census: end]" in l and cur_skip:
+            skips.append((cur_skip[0], i, cur_skip[1])); cur_skip = None
+    with tempfile.TemporaryDirectory() as d:
+        out = os.path.join(d, "k.s")
+        subprocess.run(["/opt/rocm/bin/hipcc", *FLAGS, "-gline-tables-only", "-o", out, src_path], check=True, stderr=subprocess.DEVNULL)
+        asm = open(out).read().split("\n")
+    i0 = next(i for i, l in enumerate(asm) if re.match(r"^_Z\w+:", l) and want in l)
+    i1 = next(j for j in range(i0, len(asm)) if asm[j].startswith(".Lfunc_end"))
+    name = asm[i0].split(":")[0]
+    table, depth2, frames = {}, False, []
+    rng_lines = None
+    dev = open(os.path.join(CSRC, "ois_device.h")).read().split("\n")
+    r0 = next(i for i, l in enumerate(dev, 1) if "OIS_DEV void philox4x32_10" in l)
+    r1 = next(i for i, l in enumerate(dev, 1) if i > r0 and "OIS_DEV void draw4" in l) + 8
+    for l in asm[i0 + 1:i1]:
+        s_ = l.strip()
+        if re.match(r"^(\.LBB\d+_\d+):", s_) or s_.startswith("; %bb."):
+            depth2 = "Depth=2" in s_
+            continue
+        if s_.startswith(";") and "Loop Header: Depth=" in s_:
+            depth2 = "Depth=2" in s_
+        m = re.match(r"^\.loc\s+\d+\s+\d+.*?;\s*(.*)$", s_)
+        if m:
+            frames = [(os.path.basename(a), int(b)) for a, b in re.findall(r"([^\s\[\]@:]+):(\d+)(?::\d+)?", m.group(1))]
+            continue
+        if not s_ or s_[0] in ";.":
+            continue
+        op = s_.split()[0]
+        line = next((ln for f, ln in frames if f == "ois_kernels.hip" and body0 <= ln < body1), None)
+        if line is None:
+            ph = "(unattributed)"
+        else:
+            ph = next((n for a, n in reversed(phases) if a <= line), "(before the first marker)")
+            sk = next((w for a, b, w in skips if a <= line <= b), None)
+            if sk:
+                ph = "not in the bench configuration: " + sk
+        if ph.startswith("substeps"):
+            ph = "substep loop body (x nsub - 1)" if depth2 else "first substep (exact reciprocals) + body <-> world glue (per step)"
+        elif frames and frames[0][0] == "ois_device.h" and r0 <= frames[0][1] <= r1 and not ph.startswith(("not in", "reset_idx")):
+            ph = "Philox4x32-10 of the switch draw (per step)"
+        t = table.setdefault(ph, {"instructions": 0, "valu": 0, "valu_packed": 0, "lane_spill": 0, "v_mov": 0, "salu": 0, "mem": 0})
+        t["instructions"] += 1
+        if op.startswith("v_"):
+            t["valu"] += 1
+            t["valu_packed"] += op.startswith("v_pk_")
+            t["lane_spill"] += op in ("v_readlane_b32", "v_writelane_b32")
+            t["v_mov"] += op.startswith(("v_mov", "v_accvgpr"))
+        elif op.startswith("s_"):
+            t["salu"] += 1
+        else:
+            t["mem"] += 1
+    per_launch = sum(v["valu"] for k, v in table.items() if "(per launch)" in k or "last step of a launch" in k)
+    per_step = sum(v["valu"] for k, v in table.items() if "(per step)" in k)
+    loop = table.get("substep loop body (x nsub - 1)", {}).get("valu", 0)
+    return {"kernel": kernel_id(name), "phases": table,
+            "valu_static": {"per_launch": per_launch, "per_step_outside_the_loop": per_step, "substep_loop_body_all_blocks": loop},
+            "note": "static counts of the instructions WRITTEN in each phase (all blocks of it, incl. branches a step does not take: the loop body's "
+                    "executed path is `substep_valu` above); executed VALU per wave of a k-step launch ~ per_launch + k * (per_step + 19 * substep_valu)"}
+
+
 def main():
     js = None
     args = sys.argv[1:]
+    if args[:1] == ["--phases"]:
+        res = phase_table(*(args[1:2] or []))
+        print(f"== {res['kernel']}")
+        for k, v in sorted(res["phases"].items(), key=lambda kv: -kv[1]["valu"]):
+            print(f"   {v['valu']:5d} VALU ({v['valu_packed']:3d} packed, {v['lane_spill']:3d} lane spill, {v['v_mov']:3d} mov) {v['salu']:4d} SALU {v['mem']:3d} mem   {k}")
+        print("  ", res["valu_static"])
+        return
     if args[:1] == ["--json"]:
         js, args = args[1], ["step_kernel"]
     want = args or ["step_kernelILi1ELb1ELi4"]
@@ -113,7 +200,7 @@ def main():
         import bench
         doc = {"kernel_src_sha256": bench.kernel_source_hash(), "lanes_per_substep_note": "per LANE and substep, the executed path of the substep loop "
                "(the short rare blocks with a sqrt / division — velocity cap, exact quaternion normalisation — are not counted); with lanes_per_arena = 2 an arena is two lanes; flop: fma = 2, packed = x2",
-               "kernels": res}
+               "kernels": res, "phases_of_the_headline_kernel": phase_table()}
         json.dump(doc, open(js, "w"), indent=1, sort_keys=True)
         print("wrote", js, len(res), "kernels")
 

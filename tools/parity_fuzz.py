@@ -1,5 +1,5 @@
 """Wide one-off parity sweep, kernel vs CPU oracle, bit for bit (GPU box; the oracle runs on the
-host cores): every task variant x {plane, per-arena friction + slope, height field} x kernel
+host cores): every task variant x {plane, per-arena friction + slope, plane + level curriculum, height field, field + curriculum} x kernel
 shell (one lane per arena in its two register budgets, a lane pair per arena), N arenas x STEPS single steps with random actions, then one fused rollout.
     python tools/parity_fuzz.py [N] [STEPS]
 Prints one line per case; exits non-zero on the first difference."""
@@ -40,7 +40,7 @@ def same(dev, orc, where):
 cases = 0
 t0 = time.time()
 for variant in sorted(VARIANTS):
-    for ground in ("plane", "domain-rand", "field", "field+curriculum"):
+    for ground in ("plane", "domain-rand", "plane+curriculum", "field", "field+curriculum"):
         for shell in ("1", "2", "pair"):
             os.environ["OIS_STEP_WAVES"] = "1" if shell == "pair" else shell
             os.environ["OIS_LANES_PER_ARENA"] = "2" if shell == "pair" else "1"  # by size it would be the pair at this N
@@ -49,7 +49,10 @@ for variant in sorted(VARIANTS):
             if ground.endswith("curriculum") and VARIANTS[variant].get("cmd_sampler") == _abi.CMD_EVAL:
                 continue  # EvalSampling with a curriculum terrain is refused (KAMMA_eval.py:544 tests evalsampling first)
             seed = 100 + cases
-            cfg = build_config(variant=variant, num_envs=N, seed=seed, max_sim_steps=float(STEPS))
+            # plane+curriculum: terrain.curriculum without a terrain (what the reference's TASK_CFG can express): every arena on
+            # level 0, the commands re-drawn after every step; the fused rollout below runs the plane FOLD shells
+            extra = dict(cmd_sampler=_abi.CMD_LEVEL) if ground == "plane+curriculum" else {}
+            cfg = build_config(variant=variant, num_envs=N, seed=seed, max_sim_steps=float(STEPS), **extra)
             dev, orc = NativeEnv(cfg, "cuda:0"), OracleEnv(cfg, threads=16)
             if ground == "domain-rand":
                 sl = [-0.3, -0.2, 0.0, 0.2, 0.3]
