@@ -905,6 +905,97 @@ __global__ __launch_bounds__(64) void logs_kernel(DevConsts K, DevBuffers B, int
   }
 }
 
+// The same in ONE WORKGROUP, for environments of up to kBlockChunks chunks (131 072 arenas) on the plane — the case a trainer's
+// loop is in after every step. The 8 XCDs of the part do not share an L2: the ticket of logs_kernel costs its 64 blocks an
+// agent-scope release each (a write-back of the XCD's dirty L2, right behind a step kernel that stored 26 MB) and 64
+// same-address atomics that serialise at the memory side — 14.5 us per launch in the trainer's loop (rocprofv3), for 0.5 MB of
+// reads. One workgroup needs no cross-XCD hop at all: 16 waves take the chunks two at a time (lanes 0-31 one chunk, lanes
+// 32-63 the next: the 32 record slots), level 2 goes through 16 KB of LDS in chunk order. And it reads only what changed:
+//  * the newest stamp first (16 KB). If it is the one the published record already carries (no arena reset in this step —
+//    98 steps of 99 while the episodes run in step), the record is re-published as it stands;
+//  * otherwise only the rows carrying the newest stamp are loaded (a few groups after a fall, all of them after a timeout).
+// Same two-level order, same values, bit for bit (tests/test_gpu_parity.py::test_one_launch_logging_reductions_against_the_oracle).
+constexpr int kBlockChunks = 128;
+constexpr int kLogsThreads = 1024;
+__global__ __launch_bounds__(kLogsThreads) void logs_block_kernel(DevConsts K, DevBuffers B, int ngroups, int nchunks, int N, LogsArgs A,
+                                                                 int force) {
+  __shared__ float s_part[kBlockChunks][32];
+  __shared__ int s_cmax[kBlockChunks];
+  __shared__ int s_red[kLogsThreads / 64];
+  constexpr int kNever = -2147483647 - 1;
+  const int t = threadIdx.x, lane = t & 63, w = t >> 6, h = lane >> 5, slot = lane & 31;
+  int sm = kNever;
+  for (int g = t; g < ngroups; g += kLogsThreads) sm = max(sm, B.stamps[g]);
+  sm = wave_max_i(sm);
+  if (lane == 0) s_red[w] = sm;
+  __syncthreads();
+  int smax = s_red[0];
+#pragma unroll
+  for (int k = 1; k < kLogsThreads / 64; ++k) smax = max(smax, s_red[k]);
+  const bool fresh = force != 0 || B.episode_info[OIS_EI_STEP] != (float)smax;  // block-uniform
+  const bool is_gamma = slot == 24 || slot == 25;
+  if (fresh) {
+    for (int c0 = 2 * w; c0 < nchunks; c0 += 2 * (kLogsThreads / 64)) {
+      const int ga = c0 * kChunkGroups, na = min(kChunkGroups, ngroups - ga);
+      const int gb = ga + kChunkGroups, nb = c0 + 1 < nchunks ? min(kChunkGroups, ngroups - gb) : 0;
+      const int st_a = lane < na ? B.stamps[ga + lane] : kNever;
+      const int st_b = lane < nb ? B.stamps[gb + lane] : kNever;
+      const int ma = wave_max_i(st_a), mb = wave_max_i(st_b);
+      const float* rows = B.partials + (size_t)(h ? gb : ga) * 32 + slot;
+      float x[kChunkGroups];
+#pragma unroll
+      for (int i = 0; i < kChunkGroups; ++i) {  // the loads of the rows that count, all in flight before the first add
+        const int sa = __builtin_amdgcn_readlane(st_a, i), sb = __builtin_amdgcn_readlane(st_b, i);
+        x[i] = 0.0f;
+        if ((h ? sb : sa) == smax) x[i] = rows[(size_t)i * 32];
+      }
+      float a = is_gamma ? -__builtin_inff() : 0.0f;
+#pragma unroll
+      for (int i = 0; i < kChunkGroups; ++i) {  // row order
+        const int sa = __builtin_amdgcn_readlane(st_a, i), sb = __builtin_amdgcn_readlane(st_b, i);
+        const float y = is_gamma ? fmaxf(a, x[i]) : a + x[i];
+        a = (h ? sb : sa) == smax ? y : a;
+      }
+      const int c = c0 + h;
+      if (c < nchunks) {
+        s_part[c][slot] = a;
+        if (slot == 0) s_cmax[c] = h ? mb : ma;
+      }
+    }
+  }
+  __syncthreads();
+  if (w != 0) return;
+  float out;
+  if (fresh) {
+    float a = is_gamma ? -__builtin_inff() : 0.0f;
+    for (int c = 0; c < nchunks; ++c) {  // chunk order
+      const float x = s_part[c][slot];
+      const float y = is_gamma ? fmaxf(a, x) : a + x;
+      a = s_cmax[c] == smax ? y : a;
+    }
+    const int s = slot;
+    const int src = (s >= OIS_EI_R1 && s <= OIS_EI_OBSERVED_OVER_FINAL) ? s + 3
+                  : (s >= OIS_EI_SMOOTHNESS && s <= OIS_EI_DESIRED_VELOCITY) ? s
+                  : s == OIS_EI_GAMMA1 ? 24 : s == OIS_EI_GAMMA2 ? 25 : 0;
+    const float cnt = __shfl(a, 0, 64), v = __shfl(a, src, 64);
+    out = 0.0f;
+    if ((s >= OIS_EI_R1 && s <= OIS_EI_OBSERVED_OVER_FINAL) || (s >= OIS_EI_SMOOTHNESS && s <= OIS_EI_DESIRED_VELOCITY))
+      out = (v / cnt) / K.reset.episode_length_s;                            // :482-484
+    else if (s == OIS_EI_COUNT || s == OIS_EI_GAMMA1 || s == OIS_EI_GAMMA2) out = v;  // :486, :487
+    else if (s == OIS_EI_STEP) out = (float)smax;                            // (:488 terrain_level: zeros without a terrain, :223)
+    if (lane < 32) B.episode_info[lane] = out;
+  } else {
+    out = B.episode_info[slot];
+  }
+  if (lane >= 32) out = B.env0_diag[lane - 32];
+  if (A.host_block != nullptr) {
+    A.host_block[lane] = out;
+    __threadfence_system();
+    if (lane == 0) __hip_atomic_store(reinterpret_cast<unsigned long long*>(A.host_block + 64), A.seq, __ATOMIC_RELEASE,
+                                      __HIP_MEMORY_SCOPE_SYSTEM);
+  }
+}
+
 // finished-episode statistics: the same two-level order over the per-group accumulators, in double
 // (sum of squared returns of millions of episodes: the variance is a difference of two large numbers); one launch,
 // the loads of a level in flight together (the two launches of serial loads took 20 + 15 us)
@@ -1176,6 +1267,8 @@ struct ois_env {
   unsigned long long logs_seq;   // sequence number of the last logs_kernel enqueued with the host block
   bool logs_on;                  // ois_step enqueues logs_kernel behind the step kernel
   bool logs_current;             // the last enqueued logs_kernel saw the current state
+  bool logs_force;               // state changed by something other than a step since the last logs kernel (reset, state blob,
+                                 // terrain): the record on the device may be stale although its stamp is the newest
 };
 
 // Lanes per arena of the step kernel.
@@ -1343,7 +1436,7 @@ int ois_create(const ois_config* cfg, int device, void* workspace_device, size_t
   std::memset(&B.ter, 0, sizeof B.ter);
   e->rp_mem = nullptr; e->rp_head = 0; e->rp_filled = false;
   e->prof_on = false; e->prof_used = 0; e->prof_ms = 0.0; e->prof_launches = 0;
-  e->logs_host = nullptr; e->logs_seq = 0; e->logs_on = false; e->logs_current = false;
+  e->logs_host = nullptr; e->logs_seq = 0; e->logs_on = false; e->logs_current = false; e->logs_force = true;
   // default per-arena parameters: mu = cfg.friction, flat plane n = +z
   hipError_t he = hipMemsetAsync(e->ws, 0, L.total, nullptr);
   if (he == hipSuccess) {
@@ -1400,7 +1493,7 @@ int ois_reset(ois_env* e, uint64_t seed, void* stream) {
   HIP_TRY(hipGetLastError());
   e->reset_done = true;
   e->steps_done = 0.0;
-  e->logs_current = false;
+  e->logs_current = false; e->logs_force = true;
   return OIS_OK;
 }
 
@@ -1524,8 +1617,13 @@ static int enqueue_logs(ois_env* e, void* stream) {
   A.ticket = (unsigned*)(e->ws + e->L.red_ticket);
   A.host_block = e->logs_host;
   A.seq = e->logs_host ? e->logs_seq + 1 : 0;
-  hipLaunchKernelGGL(logs_kernel, dim3(e->L.nchunks), dim3(64), 0, (hipStream_t)stream, e->K, e->B, e->L.nwaves, e->L.nchunks, e->N, A);
+  if (!e->B.ter.on && e->L.nchunks <= kBlockChunks)  // one workgroup, no cross-XCD hop (logs_block_kernel)
+    hipLaunchKernelGGL(logs_block_kernel, dim3(1), dim3(kLogsThreads), 0, (hipStream_t)stream, e->K, e->B, e->L.nwaves, e->L.nchunks, e->N, A,
+                       e->logs_force ? 1 : 0);
+  else
+    hipLaunchKernelGGL(logs_kernel, dim3(e->L.nchunks), dim3(64), 0, (hipStream_t)stream, e->K, e->B, e->L.nwaves, e->L.nchunks, e->N, A);
   HIP_TRY(hipGetLastError());
+  e->logs_force = false;
   if (e->logs_host) { e->logs_seq += 1; e->logs_current = true; }
   return OIS_OK;
 }
@@ -1620,7 +1718,7 @@ int ois_terrain_attach(ois_env* e, const ois_terrain* t, const int16_t* heights_
   OIS_ON_DEVICE(e->device);
   hipStream_t s = (hipStream_t)stream;
   const size_t f4 = (size_t)e->N * 4 * sizeof(float);
-  e->logs_current = false;  // the terrain-level mean of extras["episode"] changes with the attachment
+  e->logs_current = false; e->logs_force = true;  // the terrain-level mean of extras["episode"] changes with the attachment
   if (!t) {  // detach: back to the per-arena plane, origins and indices cleared
     std::memset(&e->B.ter, 0, sizeof e->B.ter);
     e->K.task.cmd_sampler = e->cfg.cmd_sampler;
@@ -1923,7 +2021,7 @@ int ois_load_state(ois_env* e, const void* host_blob, size_t bytes, void* stream
   HIP_TRY(hipMemcpyAsync(e->ws, (const char*)host_blob + sizeof h, e->L.total, hipMemcpyHostToDevice, (hipStream_t)stream));
   HIP_TRY(hipStreamSynchronize((hipStream_t)stream));
   e->reset_done = h.reset_done != 0;
-  e->logs_current = false;
+  e->logs_current = false; e->logs_force = true;
   e->seed = h.seed;
   e->K.task.seed_lo = (uint32_t)(h.seed & 0xffffffffu);
   e->K.task.seed_hi = (uint32_t)(h.seed >> 32);

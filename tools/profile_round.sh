@@ -2,9 +2,11 @@
 # Regenerates the measured artefacts of one round on the GPU box (run through gpurun from the
 # repo root): bench lines, the rocprofv3 kernel-trace summary of the same command, and the HBM
 # traffic counters (separate --pmc passes, as the microarch guide prescribes).
-#   tools/profile_round.sh r1        -> gpurun_out/r1_*   (copy what is judged into profiles/)
+#   git rev-parse HEAD > .git_head && gpurun --timeout 1200 -- 'bash tools/profile_round.sh r4'
+#        -> gpurun_out/r4_*   (copy what is judged into profiles/). .git_head travels with the snapshot (the box has no .git);
+#        every artefact also names the sha256 of the kernel sources it was taken on, which is what bench.py checks.
 set -e -o pipefail
-R=${1:-r2}
+R=${1:-r4}
 OUT=$PWD/gpurun_out
 mkdir -p $OUT
 export TMPDIR=/tmp
@@ -67,11 +69,21 @@ tail -c 400 $OUT/${R}_bench_gloo2.json
 # side measurements of the round (each file starts with the kernel-source hash it was taken on)
 (echo "# kernel sources sha256 $HASH"; python tools/launch_overhead_probe.py 4096 16384 65536) > $OUT/${R}_launch_overhead.txt 2>&1
 (echo "# kernel sources sha256 $HASH"; python tools/inloop_probe.py) > $OUT/${R}_inloop_probe.txt 2>&1
-(echo "# kernel sources sha256 $HASH"; python tools/overlap_probe.py) > $OUT/${R}_overlap.txt 2>&1
 (echo "# kernel sources sha256 $HASH"; python tools/level_cost_probe.py) > $OUT/${R}_level_cost.txt 2>&1
-python bench.py --shards 2 --no-cpu-baseline > $OUT/${R}_bench_shards2.json 2>> $OUT/${R}_bench.err
 python bench.py --fused 20 --steps 60 --warmup 5 --no-cpu-baseline > $OUT/${R}_bench_fused20.json 2>> $OUT/${R}_bench.err
 python bench.py --domain-rand --no-cpu-baseline > $OUT/${R}_bench_config4_domain_rand.json 2>> $OUT/${R}_bench.err
 python bench.py --terrain --no-cpu-baseline > $OUT/${R}_bench_config4_terrain.json 2>> $OUT/${R}_bench.err
 python bench.py --steps 20 --warmup 5 > $OUT/${R}_bench_driver_shape.json 2>> $OUT/${R}_bench.err
+# the reference trainer's per-step loop around the env (base_KA_DDPG.py:170-262): the four lines + where the host spends a step,
+# and the rocprofv3 kernel trace of the same loop
+(echo "# kernel sources sha256 $HASH"; python tools/trainer_loop_probe.py 65536 --breakdown) > $OUT/${R}_trainer_loop.txt 2>&1
+(cd /tmp && rocprofv3 --kernel-trace --stats --output-format csv -d $P/tl -- python3 $OLDPWD/tools/trainer_loop_probe.py > $P/tl.log 2> $P/tl.err) || { tail -5 $P/tl.err; exit 1; }
+cp $(find $P/tl -name '*kernel_stats.csv' | head -1) $OUT/${R}_trainer_loop_kernel_stats.csv
+(echo "# kernel sources sha256 $HASH"; python tools/info_probe.py) > $OUT/${R}_info_probe.txt 2>&1
+python tools/gae_probe.py > /dev/null 2>&1 && cp $OUT/gae_probe.json $OUT/${R}_gae_probe.json
+# one wave per SIMD, claimed (OIS_STEP_WAVES=1, the default at this size) against two allowed (=2): the same body
+(echo "# kernel sources sha256 $HASH"; bash tools/waves_ab.sh) > $OUT/${R}_ab_occupancy.txt 2>&1
+# the N-rank path's collective through RCCL itself, with the one rank this box has
+(echo "# kernel sources sha256 $HASH"; python tools/nccl_single_rank_check.py) > $OUT/${R}_rccl_1rank.txt 2>&1
+OIS_BENCH_FORCE_DIST=1 python bench.py --steps 120 --warmup 10 --no-cpu-baseline --no-extras > $OUT/${R}_bench_rccl_1rank.json 2>> $OUT/${R}_bench.err
 echo "side measurements done"
