@@ -159,6 +159,12 @@ class NativeEnv:
         self.policy_steps += int(k)
         self.epoch += 1
 
+    def state_changed(self):
+        """tell the host-side log caches that the device state moved without a call through this object — a replayed HIP
+        graph that contains ``step()``: the replays do not run this class's code, so ``host_logs()``, ``observed_components``
+        and ``infos["episode"]`` would otherwise keep serving the step the graph was captured at"""
+        self.epoch += 1
+
     def kernel_info(self) -> str:
         """the step-kernel instantiation this environment launches right now (ois_kernel_info)"""
         import ctypes as C

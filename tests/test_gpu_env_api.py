@@ -337,6 +337,25 @@ def test_step_is_capturable_in_a_hip_graph():
     torch.cuda.synchronize()
     for bid in (_abi.BUF_OBS, _abi.BUF_REW, _abi.BUF_POSE, _abi.BUF_QUAT, _abi.BUF_COUNTERS, _abi.BUF_SUMS_B):
         assert torch.equal(eager.buffer(bid), graphed.buffer(bid)), bid
+    # the step's host logs around a graph: with ois_logs_enable on, a CAPTURED step does not enqueue the publishing kernel (its
+    # sequence number advances per call, not per replay) — the capture still works, and after replays the fetch finalises
+    # the current state itself once the host caches are told that the state moved (NativeEnv.state_changed)
+    logged = NativeEnv(cfg, "cuda:0")
+    logged.reset(6)
+    logged.step(policy(logged.buffer(_abi.BUF_OBS)))       # step 1
+    first = logged.host_logs()[1].copy()                   # switches ois_logs_enable on
+    assert logged._logs_eager
+    obs2 = logged.buffer(_abi.BUF_OBS)
+    g2 = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g2):
+        logged.step(policy(obs2))
+    for _ in range(6):
+        g2.replay()
+    torch.cuda.synchronize()
+    logged.state_changed()
+    ei, diag = logged.host_logs()[:2]
+    assert np.array_equal(diag, eager.env0_diag(direct=True)) and not np.array_equal(diag, first)
+    assert np.array_equal(ei, eager.episode_info().cpu().numpy(), equal_nan=True)
 
 
 def test_ppo_example_runs():
