@@ -793,13 +793,14 @@ __global__ void randomize_params_kernel(DevConsts K, DevBuffers B, int N, float 
 // the most recent reset event (docs/SPEC.md §2.10). Level 1: one wave per chunk of kChunkGroups
 // consecutive groups sums, in group order, the records carrying the chunk's newest stamp;
 // level 2: the chunk partials whose newest stamp is the global newest are summed in chunk order.
-// ONE launch since round 4: the wave that takes the last ticket does level 2 (the others have published
-// their partial before they took theirs), and every load of a level is in flight before the first add —
-// the sums are chains of 64 dependent adds, not of 64 dependent round trips to L2 (two launches of
-// serial loads took 18.2 us at 65 536 arenas, the reference trainer reads infos after every step).
-// The same wave then leaves the 32 values + the 32 env-0 diagnostics of the step in the caller's pinned
-// host block and publishes a sequence number behind them (ois_logs_*): the host waits on a word in its
-// own memory instead of draining the stream through a blocking copy.
+// ONE launch since round 4, and every load of a level is in flight before the first add — the sums are chains of
+// 64 dependent adds, not of 64 dependent round trips to L2 (two launches of serial loads took 18.2 us at 65 536
+// arenas; the reference trainer reads infos after every step). The finishing wave then leaves the 32 values + the 32
+// env-0 diagnostics of the step in the library's pinned host block and publishes a sequence number behind them
+// (ois_logs_*): the host waits on a word in its own memory instead of draining the stream through a blocking copy.
+// Two kernels: logs_block_kernel (one workgroup: the default, below) and logs_kernel (one wave per chunk, the wave
+// that takes the last ticket does level 2: for more than kBlockChunks chunks and with a terrain, whose level mean is
+// a sum over all arenas).
 constexpr int kChunkGroups = 64;  // 1024 arenas per chunk
 
 OIS_DEV int wave_max_i(int x) {
@@ -1246,7 +1247,7 @@ struct ois_env {
                 // the last ois_load_state of a flat blob (OIS_FLAT=0 forces the general kernels)
   bool flat_allowed;
   bool packed;  // LPA = 1 only: per-wheel math on v_pk_*_f32 (ois_physics_pk.h)
-  bool waves2;  // plane kernel shell held to 256 registers (step_kernel_w2), chosen by arena count
+  bool waves2;  // plane kernel shell without the one-wave-per-SIMD claim (step_kernel_w2), chosen by arena count
   uint64_t seed;  // seed of the last ois_reset (RNG key of the episode stream)
   bool reset_done;
   double steps_done;
@@ -1402,7 +1403,7 @@ int ois_create(const ois_config* cfg, int device, void* workspace_device, size_t
     const char* fl = getenv("OIS_FLAT");
     e->flat_allowed = fl ? (fl[0] == '1') : true;
     e->flat = e->flat_allowed;  // params start as (mu, 0, 0, 1) below
-    // Plane kernel shell (see step_kernel / step_kernel_w2): the 256-register one only where a
+    // Plane kernel shell (see step_kernel / step_kernel_w2): two waves per SIMD allowed only where a
     // second wave per SIMD exists to be had, i.e. more arenas than one wave per SIMD covers.
     int simds = 1024;
     hipDeviceProp_t prop;
