@@ -15,6 +15,7 @@ torch.manual_seed(0)
 actor = torch.nn.Sequential(torch.nn.Linear(6, 512), torch.nn.ELU(), torch.nn.Linear(512, 512), torch.nn.ELU(),
                             torch.nn.Linear(512, 128), torch.nn.ELU(), torch.nn.Linear(128, 4), torch.nn.Sigmoid()).cuda()
 clock = time.perf_counter
+STEPS = 500  # per line; a line moves by a few us from run to run and by up to 15 us from box to box (the synchronisation's wake-up)
 
 
 def loop(steps, read_diag, read_infos, on_host=True, phases=None, bare_sync=False):
@@ -51,18 +52,18 @@ def loop(steps, read_diag, read_infos, on_host=True, phases=None, bare_sync=Fals
 
 
 loop(20, True, True)
-print(f"N={N} actor + step only:                      {loop(200, False, False):8.1f} us/step")
+print(f"N={N} actor + step only:                      {loop(STEPS, False, False):8.1f} us/step")
 print(f"N={N} + a bare stream synchronisation after every step (what ANY host read of the step's values costs this loop): "
-      f"{loop(200, False, False, bare_sync=True):8.1f} us/step")
-print(f"N={N} + observed_components + executed actions: {loop(200, True, False):8.1f} us/step")
-print(f"N={N} + infos['episode'] .item() x22 (host copy): {loop(200, True, True):8.1f} us/step")
-print(f"N={N} + infos['episode'] .item() x22 (device tensors, as the reference returns them): {loop(200, True, True, on_host=False):8.1f} us/step")
+      f"{loop(STEPS, False, False, bare_sync=True):8.1f} us/step")
+print(f"N={N} + observed_components + executed actions: {loop(STEPS, True, False):8.1f} us/step")
+print(f"N={N} + infos['episode'] .item() x22 (host copy): {loop(STEPS, True, True):8.1f} us/step")
+print(f"N={N} + infos['episode'] .item() x22 (device tensors, as the reference returns them): {loop(STEPS, True, True, on_host=False):8.1f} us/step")
 if "--breakdown" in sys.argv:
     ph = [0.0] * 5
-    total = loop(200, True, True, phases=ph)
+    total = loop(STEPS, True, True, phases=ph)
     names = ("actor(states) [host: 8 launches]", "env.step(actions) [ois_step + logs launch + 4 output copies]",
              "observed_components x27 [waits for the published block]", "wheel_torqs / action_scale [1 launch]",
              "infos['episode'] items + .item() x22")
     print(f"host time per step of the full loop ({total:.1f} us/step):")
     for n_, p in zip(names, ph):
-        print(f"   {p / 200 * 1e6:7.1f} us  {n_}")
+        print(f"   {p / STEPS * 1e6:7.1f} us  {n_}")
