@@ -296,6 +296,7 @@ class Cosim:
                 d[g] = T.__dict__[g].clone().float()
         ex = T.extras.get("episode", {})
         d["extras_keys"] = np.array(sorted(ex))
+        d["extras_order"] = np.array(list(ex))  # the ORDER the reference's reset_idx fills the dict in (what a logger iterates)
         d["extras"] = np.array([float(ex[k]) for k in sorted(ex)], np.float64)
         oc = getattr(T, "observed_components", None)
         if oc:
@@ -360,11 +361,13 @@ def run_variant(variant, n, T, seed, events):
 
 def pack(variant, co, first, steps):
     d = {}
-    per_step = [k for k in steps[0] if k not in ("extras_keys", "components_keys")]
+    per_step = [k for k in steps[0] if k not in ("extras_keys", "extras_order", "components_keys")]
     for k in per_step:
         d[k] = np.stack([s[k] for s in steps])
     d["extras_keys"], d["components_keys"] = steps[0]["extras_keys"], steps[0]["components_keys"]
-    assert all((s["extras_keys"] == d["extras_keys"]).all() and (s["components_keys"] == d["components_keys"]).all() for s in steps)
+    d["extras_order"] = steps[0]["extras_order"]
+    assert all((s["extras_keys"] == d["extras_keys"]).all() and (s["components_keys"] == d["components_keys"]).all()
+               and (s["extras_order"] == d["extras_order"]).all() for s in steps)
     for k in ("commands", "episode_buf", "sim_steps", "episode_count", "extras"):
         d["first__" + k] = first[k]
     d["first__reset_u"] = co.first_reset_u

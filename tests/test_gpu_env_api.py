@@ -407,6 +407,7 @@ def test_combined_host_logs_equal_the_separate_reads():
             a, b = ep[key], float(direct_info[slot])
             assert a == b or (np.isnan(a) and np.isnan(b)), key
         assert all(v.device.type == "cpu" for v in infos["episode"].values())
+        assert list(infos["episode"]) == [k for k, _ in _abi.episode_info_layout(True, False)]   # the reference's dict order (KAMMA_eval)
     n = env.task.native
     assert n._logs_eager                                 # the loop read its logs: ois_step publishes them itself
     for _ in range(18):                                  # ... and stops paying for that once nobody reads them

@@ -66,7 +66,7 @@ def test_oracle_follows_the_reference_statements_step_by_step(fixture, variant):
     check_step(env, cfg, first, f"{variant} post_reset", first=True, drawn_commands=drawn)
     if int(d["start_sim_steps"]):
         env.buffer(_abi.BUF_COUNTERS)[:, 1] = int(d["start_sim_steps"])
-    per_step = [k for k in d if not k.startswith("first__") and k not in ("extras_keys", "components_keys", "start_sim_steps",
+    per_step = [k for k in d if not k.startswith("first__") and k not in ("extras_keys", "extras_order", "components_keys", "start_sim_steps",
                                                                           "reference_raised_zero_division_at", "env_file", "task_cfg_patches_json")]
     for t in range(T):
         lv = dict(level_z=np.ascontiguousarray(d["level_z"][t]), levels=np.ascontiguousarray(d["levels"][t])) if drawn else {}
@@ -113,6 +113,22 @@ def test_oracle_follows_the_reference_statements_step_by_step(fixture, variant):
         # the reference itself stops at this step: get_observations divides by rew_buf[0].item() == 0.0 in Python floats
         # (KAMMA_g11_g21.py:859; gamma2 = 1 and unclipped expert torques). The build yields inf / nan diagnostics instead.
         assert variant == "KAMMA_g11_g21" and stop == T
+
+
+@pytest.mark.parametrize("variant", RUN_NAMES)
+def test_extras_dict_has_the_references_key_order(fixture, variant):
+    """what a logger iterates is the dict's ORDER, and the tests compared sorted keys. The fixture now also holds the
+    order in which the reference's own reset_idx filled extras["episode"] (declared episode sums incl. the four never-written
+    `... reward/Final reward` keys and the eval files' three, then the ratio keys reset_idx adds, the assist factor(s),
+    terrain_level: KAMMA.py:204-221, 470-488; KA_DDPG_4D.py:484): `_abi.episode_info_layout`, from which both VecEnv's
+    infos["episode"] and the multi-rank merge of `dist` are built, yields exactly that sequence for every env file."""
+    from options_in_simulation_amd.config import VARIANTS as CFG
+    d = _variant(fixture, variant)
+    env_file = str(d["env_file"])
+    cfg = build_config(variant=env_file, num_envs=1)
+    layout = [k for k, _ in _abi.episode_info_layout(bool(cfg.eval_sums), cfg.mix_mode == _abi.MIX_BLEND)]
+    assert layout == [str(k) for k in d["extras_order"]], env_file
+    assert sorted(layout) == [str(k) for k in d["extras_keys"]] and env_file in CFG
 
 
 def test_the_switch_and_every_sampler_are_exercised(fixture):
