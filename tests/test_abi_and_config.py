@@ -231,3 +231,31 @@ def test_census_ids_are_the_ids_ois_kernel_info_reports():
                 "step_kernel<1,1,4,1>+fold"):
         assert kid in d and d[kid]["scratch_bytes"] <= (256 if "w2" in kid else 64), kid
     assert d["step_kernel<1,1,4,0>"]["substep_valu"] - d["step_kernel<1,1,4,1>"]["substep_valu"] == 12   # the flat-plane shells
+
+
+def test_observed_components_are_the_references_python_double_arithmetic():
+    """task.observed_components (KAMMA.py:840-867) is rebuilt on the host from the 32-float env-0 block after EVERY step of a
+    trainer that logs, in plain Python floats since round 4 (it used to cost 20 us of numpy scalars per step). Same values as the
+    float64 numpy evaluation of the reference's expression `100.0 * (1 - gamma2) * comp / rew`, left to right, incl. what the
+    reference's ZeroDivisionError case becomes here (inf / nan by the IEEE rules, both signs of zero)."""
+    import numpy as np
+    from options_in_simulation_amd.vecenv import observed_components_from_diag
+    from options_in_simulation_amd.tracking import ENV0_TAGS
+    rng = np.random.default_rng(0)
+    cases = [rng.normal(size=32).astype(np.float32) for _ in range(50)]
+    for rew in (0.0, -0.0, np.float32(1e-12), np.float32(np.nan)):
+        for comp in (1.5, -2.0, 0.0, np.float32(np.inf)):
+            d = rng.normal(size=32).astype(np.float32)
+            d[27], d[20], d[26] = rew, comp, -comp
+            cases.append(d)
+    for d in cases:
+        got = observed_components_from_diag(d)
+        d64 = d.astype(np.float64)
+        g2, rew = d64[19], d64[27]
+        with np.errstate(divide="ignore", invalid="ignore"):
+            want = {"env0_perc_r1": np.float64(100.0) * (1 - g2) * d64[20] / rew, "env0_perc_dense": np.float64(100.0) * (1 - g2) * d64[23] / rew,
+                    "env0_perc_guiding": np.float64(100.0) * g2 * d64[26] / rew}
+        for k, w in want.items():
+            assert got[k] == float(w) or (np.isnan(got[k]) and np.isnan(w)), (k, got[k], w, d[27])
+        assert got["env0_desired_v"] == float(d64[0]) and got["env0_episode_count"] == int(d64[8]) and isinstance(got["env0_episode_count"], int)
+        assert set(ENV0_TAGS) <= set(got) and len(got) == 26   # the 26 keys the trainer reads (base_KA_DDPG.py:184-209)
