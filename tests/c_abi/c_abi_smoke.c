@@ -104,6 +104,31 @@ int main(int argc, char** argv) {
     if (diag[8] != 2.0f) { fprintf(stderr, "env-0 episode count %f\n", diag[8]); return 1; }
   }
   CHECK(ois_logs_enable(env, 0));
+  /* the wrapper's per-step copies in one launch (ois_outputs_copy): fresh arrays of the caller's == the library's buffers */
+  {
+    float *o_obs = NULL, *o_rew = NULL;
+    unsigned char *o_term = NULL, *o_trunc = NULL;
+    HIP(hipMalloc((void**)&o_obs, sizeof(float) * N * 6)); HIP(hipMalloc((void**)&o_rew, sizeof(float) * N));
+    HIP(hipMalloc((void**)&o_term, N)); HIP(hipMalloc((void**)&o_trunc, N));
+    HIP(hipMemsetAsync(o_trunc, 0xff, N, stream));
+    CHECK(ois_outputs_copy(env, o_obs, o_rew, o_term, o_trunc, stream));
+    float* a = (float*)malloc(sizeof(float) * N * 6); float* b = (float*)malloc(sizeof(float) * N * 6);
+    unsigned char* t = (unsigned char*)malloc(N);
+    HIP(hipMemcpyAsync(a, o_obs, sizeof(float) * N * 6, hipMemcpyDeviceToHost, stream));
+    CHECK(ois_buffer(env, OIS_BUF_OBS, &p, &n));
+    HIP(hipMemcpyAsync(b, p, n, hipMemcpyDeviceToHost, stream));
+    HIP(hipMemcpyAsync(t, o_trunc, N, hipMemcpyDeviceToHost, stream));
+    HIP(hipStreamSynchronize(stream));
+    if (memcmp(a, b, sizeof(float) * N * 6) != 0) { fprintf(stderr, "ois_outputs_copy: observations differ\n"); return 1; }
+    for (int i = 0; i < N; ++i) if (t[i] != 0) { fprintf(stderr, "ois_outputs_copy: truncated not zeroed\n"); return 1; }
+    if (ois_outputs_copy(env, (float*)((char*)o_obs + 4), NULL, NULL, NULL, stream) != OIS_EINVAL) { fprintf(stderr, "misaligned obs_out not refused\n"); return 1; }
+    HIP(hipFree(o_obs)); HIP(hipFree(o_rew)); HIP(hipFree(o_term)); HIP(hipFree(o_trunc)); free(a); free(b); free(t);
+  }
+  /* a caller that writes plane normals itself leaves the flat-plane kernels by saying so */
+  CHECK(ois_params_dirty(env));
+  CHECK(ois_kernel_info(env, info, sizeof info));
+  if (!strstr(info, "plane=per-arena")) { fprintf(stderr, "ois_params_dirty did not leave the flat shell: %s\n", info); return 1; }
+  CHECK(ois_randomize_params(env, 0.85f, 0.85f, NULL, 0, stream)); /* back on the default plane */
   if (ois_logs_fetch(env, NULL, diag, stream) != OIS_EINVAL) { fprintf(stderr, "null logs output not refused\n"); return 1; }
 
   size_t sb = ois_state_bytes(env);

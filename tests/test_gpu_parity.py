@@ -34,11 +34,11 @@ EXACT_BUFS = [_abi.BUF_COUNTERS, _abi.BUF_DONE, _abi.BUF_TIMEOUT]
 RTOL, ATOL = 1e-5, 1e-6
 
 
-def make_pair(device="cuda:0", **kw):
+def make_pair(device="cuda:0", oracle_threads=1, **kw):
     from options_in_simulation_amd.vecenv import NativeEnv
     from oracle.binding import OracleEnv
     cfg = build_config(**kw)
-    return cfg, NativeEnv(cfg, device), OracleEnv(cfg)
+    return cfg, NativeEnv(cfg, device), OracleEnv(cfg, threads=oracle_threads)
 
 
 def compare(dev, orc, where="", exact_float=False):
@@ -107,14 +107,15 @@ def test_eval_variants_zero_old_torques_of_every_arena_on_any_reset(variant, N):
     assert np.array_equal(rs.cpu().numpy(), ro)
 
 
-@pytest.mark.parametrize("N", [1, 1000, 66000, 140000])
+@pytest.mark.parametrize("N", [1, 1000, 66000, 140000, 524288])
 def test_one_launch_logging_reductions_against_the_oracle(N):
     """extras["episode"] and the finished-episode statistics are one launch each since round 4 (logs_kernel / stats_kernel:
     the wave with the last ticket does level 2). Same two-level order as the oracle, bit for bit: 1 chunk, 1 ragged chunk,
-    65 chunks (a second level-2 batch of one), 137 chunks (three batches); after post_reset (every group carries stamp 0),
+    65 chunks (one workgroup, 16 waves x 2 chunks x 3 passes), 137 and 512 chunks (the one-wave-per-chunk kernel: three / eight level-2 batches); after post_reset (every group carries stamp 0),
     after single falls (one group, one chunk), after two falls in different chunks of one step, and with short episodes after
     the synchronous timeout. The block ois_logs_fetch publishes in pinned host memory == the device buffers == the oracle."""
-    cfg, dev, orc = make_pair(variant="KAMMA_medium", num_envs=N, seed=31, max_episode_length=6)  # timeout when episode_buf reaches 5
+    cfg, dev, orc = make_pair(variant="KAMMA_medium", num_envs=N, seed=31, max_episode_length=6,  # timeout when episode_buf reaches 5
+                              oracle_threads=8 if N > 100000 else 1)
     dev.reset(31); orc.reset(31)
     rng = np.random.default_rng(8)
     up = np.array([0.0, 1.0, 0.0, 0.0], np.float32)
