@@ -74,6 +74,9 @@ def episode_info_layout(eval_keys: bool, single_gamma: bool):
     return out
 
 
+EPISODE_INFO_FIRST_SLOT, EPISODE_INFO_LAST_SLOT = 1, 22  # the slots a key can name, besides the always-zero slot 31
+
+
 def episode_info_items(vec, eval_keys: bool, single_gamma: bool):
     """(key, value) pairs of extras["episode"] (KAMMA.py:480-488) from the 32-slot vector of OIS_BUF_EPISODE_INFO, in the
     key set and order of the reference file the variant stands for: `vec` is anything indexable (numpy row, 1-D tensor)."""

@@ -228,7 +228,7 @@ class NativeEnv:
         _native.check(self.L.ois_env0_diag(self.h, out.ctypes.data_as(C.POINTER(C.c_float)), _stream_ptr(self.device)))
         return out
 
-    def host_logs(self) -> Tuple[np.ndarray, np.ndarray, Tuple[torch.Tensor, ...]]:
+    def host_logs(self) -> Tuple[np.ndarray, np.ndarray, "_SlotTensors"]:
         """(episode_info[32], env0_diag[32], the first as 32 0-dim CPU tensors) of the current step on the host (ois_logs_fetch): ONE finalisation
         launch whose last wave writes both blocks into the library's pinned host memory and publishes a sequence
         number behind them; the host polls that word — no blocking copy, no drained stream. The first read switches
@@ -253,7 +253,10 @@ class NativeEnv:
         reading loop would otherwise pay between the GPU finishing the step and the next policy launch. Made right
         after the step was enqueued, i.e. while the host has nothing to do but wait."""
         blob = np.empty(_abi.EPISODE_INFO_LEN + _abi.ENV0_DIAG_LEN, np.float32)
-        tensors = torch.from_numpy(blob[:_abi.EPISODE_INFO_LEN]).unbind(0)
+        # only the slots a key can name become tensors (0.6 us each: at small arena counts the loop is host-bound and pays for
+        # every one); the never-written keys (slot 31, always 0) share one constant
+        lo, hi = _abi.EPISODE_INFO_FIRST_SLOT, _abi.EPISODE_INFO_LAST_SLOT
+        tensors = _SlotTensors(lo, torch.from_numpy(blob[lo:hi + 1]).unbind(0))
         self._logs_next = (blob, tensors, C.c_void_p(blob.ctypes.data), C.c_void_p(blob.ctypes.data + 4 * _abi.EPISODE_INFO_LEN))
 
     def attach_terrain(self, terrain, levels_types: np.ndarray, curriculum: Optional[bool] = None,
@@ -353,6 +356,18 @@ class NativeEnv:
         buf = (C.c_uint8 * len(blob)).from_buffer_copy(blob)
         _native.check(self.L.ois_load_state(self.h, C.cast(buf, C.c_void_p), len(blob), _stream_ptr(self.device)))
         self.epoch += 1
+
+
+class _SlotTensors:
+    """the 0-dim CPU tensors of one fetched extras vector, indexable by slot like the vector itself"""
+    _ZERO = torch.zeros(())
+
+    def __init__(self, first_slot: int, tensors):
+        self._first, self._t = first_slot, tensors
+
+    def __getitem__(self, slot: int) -> torch.Tensor:
+        i = slot - self._first
+        return self._t[i] if 0 <= i < len(self._t) else self._ZERO
 
 
 class _LazyEpisodeInfo(dict):
