@@ -68,7 +68,8 @@ extern "C" {
 /* 5: ois_kernel_info; state blobs carry the flat-plane flag (version 4 blobs do not load); ois_config validation
  *    also refuses an unstable joint resistance and a negative depenetration velocity */
 /* 6: ois_logs_enable / ois_logs_fetch (the step's logs through pinned host memory); ois_episode_info and ois_stats_fetch are
- *    one launch each; the workspace grew by one 256-byte slot (state blobs of version 5 do not load) */
+ *    restructured (one launch of one workgroup / two launches); the workspace grew by one 256-byte slot (state blobs of
+ *    version 5 do not load) */
 #define OIS_ABI_VERSION 6
 
 /* error codes */
@@ -324,8 +325,9 @@ int ois_kernel_info(const ois_env* env, char* out, size_t cap);
  * defines it and never calls it; here for scripts that do. */
 int ois_push_robots(ois_env* env, void* stream);
 
-/* Reduce the per-group records of the most recent reset event into OIS_BUF_EPISODE_INFO
- * (device; one launch). No host synchronisation. */
+/* Reduce the per-group records of the most recent reset event into OIS_BUF_EPISODE_INFO (device; one launch up to
+ * 131 072 arenas, two above or on a terrain with a level curriculum). No host synchronisation. A caller that rewrites
+ * OIS_BUF_TERRAIN_IDX itself re-attaches the terrain (the level mean of a terrain without curriculum is taken at attach). */
 int ois_episode_info(ois_env* env, void* stream);
 
 /* Copy finished-episode statistics to the host (synchronises `stream`). */
@@ -340,7 +342,7 @@ int ois_env0_diag(ois_env* env, float* host_out /*[OIS_ENV0_DIAG_LEN]*/, void* s
  * Through ois_episode_info + a copy that is two launches, a blocking transfer and a drained stream per step.
  *   ois_logs_fetch: the [OIS_EPISODE_INFO_LEN] extras["episode"] values (slots: ois_episode_info_slot) and the
  *     [OIS_ENV0_DIAG_LEN] arena-0 diagnostics of the CURRENT state into two host arrays. If no finalisation of the current
- *     state is in flight it enqueues one on `stream` (ONE launch, which also fills OIS_BUF_EPISODE_INFO); then it waits
+ *     state is in flight it enqueues one on `stream` (one launch — two above 131 072 arenas — which also fills OIS_BUF_EPISODE_INFO); then it waits
  *     until the kernel has published the values: the kernel writes them into a pinned, host-coherent block the library
  *     allocates on first use (hipHostMalloc, 4 KiB — host memory; device memory stays the caller's) and stores a sequence
  *     number behind them, the host polls that word. No stream synchronisation, no copy engine; work enqueued behind the

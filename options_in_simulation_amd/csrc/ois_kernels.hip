@@ -793,14 +793,15 @@ __global__ void randomize_params_kernel(DevConsts K, DevBuffers B, int N, float 
 // the most recent reset event (docs/SPEC.md §2.10). Level 1: one wave per chunk of kChunkGroups
 // consecutive groups sums, in group order, the records carrying the chunk's newest stamp;
 // level 2: the chunk partials whose newest stamp is the global newest are summed in chunk order.
-// ONE launch since round 4, and every load of a level is in flight before the first add — the sums are chains of
+// Since round 4 every load of a level is in flight before the first add — the sums are chains of
 // 64 dependent adds, not of 64 dependent round trips to L2 (two launches of serial loads took 18.2 us at 65 536
 // arenas; the reference trainer reads infos after every step). The finishing wave then leaves the 32 values + the 32
 // env-0 diagnostics of the step in the library's pinned host block and publishes a sequence number behind them
 // (ois_logs_*): the host waits on a word in its own memory instead of draining the stream through a blocking copy.
-// Two kernels: logs_block_kernel (one workgroup: the default, below) and logs_kernel (one wave per chunk, the wave
-// that takes the last ticket does level 2: for more than kBlockChunks chunks and with a terrain, whose level mean is
-// a sum over all arenas).
+// Two forms: logs_block_kernel (one workgroup, one launch: the default, below) and, for more than kBlockChunks chunks or
+// a terrain whose levels move (its level mean is a sum over all arenas), logs_level1_kernel (one wave per chunk) +
+// logs_level2_kernel: two launches, because the end of a kernel is the cheapest grid-wide barrier this part has — a
+// "wave with the last ticket does level 2" version of the same took 14.5 us per launch.
 constexpr int kChunkGroups = 64;  // 1024 arenas per chunk
 
 OIS_DEV int wave_max_i(int x) {
@@ -808,19 +809,6 @@ OIS_DEV int wave_max_i(int x) {
   for (int w = 32; w >= 1; w >>= 1) { const int y = __shfl_xor(x, w, 64); x = y > x ? y : x; }
   return x;
 }
-// the lane that took the last of `n` tickets sees every other block's global writes (release before the
-// ticket, acquire after it); the counter is back at 0 when the kernel ends
-OIS_DEV bool last_block(unsigned* ticket, unsigned n, int t) {
-  __threadfence();
-  unsigned k = 0;
-  if (t == 0) k = atomicAdd(ticket, 1u);
-  k = __shfl(k, 0, 64);
-  if (k != n - 1) return false;
-  __threadfence();
-  if (t == 0) *ticket = 0u;
-  return true;
-}
-
 // one level of the record sum for slot `t` (0..31; called by all 64 lanes, the upper half shadows the lower): the
 // up-to-64 rows at `rows`, stride 32 floats, of which row i counts when lane i's `stamp` equals `newest`; slots
 // 24 / 25 (gamma1 / gamma2, identical in every record of one event) are max-reduced. All loads first, then the adds
@@ -843,12 +831,12 @@ struct LogsArgs {
   float* part;          // [nchunks][32] level-1 partials
   int* cmax;            // [nchunks] newest stamp of each chunk
   long long* lvl;       // [nchunks] terrain-level sums
-  unsigned* ticket;
+  float level_mean;     // torch.mean(terrain_levels) when the host knows it (a terrain without curriculum: set at attach); else < 0
   float* host_block;    // pinned host memory: [32] episode info | [32] env-0 diagnostics | uint64 sequence; or null
   unsigned long long seq;
 };
 
-__global__ __launch_bounds__(64) void logs_kernel(DevConsts K, DevBuffers B, int ngroups, int nchunks, int N, LogsArgs A) {
+__global__ __launch_bounds__(64) void logs_level1_kernel(DevBuffers B, int ngroups, int N, LogsArgs A) {
   const int c = blockIdx.x, t = threadIdx.x;
   constexpr int kNever = -2147483647 - 1;
   {
@@ -860,7 +848,7 @@ __global__ __launch_bounds__(64) void logs_kernel(DevConsts K, DevBuffers B, int
     if (t < 32) A.part[(size_t)c * 32 + t] = p;
     if (t == 0) A.cmax[c] = m;
     // :488 torch.mean(terrain_levels.float()) over ALL arenas: integer sums, exact and order-free
-    if (B.ter.on) {
+    if (B.ter.on && A.level_mean < 0.0f) {
       long long ls = 0;
       const int a1 = min((g0 + n) * kGroup, N);
       for (int i = g0 * kGroup + t; i < a1; i += 64) ls += B.terrain_idx[i].x;
@@ -868,7 +856,11 @@ __global__ __launch_bounds__(64) void logs_kernel(DevConsts K, DevBuffers B, int
       if (t == 0) A.lvl[c] = ls;
     }
   }
-  if (!last_block(A.ticket, (unsigned)nchunks, t)) return;
+}
+
+__global__ __launch_bounds__(64) void logs_level2_kernel(DevConsts K, DevBuffers B, int nchunks, int N, LogsArgs A) {
+  const int t = threadIdx.x;
+  constexpr int kNever = -2147483647 - 1;
   int sm = kNever;
   for (int i = t; i < nchunks; i += 64) sm = max(sm, A.cmax[i]);
   const int smax = wave_max_i(sm);
@@ -880,7 +872,7 @@ __global__ __launch_bounds__(64) void logs_kernel(DevConsts K, DevBuffers B, int
     a = record_level(A.part + (size_t)c0 * 32, n, cm, smax, t & 31, a);
   }
   long long tot = 0;
-  if (B.ter.on) {
+  if (B.ter.on && A.level_mean < 0.0f) {
     for (int i = t; i < nchunks; i += 64) tot += A.lvl[i];
     for (int w = 32; w >= 1; w >>= 1) tot += __shfl_xor(tot, w, 64);
   }
@@ -894,7 +886,7 @@ __global__ __launch_bounds__(64) void logs_kernel(DevConsts K, DevBuffers B, int
   if ((s >= OIS_EI_R1 && s <= OIS_EI_OBSERVED_OVER_FINAL) || (s >= OIS_EI_SMOOTHNESS && s <= OIS_EI_DESIRED_VELOCITY))
     out = (v / cnt) / K.reset.episode_length_s;                            // :482-484
   else if (s == OIS_EI_COUNT || s == OIS_EI_GAMMA1 || s == OIS_EI_GAMMA2) out = v;  // :486, :487
-  else if (s == OIS_EI_TERRAIN_LEVEL) out = (float)tot / (float)N;   // :488 (zeros without a terrain, :223)
+  else if (s == OIS_EI_TERRAIN_LEVEL) out = A.level_mean >= 0.0f ? A.level_mean : (float)tot / (float)N;   // :488 (zeros without a terrain, :223)
   else if (s == OIS_EI_STEP) out = (float)smax;
   if (t < 32) B.episode_info[t] = out;
   else out = B.env0_diag[t - 32];
@@ -906,12 +898,13 @@ __global__ __launch_bounds__(64) void logs_kernel(DevConsts K, DevBuffers B, int
   }
 }
 
-// The same in ONE WORKGROUP, for environments of up to kBlockChunks chunks (131 072 arenas) on the plane — the case a trainer's
-// loop is in after every step. The 8 XCDs of the part do not share an L2: the ticket of logs_kernel costs its 64 blocks an
-// agent-scope release each (a write-back of the XCD's dirty L2, right behind a step kernel that stored 26 MB) and 64
-// same-address atomics that serialise at the memory side — 14.5 us per launch in the trainer's loop (rocprofv3), for 0.5 MB of
-// reads. One workgroup needs no cross-XCD hop at all: 16 waves take the chunks two at a time (lanes 0-31 one chunk, lanes
-// 32-63 the next: the 32 record slots), level 2 goes through 16 KB of LDS in chunk order. And it reads only what changed:
+// The same in ONE WORKGROUP and one launch, for environments of up to kBlockChunks chunks (131 072 arenas) on the plane or on a
+// terrain whose levels cannot move — the case a trainer's loop is in after every step. The 8 XCDs of the part do not share an
+// L2: a single-launch version with one wave per chunk and a "last ticket" (an agent-scope release per block = a write-back of
+// the XCD's dirty L2, right behind a step kernel that stored 26 MB; 64 same-address atomics that serialise at the memory side)
+// took 14.5 us per launch in the trainer's loop (rocprofv3), for 0.5 MB of reads. One workgroup needs no cross-XCD hop at all:
+// 16 waves take the chunks two at a time (lanes 0-31 one chunk, lanes 32-63 the next: the 32 record slots), level 2 goes
+// through 16 KB of LDS in chunk order. And it reads only what changed:
 //  * the newest stamp first (16 KB). If it is the one the published record already carries (no arena reset in this step —
 //    98 steps of 99 while the episodes run in step), the record is re-published as it stands;
 //  * otherwise only the rows carrying the newest stamp are loaded (a few groups after a fall, all of them after a timeout).
@@ -983,7 +976,8 @@ __global__ __launch_bounds__(kLogsThreads) void logs_block_kernel(DevConsts K, D
     if ((s >= OIS_EI_R1 && s <= OIS_EI_OBSERVED_OVER_FINAL) || (s >= OIS_EI_SMOOTHNESS && s <= OIS_EI_DESIRED_VELOCITY))
       out = (v / cnt) / K.reset.episode_length_s;                            // :482-484
     else if (s == OIS_EI_COUNT || s == OIS_EI_GAMMA1 || s == OIS_EI_GAMMA2) out = v;  // :486, :487
-    else if (s == OIS_EI_STEP) out = (float)smax;                            // (:488 terrain_level: zeros without a terrain, :223)
+    else if (s == OIS_EI_TERRAIN_LEVEL) out = A.level_mean >= 0.0f ? A.level_mean : 0.0f;  // :488; zeros without a terrain (:223)
+    else if (s == OIS_EI_STEP) out = (float)smax;
     if (lane < 32) B.episode_info[lane] = out;
   } else {
     out = B.episode_info[slot];
@@ -998,8 +992,8 @@ __global__ __launch_bounds__(kLogsThreads) void logs_block_kernel(DevConsts K, D
 }
 
 // finished-episode statistics: the same two-level order over the per-group accumulators, in double
-// (sum of squared returns of millions of episodes: the variance is a difference of two large numbers); one launch,
-// the loads of a level in flight together (the two launches of serial loads took 20 + 15 us)
+// (sum of squared returns of millions of episodes: the variance is a difference of two large numbers); two launches
+// (level 1 per chunk, level 2 in one wave), the loads of a level in flight together
 OIS_DEV double stat_level(const double* __restrict__ rows, int nrows, int t, double a) {
   double x[kChunkGroups];
 #pragma unroll
@@ -1011,16 +1005,16 @@ OIS_DEV double stat_level(const double* __restrict__ rows, int nrows, int t, dou
   }
   return a;
 }
-__global__ __launch_bounds__(64) void stats_kernel(DevBuffers B, int ngroups, int nchunks, double* __restrict__ part8,
-                                                  double* __restrict__ out8, unsigned* ticket, int reset_after) {
+__global__ __launch_bounds__(64) void stats_level1_kernel(DevBuffers B, int ngroups, double* __restrict__ part8, int reset_after) {
   const int c = blockIdx.x, t = threadIdx.x;
   const int g0 = c * kChunkGroups, n = min(kChunkGroups, ngroups - g0);
-  if (t < 8) {
-    double* rows = B.stat_acc + (size_t)g0 * 8;
-    part8[(size_t)c * 8 + t] = stat_level(rows, n, t, t < 4 ? 0.0 : -__builtin_inf());
-    if (reset_after) for (int i = 0; i < n; ++i) rows[(size_t)i * 8 + t] = t < 4 ? 0.0 : -__builtin_inf();
-  }
-  if (!last_block(ticket, (unsigned)nchunks, t)) return;
+  if (t >= 8) return;
+  double* rows = B.stat_acc + (size_t)g0 * 8;
+  part8[(size_t)c * 8 + t] = stat_level(rows, n, t, t < 4 ? 0.0 : -__builtin_inf());
+  if (reset_after) for (int i = 0; i < n; ++i) rows[(size_t)i * 8 + t] = t < 4 ? 0.0 : -__builtin_inf();
+}
+__global__ __launch_bounds__(64) void stats_level2_kernel(int nchunks, const double* __restrict__ part8, double* __restrict__ out8) {
+  const int t = threadIdx.x;
   if (t >= 8) return;
   double a = t < 4 ? 0.0 : -__builtin_inf();
   for (int c0 = 0; c0 < nchunks; c0 += kChunkGroups) a = stat_level(part8 + (size_t)c0 * 8, min(kChunkGroups, nchunks - c0), t, a);
@@ -1138,7 +1132,7 @@ Layout make_layout(int N) {
   L.red_cmax = o; o = align256(o + (size_t)L.nchunks * sizeof(int));
   L.red_lvl = o; o = align256(o + (size_t)L.nchunks * sizeof(long long));
   L.red_part8 = o; o = align256(o + (size_t)L.nchunks * 8 * sizeof(double));
-  L.red_ticket = o; o = align256(o + 2 * sizeof(unsigned));  // last-block tickets of logs_kernel / stats_kernel (0 between launches)
+  L.red_ticket = o; o = align256(o + 2 * sizeof(unsigned));  // reserved (the ticket words of round 4's first logs kernels); keeps the blob layout
   L.reset_stamp = o; o = align256(o + 2 * sizeof(int32_t));
   L.total = o;
   return L;
@@ -1268,6 +1262,7 @@ struct ois_env {
   unsigned long long logs_seq;   // sequence number of the last logs_kernel enqueued with the host block
   bool logs_on;                  // ois_step enqueues logs_kernel behind the step kernel
   bool logs_current;             // the last enqueued logs_kernel saw the current state
+  float level_mean;              // torch.mean(terrain_levels) of a terrain whose levels cannot move (no curriculum), else < 0
   bool logs_force;               // state changed by something other than a step since the last logs kernel (reset, state blob,
                                  // terrain): the record on the device may be stale although its stamp is the newest
 };
@@ -1437,7 +1432,7 @@ int ois_create(const ois_config* cfg, int device, void* workspace_device, size_t
   std::memset(&B.ter, 0, sizeof B.ter);
   e->rp_mem = nullptr; e->rp_head = 0; e->rp_filled = false;
   e->prof_on = false; e->prof_used = 0; e->prof_ms = 0.0; e->prof_launches = 0;
-  e->logs_host = nullptr; e->logs_seq = 0; e->logs_on = false; e->logs_current = false; e->logs_force = true;
+  e->logs_host = nullptr; e->logs_seq = 0; e->logs_on = false; e->logs_current = false; e->logs_force = true; e->level_mean = -1.0f;
   // default per-arena parameters: mu = cfg.friction, flat plane n = +z
   hipError_t he = hipMemsetAsync(e->ws, 0, L.total, nullptr);
   if (he == hipSuccess) {
@@ -1615,14 +1610,16 @@ static int enqueue_logs(ois_env* e, void* stream) {
   A.part = (float*)(e->ws + e->L.red_part);
   A.cmax = (int*)(e->ws + e->L.red_cmax);
   A.lvl = (long long*)(e->ws + e->L.red_lvl);
-  A.ticket = (unsigned*)(e->ws + e->L.red_ticket);
+  A.level_mean = e->B.ter.on ? e->level_mean : -1.0f;
   A.host_block = e->logs_host;
   A.seq = e->logs_host ? e->logs_seq + 1 : 0;
-  if (!e->B.ter.on && e->L.nchunks <= kBlockChunks)  // one workgroup, no cross-XCD hop (logs_block_kernel)
+  if (e->L.nchunks <= kBlockChunks && (!e->B.ter.on || e->level_mean >= 0.0f))  // one workgroup, no cross-XCD hop (logs_block_kernel)
     hipLaunchKernelGGL(logs_block_kernel, dim3(1), dim3(kLogsThreads), 0, (hipStream_t)stream, e->K, e->B, e->L.nwaves, e->L.nchunks, e->N, A,
                        e->logs_force ? 1 : 0);
-  else
-    hipLaunchKernelGGL(logs_kernel, dim3(e->L.nchunks), dim3(64), 0, (hipStream_t)stream, e->K, e->B, e->L.nwaves, e->L.nchunks, e->N, A);
+  else {
+    hipLaunchKernelGGL(logs_level1_kernel, dim3(e->L.nchunks), dim3(64), 0, (hipStream_t)stream, e->B, e->L.nwaves, e->N, A);
+    hipLaunchKernelGGL(logs_level2_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, e->K, e->B, e->L.nchunks, e->N, A);
+  }
   HIP_TRY(hipGetLastError());
   e->logs_force = false;
   if (e->logs_host) { e->logs_seq += 1; e->logs_current = true; }
@@ -1720,6 +1717,7 @@ int ois_terrain_attach(ois_env* e, const ois_terrain* t, const int16_t* heights_
   hipStream_t s = (hipStream_t)stream;
   const size_t f4 = (size_t)e->N * 4 * sizeof(float);
   e->logs_current = false; e->logs_force = true;  // the terrain-level mean of extras["episode"] changes with the attachment
+  e->level_mean = -1.0f;
   if (!t) {  // detach: back to the per-arena plane, origins and indices cleared
     std::memset(&e->B.ter, 0, sizeof e->B.ter);
     e->K.task.cmd_sampler = e->cfg.cmd_sampler;
@@ -1751,6 +1749,11 @@ int ois_terrain_attach(ois_env* e, const ois_terrain* t, const int16_t* heights_
     if (lvl < 0 || lvl >= t->num_levels || typ < 0 || typ >= t->num_types) return fail(OIS_EINVAL, "terrain level / type out of range");
     idx[(size_t)4 * i] = lvl; idx[(size_t)4 * i + 1] = typ;
     for (int k = 0; k < 3; ++k) org[(size_t)4 * i + k] = tab[((size_t)lvl * t->num_types + typ) * 3 + k];
+  }
+  if (!t->curriculum) {  // the levels cannot move: their mean (KAMMA.py:488) is known here, as the same float the kernels would form
+    long long lsum = 0;
+    for (int i = 0; i < e->N; ++i) lsum += levels_types_host[2 * i];
+    e->level_mean = (float)lsum / (float)e->N;
   }
   HIP_TRY(hipMemcpyAsync(e->B.env_origins, org.data(), f4, hipMemcpyHostToDevice, s));
   HIP_TRY(hipMemcpyAsync(e->B.terrain_idx, idx.data(), f4, hipMemcpyHostToDevice, s));
@@ -1873,8 +1876,8 @@ int ois_stats_fetch(ois_env* e, ois_stats* out, int reset_after, void* stream) {
   OIS_ON_DEVICE(e->device);
   double* d = (double*)(e->ws + e->L.stat_out);
   double* part8 = (double*)(e->ws + e->L.red_part8);
-  hipLaunchKernelGGL(stats_kernel, dim3(e->L.nchunks), dim3(64), 0, (hipStream_t)stream, e->B, e->L.nwaves, e->L.nchunks, part8, d,
-                     (unsigned*)(e->ws + e->L.red_ticket) + 1, reset_after);
+  hipLaunchKernelGGL(stats_level1_kernel, dim3(e->L.nchunks), dim3(64), 0, (hipStream_t)stream, e->B, e->L.nwaves, part8, reset_after);
+  hipLaunchKernelGGL(stats_level2_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, e->L.nchunks, part8, d);
   HIP_TRY(hipGetLastError());
   double h[8];
   HIP_TRY(hipMemcpyAsync(h, d, sizeof h, hipMemcpyDeviceToHost, (hipStream_t)stream));
@@ -2023,6 +2026,7 @@ int ois_load_state(ois_env* e, const void* host_blob, size_t bytes, void* stream
   HIP_TRY(hipStreamSynchronize((hipStream_t)stream));
   e->reset_done = h.reset_done != 0;
   e->logs_current = false; e->logs_force = true;
+  e->level_mean = -1.0f;  // the terrain rows came with the blob: the level mean is summed on the device from now on
   e->seed = h.seed;
   e->K.task.seed_lo = (uint32_t)(h.seed & 0xffffffffu);
   e->K.task.seed_hi = (uint32_t)(h.seed >> 32);

@@ -109,9 +109,9 @@ def test_eval_variants_zero_old_torques_of_every_arena_on_any_reset(variant, N):
 
 @pytest.mark.parametrize("N", [1, 1000, 66000, 140000, 524288])
 def test_one_launch_logging_reductions_against_the_oracle(N):
-    """extras["episode"] and the finished-episode statistics are one launch each since round 4 (logs_kernel / stats_kernel:
-    the wave with the last ticket does level 2). Same two-level order as the oracle, bit for bit: 1 chunk, 1 ragged chunk,
-    65 chunks (one workgroup, 16 waves x 2 chunks x 3 passes), 137 and 512 chunks (the one-wave-per-chunk kernel: three / eight level-2 batches); after post_reset (every group carries stamp 0),
+    """extras["episode"] and the finished-episode statistics since round 4 (logs_block_kernel: one workgroup; logs_level1 / level2
+    and stats_level1 / level2: two launches). Same two-level order as the oracle, bit for bit: 1 chunk, 1 ragged chunk,
+    65 chunks (one workgroup, 16 waves x 2 chunks x 3 passes), 137 and 512 chunks (one wave per chunk, then three / eight level-2 batches); after post_reset (every group carries stamp 0),
     after single falls (one group, one chunk), after two falls in different chunks of one step, and with short episodes after
     the synchronous timeout. The block ois_logs_fetch publishes in pinned host memory == the device buffers == the oracle."""
     cfg, dev, orc = make_pair(variant="KAMMA_medium", num_envs=N, seed=31, max_episode_length=6,  # timeout when episode_buf reaches 5
