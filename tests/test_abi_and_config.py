@@ -259,3 +259,15 @@ def test_observed_components_are_the_references_python_double_arithmetic():
             assert got[k] == float(w) or (np.isnan(got[k]) and np.isnan(w)), (k, got[k], w, d[27])
         assert got["env0_desired_v"] == float(d64[0]) and got["env0_episode_count"] == int(d64[8]) and isinstance(got["env0_episode_count"], int)
         assert set(ENV0_TAGS) <= set(got) and len(got) == 26   # the 26 keys the trainer reads (base_KA_DDPG.py:184-209)
+
+
+def test_committed_profiles_were_taken_on_these_kernel_sources():
+    """every profiles/r4_* artefact bench.py quotes names the sha256 of the kernel sources it was taken on; at a commit they
+    are the checkout's (a kernel edit without `tools/profile_round.sh` + `tools/isa_census.py --json` shows up here, not in a
+    silently stale roofline)"""
+    import json
+    import bench
+    h = bench.kernel_source_hash()
+    assert h in open(os.path.join(ROOT, "profiles", f"{bench.ROUND}_kernel_src_sha256.txt")).read()
+    for name in (f"{bench.ROUND}_isa_census.json", f"{bench.ROUND}_pmc_sq.json", f"{bench.ROUND}_pmc_traffic.json"):
+        assert json.load(open(os.path.join(ROOT, "profiles", name)))["kernel_src_sha256"] == h, name
