@@ -201,6 +201,27 @@ def test_domain_randomisation_parity():
     compare(dev, orc, "sloped arenas, expert controller", exact_float=True)
 
 
+@pytest.mark.parametrize("N,shell", [(32768, "step_kernel<2,"), (32769, "step_kernel<1,"), (65536, "step_kernel<1,"), (65537, "step_kernel_w2<")])
+def test_shell_selection_boundaries(N, shell, lanes_per_arena):
+    """The library picks the step kernel by arena count: a lane pair per arena up to 32 768 (= one wave per SIMD of an
+    MI355X), one lane per arena with one wave per SIMD claimed up to 65 536, two waves per SIMD allowed above. At each
+    boundary and one arena beyond it (a last wave with a single live lane): the shell ois_kernel_info names, and three steps +
+    a fused rollout bit-identical to the oracle."""
+    cfg, dev, orc = make_pair(variant="KAMMA_medium", num_envs=N, seed=23, oracle_threads=8)
+    if lanes_per_arena == "by-size":
+        assert dev.kernel_info().startswith(shell), dev.kernel_info()
+    dev.reset(23); orc.reset(23)
+    rng = np.random.default_rng(N)
+    for t in range(3):
+        a = rng.uniform(0, 1, size=(N, 4)).astype(np.float32)
+        dev.step(torch.from_numpy(a).cuda()); orc.step(a)
+    compare(dev, orc, f"N={N} single steps", exact_float=True)
+    dev.rollout(4, _abi.POLICY_RANDOM); orc.rollout(4, _abi.POLICY_RANDOM)
+    compare(dev, orc, f"N={N} fused rollout", exact_float=True)
+    np.testing.assert_array_equal(dev.host_logs()[0], orc.episode_info())
+    dev.close()
+
+
 def test_sharding_invariance():
     """arena i gets the same stream whether it lives in a 1-GPU env or in shard 1 of 2."""
     from options_in_simulation_amd.vecenv import NativeEnv
