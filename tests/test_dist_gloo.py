@@ -31,20 +31,23 @@ def _free_port():
         return s.getsockname()[1]
 
 
-def _worker(rank, world, port, total, steps, out_dir):
+def _worker(rank, world, port, total, steps, out_dir, variant="KAMMA_medium"):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     dist.init_process_group("gloo", rank=rank, world_size=world)
     from oracle.binding import OracleEnv
     lo, hi = shard_range(total, rank, world)
-    env = OracleEnv(build_config(variant="KAMMA_medium", num_envs=hi - lo, seed=11, arena_offset=lo, max_sim_steps=80.0))
+    cfg = build_config(variant=variant, num_envs=hi - lo, seed=11, arena_offset=lo, max_sim_steps=80.0)
+    env = OracleEnv(cfg)
     env.reset(11)
     env.rollout(steps, _abi.POLICY_RANDOM)
     parts = gather_stats(env.stats(reset_after=True))
     assert len(parts) == world
     merged = merge_stats(parts)
     np.save(os.path.join(out_dir, f"state_{rank}.npy"), env.buffer(_abi.BUF_POSE))
-    info = gather_episode_info(env.episode_info(), hi - lo)
+    info = gather_episode_info(env.episode_info(), hi - lo, eval_keys=bool(cfg.eval_sums), single_gamma=cfg.mix_mode == _abi.MIX_BLEND)
     if rank == 0:
+        with open(os.path.join(out_dir, "info_keys.txt"), "w") as f:
+            f.write("\n".join(info))                                  # the ORDER the merged dict has
         np.save(os.path.join(out_dir, "info.npy"), np.array([info[k] for k in sorted(info)]))
         np.save(os.path.join(out_dir, "merged.npy"), np.array([merged["episodes"], merged["return_mean"], merged["return_min"],
                                                                  merged["return_max"], merged["steps"], merged["length_mean"]]))
@@ -52,11 +55,16 @@ def _worker(rank, world, port, total, steps, out_dir):
     dist.destroy_process_group()
 
 
-def test_two_rank_sharded_run_matches_single_process(tmp_path):
+@pytest.mark.parametrize("variant", ["KAMMA_medium", "KA_DDPG_2D_eval"])
+def test_two_rank_sharded_run_matches_single_process(tmp_path, variant):
+    """two gloo ranks, each with its shard of the arenas, against the unsharded run: every arena's state, the merged episode
+    statistics, and the merged extras["episode"] — under the key set and in the order of the variant's own env file (KA-DDPG:
+    one "gamma assist"; the eval files: three more sums), i.e. what a single-rank infos["episode"] iterates"""
     total, steps, world = 100, 110, 2
-    mp.spawn(_worker, args=(world, _free_port(), total, steps, str(tmp_path)), nprocs=world, join=True)
+    mp.spawn(_worker, args=(world, _free_port(), total, steps, str(tmp_path), variant), nprocs=world, join=True)
     from oracle.binding import OracleEnv
-    full = OracleEnv(build_config(variant="KAMMA_medium", num_envs=total, seed=11, max_sim_steps=80.0))
+    fcfg = build_config(variant=variant, num_envs=total, seed=11, max_sim_steps=80.0)
+    full = OracleEnv(fcfg)
     full.reset(11)
     full.rollout(steps, _abi.POLICY_RANDOM)
     cat = np.concatenate([np.load(tmp_path / f"state_{r}.npy") for r in range(world)])
@@ -69,7 +77,10 @@ def test_two_rank_sharded_run_matches_single_process(tmp_path):
     assert merged[4] == total * steps and merged[5] == 99.0
     # the merged extras of the two shards = the extras of the unsharded run (same reset event)
     ei = full.episode_info()
-    ref = {key: float(ei[slot]) for key, slot in _abi.episode_info_layout(True, False)}   # the key set a single-rank infos["episode"] has
+    layout = _abi.episode_info_layout(bool(fcfg.eval_sums), fcfg.mix_mode == _abi.MIX_BLEND)
+    ref = {key: float(ei[slot]) for key, slot in layout}   # the key set a single-rank infos["episode"] has
+    assert open(tmp_path / "info_keys.txt").read().split("\n") == [k for k, _ in layout] + ["count", "step"]
+    assert ("gamma assist" in ref) == (variant != "KAMMA_medium") and ("rew_Smoothness" in ref) == (variant != "KAMMA_medium")
     ref["count"], ref["step"] = float(ei[_abi.EI_COUNT]), float(ei[_abi.EI_STEP])
     got = dict(zip(sorted(ref), np.load(tmp_path / "info.npy")))
     assert got["count"] == ref["count"] > 0 and got["step"] == ref["step"]
