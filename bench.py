@@ -127,7 +127,8 @@ def executed_flop_per_env_step(kernel_id, substeps, profile=None):
         return FLOP_PER_ENV_STEP, None, prov
     lanes = 2 if kernel_id.startswith("step_kernel<2") else 1
     prov["status"] = "quoted: executed path of the substep loop x substeps x lanes per arena (pre / post-physics not counted)"
-    return float(k["substep_flop_per_lane"] * lanes * substeps), float(k["substep_valu"] * substeps), prov
+    per = float(k.get("loop_substeps", 1))  # substeps one iteration of the census's loop holds (2 with footprint stride 2)
+    return float(k["substep_flop_per_lane"] * lanes * substeps) / per, float(k["substep_valu"] * substeps) / per, prov
 
 
 def pmc_sq(n_arenas, profile=None):
@@ -258,6 +259,8 @@ def parse_args(argv):
                     help="BASELINE.json configs[3]: per-arena friction U(0.5, 1.0) and plane slope from the generator's set")
     ap.add_argument("--terrain", action="store_true",
                     help="configs[3] on the reference's full terrain family: 6 x 2 random tiles, wheel contact on the height field")
+    ap.add_argument("--footprint-stride", type=int, default=1, choices=(1, 2),
+                    help="with --terrain: ois_terrain.footprint_stride (2 = wheel footprints sampled every second substep, docs/SPEC.md 3.8)")
     return ap.parse_args(argv)
 
 
@@ -404,7 +407,8 @@ def main(argv=None):
     if args.domain_rand:
         terrain_note = "per-arena friction U(0.5,1.0) + plane slope {-0.3,-0.2,0,0.2,0.3}"
     if args.terrain:
-        terrain_note = "height-field terrain, 6 x 2 random tiles of 10 m (stairs +-0.15 m, obstacles, pyramid slopes)"
+        terrain_note = "height-field terrain, 6 x 2 random tiles of 10 m (stairs +-0.15 m, obstacles, pyramid slopes)" + (
+            ", footprints sampled every 2nd substep (ois_terrain.footprint_stride = 2)" if args.footprint_stride == 2 else "")
 
     def make_env(c=None):
         c = cfg if c is None else c
@@ -415,7 +419,7 @@ def main(argv=None):
             import numpy as np
             from options_in_simulation_amd import terrain as tg
             T = tg.Terrain({"numLevels": 6, "numTerrains": 2, "mapLength": 10.0, "mapWidth": 10.0}, N, seed=42)
-            e.attach_terrain(T, T.sample_levels_types(N, rng=np.random.RandomState(rank)))
+            e.attach_terrain(T, T.sample_levels_types(N, rng=np.random.RandomState(rank)), footprint_stride=args.footprint_stride)
         e.reset(42)
         return e
 

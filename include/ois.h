@@ -69,7 +69,7 @@ extern "C" {
  *    also refuses an unstable joint resistance and a negative depenetration velocity */
 /* 6: ois_logs_enable / ois_logs_fetch (the step's logs through pinned host memory); ois_episode_info and ois_stats_fetch are
  *    restructured (one launch of one workgroup / two launches); the workspace grew by one 256-byte slot (state blobs of
- *    version 5 do not load) */
+ *    version 5 do not load); ois_terrain grew by footprint_stride (struct_bytes = 52) */
 #define OIS_ABI_VERSION 6
 
 /* error codes */
@@ -441,6 +441,10 @@ typedef struct ois_terrain {
   int32_t curriculum;        /* terrain.curriculum KAMMA.py:265 */
   float threshold_low, threshold_high; /* 0.3, 5.0 KAMMA.py:509-510 */
   int32_t max_level;         /* 5 KAMMA.py:525 */
+  int32_t footprint_stride;  /* 1 (0 reads as 1): the wheel footprints are sampled on the field at every substep. 2: at every
+                                second substep; the substeps between keep the fitted plane (docs/SPEC.md section 3.8). Build-
+                                defined (the reference's terrain is commented out, KAMMA.py:296-349): a cheaper contact, not
+                                the same trajectories: a wheel meets an edge of the field up to one substep (<= 2 cm) later */
 } ois_terrain;
 /* heights_device: int16 [rows, cols]; terrain_origins_device: float [num_levels, num_types, 3];
  * levels_types_host: int32 [N, 2] initial terrain_levels / terrain_types (host memory, copied).

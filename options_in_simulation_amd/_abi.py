@@ -164,6 +164,7 @@ class OisTerrain(C.Structure):
         ("horizontal_scale", C.c_float), ("vertical_scale", C.c_float), ("border_size", C.c_float),
         ("num_levels", C.c_int32), ("num_types", C.c_int32), ("curriculum", C.c_int32),
         ("threshold_low", C.c_float), ("threshold_high", C.c_float), ("max_level", C.c_int32),
+        ("footprint_stride", C.c_int32),
     ]
 
 

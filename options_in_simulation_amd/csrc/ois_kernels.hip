@@ -123,7 +123,7 @@ OIS_DEV void store_arena(bool eval_sums, const RowPtrs& R, const WheelPtrs& Wp, 
 }
 
 // ------------------------------------------------------------------ the step kernel ---
-template <int LPA, bool PK, bool TER, int NIT, bool FLAT = false, bool FOLD = false>
+template <int LPA, bool PK, bool TER, int NIT, bool FLAT = false, bool FOLD = false, int TSTRIDE = 1>
 OIS_DEV void step_body(const PhysK& K, const DevBuffers& B, const float* __restrict__ actions,
                        float* __restrict__ reward_sum, int N, int ksteps, int policy, int rp_head) {
   // K: the physics constants only, by value. Everything else of the kernel's arguments that a LATER phase needs (task
@@ -300,7 +300,26 @@ OIS_DEV void step_body(const PhysK& K, const DevBuffers& B, const float* __restr
       X.mu = S.mu;
 #pragma unroll
       for (int k = 0; k < 3; ++k) X.to[k] = tor[k];
-      if constexpr (PK && LPA == 1) {  // packed fp32 over wheel pairs (ois_physics_pk.h)
+      if constexpr (TER && TSTRIDE == 2) {
+        // ois_terrain.footprint_stride = 2 (SPEC 3.8): the later substeps in pairs — an odd one fits the plane to the stored
+        // sample and samples nothing, the even one after it samples, keeps that plane and refreshes its reciprocals by Newton
+        int i = 1;
+        if constexpr (PK) {
+          substep_pk<true, true, NIT>(K, B.ter, X);
+          for (; i + 1 < K.nsub; i += 2) {
+            substep_pk<false, true, NIT, false, kOddSubstep>(K, B.ter, X);
+            substep_pk<false, true, NIT, false, kEvenSubstep>(K, B.ter, X);
+          }
+          if (i < K.nsub) substep_pk<false, true, NIT, false, kOddSubstep>(K, B.ter, X);
+        } else {
+          substep<true, 1, true, NIT>(K, B.ter, wheel0, X);
+          for (; i + 1 < K.nsub; i += 2) {
+            substep<false, 1, true, NIT, kOddSubstep>(K, B.ter, wheel0, X);
+            substep<false, 1, true, NIT, kEvenSubstep>(K, B.ter, wheel0, X);
+          }
+          if (i < K.nsub) substep<false, 1, true, NIT, kOddSubstep>(K, B.ter, wheel0, X);
+        }
+      } else if constexpr (PK && LPA == 1) {  // packed fp32 over wheel pairs (ois_physics_pk.h)
         substep_pk<true, TER, NIT, FLAT>(K, B.ter, X);
         for (int i = 1; i < K.nsub; ++i) substep_pk<false, TER, NIT, FLAT>(K, B.ter, X);
       } else if constexpr (PK && LPA == 2) {  // a lane pair per arena, each lane one packed side pair
@@ -535,11 +554,12 @@ void step_kernel_w2(DevConsts K, DevBuffers B, const float* __restrict__ actions
                     int ksteps, int policy, int rp_head) {
   step_body<1, PK, false, NIT, FLAT, FOLD>(K.phys, B, actions, reward_sum, N, ksteps, policy, rp_head);
 }
-template <bool PK, int NIT, bool FOLD = false>
+// TSTRIDE: ois_terrain.footprint_stride (1: every substep samples its footprints; 2: every second one, SPEC 3.8)
+template <bool PK, int NIT, bool FOLD = false, int TSTRIDE = 1>
 __global__ __launch_bounds__(kBlock) void step_kernel_terrain(DevConsts K, DevBuffers B, const float* __restrict__ actions,
                                                               float* __restrict__ reward_sum, int N, int ksteps, int policy,
                                                               int rp_head) {
-  step_body<1, PK, true, NIT, false, FOLD>(K.phys, B, actions, reward_sum, N, ksteps, policy, rp_head);
+  step_body<1, PK, true, NIT, false, FOLD, TSTRIDE>(K.phys, B, actions, reward_sum, N, ksteps, policy, rp_head);
 }
 
 // ------------------------------------------------------------------ get_heights -------
@@ -1546,7 +1566,7 @@ static int launch_kernel(ois_env* e, int k, int policy, const float* actions, fl
   const bool it4 = e->K.phys.iters == 4;
   const bool flat = e->flat && e->packed && it4 && !e->B.ter.on;  // the FLAT shells exist for the default configuration
   if ((policy & 0x200) != 0) {  // continuation launch of a level-curriculum rollout (can_fold() said these shells exist)
-    if (e->B.ter.on) OIS_LAUNCH((step_kernel_terrain<true, 4, true>), 1);
+    if (e->B.ter.on) { if (e->tdesc.footprint_stride == 2) OIS_LAUNCH((step_kernel_terrain<true, 4, true, 2>), 1); else OIS_LAUNCH((step_kernel_terrain<true, 4, true>), 1); }
     else if (e->lpa == 2) { if (flat) OIS_LAUNCH((step_kernel<2, true, 4, true, true>), 2); else OIS_LAUNCH((step_kernel<2, true, 4, false, true>), 2); }
     else if (e->waves2) { if (flat) OIS_LAUNCH((step_kernel_w2<true, 4, true, true>), 1); else OIS_LAUNCH((step_kernel_w2<true, 4, false, true>), 1); }
     else { if (flat) OIS_LAUNCH((step_kernel<1, true, 4, true, true>), 1); else OIS_LAUNCH((step_kernel<1, true, 4, false, true>), 1); }
@@ -1557,6 +1577,10 @@ static int launch_kernel(ois_env* e, int k, int policy, const float* actions, fl
   } else if (e->lpa == 2) {
     if (e->packed) { if (it4) OIS_LAUNCH((step_kernel<2, true, 4>), 2); else OIS_LAUNCH((step_kernel<2, true, 0>), 2); }
     else OIS_LAUNCH((step_kernel<2, false, 0>), 2);
+  }
+  else if (e->B.ter.on && e->tdesc.footprint_stride == 2) {
+    if (e->packed) { if (it4) OIS_LAUNCH((step_kernel_terrain<true, 4, false, 2>), 1); else OIS_LAUNCH((step_kernel_terrain<true, 0, false, 2>), 1); }
+    else           { if (it4) OIS_LAUNCH((step_kernel_terrain<false, 4, false, 2>), 1); else OIS_LAUNCH((step_kernel_terrain<false, 0, false, 2>), 1); }
   }
   else if (e->B.ter.on) {
     if (e->packed) { if (it4) OIS_LAUNCH((step_kernel_terrain<true, 4>), 1); else OIS_LAUNCH((step_kernel_terrain<true, 0>), 1); }
@@ -1700,12 +1724,12 @@ int ois_kernel_info(const ois_env* e, char* out, size_t cap) {
   const bool flat = e->flat && e->packed && it4 && !e->B.ter.on;
   const int nit = it4 ? 4 : 0, pk = e->packed ? 1 : 0;
   char id[64];
-  if (e->B.ter.on) std::snprintf(id, sizeof id, "step_kernel_terrain<%d,%d>", pk, nit);
+  if (e->B.ter.on) std::snprintf(id, sizeof id, "step_kernel_terrain<%d,%d>%s", pk, nit, e->tdesc.footprint_stride == 2 ? "+stride2" : "");
   else if (e->lpa == 2) std::snprintf(id, sizeof id, "step_kernel<2,%d,%d,%d>", pk, pk ? nit : 0, flat ? 1 : 0);
   else if (e->waves2) std::snprintf(id, sizeof id, "step_kernel_w2<%d,%d,%d>", pk, nit, flat ? 1 : 0);
   else std::snprintf(id, sizeof id, "step_kernel<1,%d,%d,%d>", pk, nit, flat ? 1 : 0);
   std::snprintf(out, cap, "%s lanes_per_arena=%d %s iterations=%s plane=%s%s", id, e->B.ter.on ? 1 : e->lpa,
-                e->packed ? "packed" : "scalar", it4 ? "4(unrolled)" : "runtime", e->B.ter.on ? "height-field" : (flat ? "flat" : "per-arena"),
+                e->packed ? "packed" : "scalar", it4 ? "4(unrolled)" : "runtime", e->B.ter.on ? (e->tdesc.footprint_stride == 2 ? "height-field(footprints every 2nd substep)" : "height-field") : (flat ? "flat" : "per-arena"),
                 e->K.task.cmd_sampler == OIS_CMD_LEVEL ? " +level_command_kernel" : "");
   return OIS_OK;
 }
@@ -1731,6 +1755,7 @@ int ois_terrain_attach(ois_env* e, const ois_terrain* t, const int16_t* heights_
       t->max_level < 0 || t->max_level >= t->num_levels || !heights_device || !minfield_device || !terrain_origins_device ||
       !levels_types_host)
     return fail(OIS_EINVAL, "bad terrain description");
+  if (t->footprint_stride < 0 || t->footprint_stride > 2) return fail(OIS_EINVAL, "ois_terrain.footprint_stride must be 1 or 2 (0 = 1)");
   if (e->lpa_forced == 2) return fail(OIS_EINVAL, "the terrain contact needs one lane per arena (unset OIS_LANES_PER_ARENA)");
   // the *_eval files test evalsampling before curriculum (KAMMA_eval.py:544): their per-step re-draw would be the eval ramp
   if (t->curriculum && e->cfg.cmd_sampler == OIS_CMD_EVAL) return fail(OIS_EINVAL, "terrain.curriculum with the EvalSampling commands is not supported");
@@ -1778,6 +1803,7 @@ int ois_terrain_attach(ois_env* e, const ois_terrain* t, const int16_t* heights_
   T.hs = t->horizontal_scale; T.inv_hs = 1.0f / t->horizontal_scale; T.vs = t->vertical_scale; T.border = t->border_size;
   T.thr_lo = t->threshold_low; T.thr_hi = t->threshold_high;
   e->tdesc = *t;
+  if (e->tdesc.footprint_stride != 2) e->tdesc.footprint_stride = 1;
   // terrain.curriculum also switches the commands to the per-level generators (KAMMA.py:533, 719)
   e->K.task.cmd_sampler = t->curriculum ? OIS_CMD_LEVEL : e->cfg.cmd_sampler;
   pick_lpa(e);
@@ -1963,7 +1989,7 @@ static uint64_t fnv1a(const void* p, size_t n, uint64_t h = 1469598103934665603u
 static uint64_t terrain_hash(const ois_env* e) {
   if (!e->B.ter.on) return 0;
   const ois_terrain& t = e->tdesc;
-  const int32_t iv[7] = {t.rows, t.cols, t.num_levels, t.num_types, t.curriculum, t.max_level, 1};
+  const int32_t iv[7] = {t.rows, t.cols, t.num_levels, t.num_types, t.curriculum, t.max_level, t.footprint_stride};  // stride: 1 or 2 (attach)
   const float fv[5] = {t.horizontal_scale, t.vertical_scale, t.border_size, t.threshold_low, t.threshold_high};
   return fnv1a(fv, sizeof fv, fnv1a(iv, sizeof iv)) | 1ull;
 }

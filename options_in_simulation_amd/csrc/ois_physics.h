@@ -31,6 +31,7 @@ struct PhysT {
   // wheel footprints sampled at the start of the previous substep (TER only, SPEC §3.8)
   float fwx[4], fwy[4], fh[4], fr00, fr10, fr01, fr11;
   int fpx[4], fpy[4];      // field cell of each stored footprint (gather cache, see terrain_footprints)
+  float pn[3], poff[4];    // footprint stride 2 only: the plane an odd substep fitted, kept by the even substep after it
 };
 
 // 1.0f / d, correctly rounded, for finite d with 2^-40 <= |d| < 2^40: the refinement chain of the
@@ -145,8 +146,13 @@ OIS_DEV float average4(const float (&c)[4 / LPA]) { return 0.25f * sum_wheels<LP
 // right-side lane when LPA = 2).
 // NIT: solver iterations known at compile time (the loop is fully unrolled: no taken branch,
 // scheduling across iteration boundaries) or 0 = K.iters at run time
-template <bool EXACT, int LPA, bool TER = false, int NIT = 0>
+// TMODE (height field with ois_terrain.footprint_stride = 2, SPEC 3.8; 0 = every substep samples): kOddSubstep fits the plane
+// to the stored sample and samples nothing; kEvenSubstep samples (for the substep after it), keeps the plane of the substep
+// before it and refreshes the reciprocals by Newton like a substep on the plane.
+constexpr int kEverySubstep = 0, kOddSubstep = 1, kEvenSubstep = 2;
+template <bool EXACT, int LPA, bool TER = false, int NIT = 0, int TMODE = kEverySubstep>
 OIS_DEV void substep(const PhysK& K, const DevTerrain& T, int wheel0, PhysT<LPA>& S) {
+  static_assert(TMODE == kEverySubstep || (TER && !EXACT), "footprint stride modes: later substeps on a height field");
   static_assert(!TER || LPA == 1, "the terrain contact needs all 4 wheels in one lane");
   constexpr int W = 4 / LPA;
 #define OIS_WH _Pragma("unroll") for (int k = 0; k < W; ++k)
@@ -158,9 +164,22 @@ OIS_DEV void substep(const PhysK& K, const DevTerrain& T, int wheel0, PhysT<LPA>
   if constexpr (TER) {
     // fit the plane to the footprints sampled one substep earlier (the first substep of a policy
     // step samples its own): this substep's 8 gathers stay in flight during the whole solve
-    terrain_footprints<EXACT>(K, T, S, R, cur);
+    if constexpr (TMODE != kOddSubstep) terrain_footprints<EXACT>(K, T, S, R, cur);
     if (EXACT) footprints_store(S, cur);
-    terrain_plane(K, S, n, off);
+    if constexpr (TMODE == kEvenSubstep) {
+#pragma unroll
+      for (int k = 0; k < 3; ++k) n[k] = S.pn[k];
+#pragma unroll
+      for (int k = 0; k < 4; ++k) off[k] = S.poff[k];
+    } else {
+      terrain_plane(K, S, n, off);
+      if constexpr (TMODE == kOddSubstep) {
+#pragma unroll
+        for (int k = 0; k < 3; ++k) S.pn[k] = n[k];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) S.poff[k] = off[k];
+      }
+    }
   }
   rotT(R, S.v, vb);
   rotT(R, n, nb);
@@ -181,7 +200,7 @@ OIS_DEV void substep(const PhysK& K, const DevTerrain& T, int wheel0, PhysT<LPA>
   // contact frame shared by the four wheels (common axle direction = body y)
   float s2 = __builtin_fmaf(nb[2], nb[2], nb[0] * nb[0]);
   s2 = fmaxf(s2, 1e-12f);
-  constexpr bool REX = EXACT || TER;  // on a height field the geometry may jump: exact reciprocals every substep
+  constexpr bool REX = EXACT || (TER && TMODE != kEvenSubstep);  // on a height field the geometry may jump: exact reciprocals in every substep that fits a plane
   const float inv_s = REX ? exact_rcp(sqrtf(s2)) : newton_rsqrt(S.inv_s, s2);  // s2 >= 1e-12
   S.inv_s = inv_s;
   const float dx = -(nb[0] * inv_s), dz = -(nb[2] * inv_s);
@@ -311,7 +330,7 @@ OIS_DEV void substep(const PhysK& K, const DevTerrain& T, int wheel0, PhysT<LPA>
   float inv = __builtin_fmaf(-0.5f, nn, 1.5f);
   if (fabsf(nn - 1.0f) > 1e-3f) inv = 1.0f / sqrtf(nn);
   S.q[0] = nqw * inv; S.q[1] = nqx * inv; S.q[2] = nqy * inv; S.q[3] = nqz * inv;
-  if constexpr (TER) footprints_store(S, cur);
+  if constexpr (TER && TMODE != kOddSubstep) footprints_store(S, cur);
 #undef OIS_WH
 }
 

@@ -203,6 +203,8 @@ DEFAULT_TERRAIN_CFG: Dict[str, object] = {
     "slopeTreshold": 0.5,
     # read by Terrain.__init__ (:46) but absent from the reference's TASK_CFG
     "terrainProportions": [0.1, 0.5, 0.4],
+    # build-defined, not a key of the reference: ois_terrain.footprint_stride (include/ois.h; docs/SPEC.md section 3.8)
+    "footprintStride": 1,
 }
 
 

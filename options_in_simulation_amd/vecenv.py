@@ -260,11 +260,13 @@ class NativeEnv:
         self._logs_next = (blob, tensors, C.c_void_p(blob.ctypes.data), C.c_void_p(blob.ctypes.data + 4 * _abi.EPISODE_INFO_LEN))
 
     def attach_terrain(self, terrain, levels_types: np.ndarray, curriculum: Optional[bool] = None,
-                       threshold_low: float = 0.3, threshold_high: float = 5.0, max_level: Optional[int] = None):
+                       threshold_low: float = 0.3, threshold_high: float = 5.0, max_level: Optional[int] = None,
+                       footprint_stride: Optional[int] = None):
         """Put the arenas on a height field (include/ois.h ois_terrain_attach). ``terrain`` is a
         ``terrain.Terrain`` (or anything with heightsamples / env_origins / horizontal_scale /
         vertical_scale / border_size), ``levels_types`` int [N, 2] = terrain_levels, terrain_types
-        (KAMMA.py:340-347). Call before ``reset``."""
+        (KAMMA.py:340-347). ``footprint_stride`` (default: ``terrain.cfg["footprintStride"]`` or 1): 2 samples the wheel
+        footprints at every second substep only (docs/SPEC.md §3.8; build-defined). Call before ``reset``."""
         field = torch.from_numpy(np.ascontiguousarray(terrain.heightsamples, dtype=np.int16)).to(self.device)
         origins = torch.from_numpy(np.ascontiguousarray(terrain.env_origins, dtype=np.float32)).to(self.device)
         lt = np.ascontiguousarray(levels_types, dtype=np.int32).reshape(self.N, 2)
@@ -278,6 +280,7 @@ class NativeEnv:
         t.curriculum = int(bool(cur))
         t.threshold_low, t.threshold_high = float(threshold_low), float(threshold_high)
         t.max_level = int(min(5, t.num_levels - 1) if max_level is None else max_level)  # KAMMA.py:525
+        t.footprint_stride = int(getattr(terrain, "cfg", {}).get("footprintStride", 1) if footprint_stride is None else footprint_stride)
         # scratch the library fills with min(h[x][y], h[x+1][y+1]) in 8 x 8-cell tiles
         minfield = torch.empty(self.L.ois_minfield_bytes(t.rows, t.cols) // 2, dtype=torch.int16, device=self.device)
         torch.cuda.synchronize(self.device)

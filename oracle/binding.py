@@ -251,7 +251,8 @@ class OracleEnv:
         s = np.asarray(slopes, np.float32)
         self._check(self.L.orc_randomize_params(self.h, mu_lo, mu_hi, fptr(s) if s.size else None, int(s.size)))
 
-    def attach_terrain(self, terrain, levels_types, curriculum=None, threshold_low=0.3, threshold_high=5.0, max_level=None):
+    def attach_terrain(self, terrain, levels_types, curriculum=None, threshold_low=0.3, threshold_high=5.0, max_level=None,
+                       footprint_stride=None):
         f = np.ascontiguousarray(terrain.heightsamples, np.int16)
         o = np.ascontiguousarray(terrain.env_origins, np.float32)
         lt = np.ascontiguousarray(levels_types, np.int32).reshape(self.N, 2)
@@ -264,6 +265,7 @@ class OracleEnv:
         t.curriculum = int(bool(cur))
         t.threshold_low, t.threshold_high = threshold_low, threshold_high
         t.max_level = int(min(5, t.num_levels - 1) if max_level is None else max_level)
+        t.footprint_stride = int(getattr(terrain, "cfg", {}).get("footprintStride", 1) if footprint_stride is None else footprint_stride)
         self._check(self.L.orc_terrain_attach(self.h, C.byref(t), f.ctypes.data_as(C.POINTER(C.c_int16)), fptr(o), iptr(lt)))
 
     def detach_terrain(self):

@@ -561,6 +561,7 @@ typedef struct {
   const int16_t* h; /* [rows, cols] raw heights */
   int rows, cols;
   float inv_hs, hs, vs, border;
+  int stride; /* ois_terrain.footprint_stride: 1 = footprints sampled every substep, 2 = every second one (SPEC 3.8) */
 } terrain_ctx;
 
 /* ground height at world (x, y): the sampling rule of get_heights (KAMMA.py:882-893: pixel =
@@ -581,6 +582,11 @@ typedef struct {
   float wx[4], wy[4], h[4];
   float r00, r10, r01, r11;
 } footprints;
+/* what a substep hands to the next one on a height field: the stored sample and, for footprint_stride 2, the plane fitted to it */
+typedef struct {
+  footprints fp;
+  float n[3], off[4];
+} terrain_carry;
 
 static void terrain_footprints(const derived* D, const terrain_ctx* T, const float origin[3], const float p[3],
                                const float R[9], footprints* F) {
@@ -611,7 +617,14 @@ static void terrain_plane(const derived* D, const footprints* F, float n[3], flo
 
 static void substep(const derived* D, float mu, const float n_in[3], const float tau[4], float p[3],
                     float q[4], float v[3], float wb[3], float spin[4], float ln[4], float l1[4],
-                    float l2[4], rcache* C, int exact, const terrain_ctx* TR, const float* origin, footprints* FP) {
+                    float l2[4], rcache* C, int sub, const terrain_ctx* TR, const float* origin, terrain_carry* TC) {
+  const int exact = sub == 0;
+  /* footprint_stride 2 (SPEC 3.8): footprints are sampled at the start of EVEN substeps only. An odd substep fits the plane to
+   * the sample of the substep before it (exact reciprocals, as with stride 1); an even substep >= 2 keeps that plane and — the
+   * geometry it sees being continuous — refreshes the reciprocals by the Newton step of SPEC 3.6. */
+  const int stride2 = TR && TR->stride == 2;
+  const int sample = TR && (!stride2 || (sub & 1) == 0);
+  const int keep_plane = stride2 && !exact && (sub & 1) == 0;
   float R[9];
   rotmat(q, R);
   float vb[3], nb[3];
@@ -621,9 +634,16 @@ static void substep(const derived* D, float mu, const float n_in[3], const float
     /* the plane is fitted to the footprints sampled one substep EARLIER (the first substep of a
      * policy step samples its own): on the GPU the 8 gathers of this substep are then in flight
      * during the whole solve instead of stalling it (SPEC §3.8). A wheel moves <= 2 cm per substep. */
-    terrain_footprints(D, TR, origin, p, R, &cur);
-    if (exact) *FP = cur;
-    terrain_plane(D, FP, n, off);
+    if (sample) terrain_footprints(D, TR, origin, p, R, &cur);
+    if (exact) TC->fp = cur;
+    if (keep_plane) {
+      for (int k = 0; k < 3; ++k) n[k] = TC->n[k];
+      for (int k = 0; k < 4; ++k) off[k] = TC->off[k];
+    } else {
+      terrain_plane(D, &TC->fp, n, off);
+      for (int k = 0; k < 3; ++k) TC->n[k] = n[k];
+      for (int k = 0; k < 4; ++k) TC->off[k] = off[k];
+    }
   }
   rotT(R, v, vb);
   rotT(R, n, nb);
@@ -645,7 +665,7 @@ static void substep(const derived* D, float mu, const float n_in[3], const float
   /* contact frame shared by the four wheels (common axle direction = body y) */
   float s2 = fmaf(nb[2], nb[2], nb[0] * nb[0]);
   s2 = fmaxf(s2, 1e-12f);
-  const int rex = exact || TR != NULL; /* on a height field the geometry may jump: exact reciprocals every substep */
+  const int rex = exact || (TR != NULL && !keep_plane); /* on a height field the geometry may jump: exact reciprocals in every substep that fits a plane */
   float inv_s = rex ? 1.0f / sqrtf(s2) : newton_rsqrt(C->inv_s, s2);
   C->inv_s = inv_s;
   float dx = -(nb[0] * inv_s), dz = -(nb[2] * inv_s);
@@ -770,7 +790,7 @@ static void substep(const derived* D, float mu, const float n_in[3], const float
   float inv = fmaf(-0.5f, nn, 1.5f);
   if (fabsf(nn - 1.0f) > 1e-3f) inv = 1.0f / sqrtf(nn);
   q[0] = nqw * inv; q[1] = nqx * inv; q[2] = nqy * inv; q[3] = nqz * inv;
-  if (TR) *FP = cur;
+  if (sample) TC->fp = cur;
 }
 
 /* w is the WORLD angular velocity here (converted to the body frame and back) */
@@ -783,7 +803,7 @@ void orc_substep(const ois_config* cfg, float mu, const float n_world[3], const 
   rotmat(q, R);
   rotT(R, w, wb);
   rcache C;
-  substep(&D, mu, n_world, tau, p, q, v, wb, spin, lam_n, lam_l, lam_t, &C, 1, NULL, NULL, NULL);
+  substep(&D, mu, n_world, tau, p, q, v, wb, spin, lam_n, lam_l, lam_t, &C, 0, NULL, NULL, NULL);
   rotmat(q, R);
   rot(R, wb, w);
 }
@@ -1234,8 +1254,8 @@ static float step_arena(orc_env* e, int i, const float* act /*[A]*/, uint8_t* rs
   for (int k = 0; k < 4; ++k) { LN[k] = orc_h2f(e->lam_n[4 * i + k]); LL[k] = orc_h2f(e->lam_l[4 * i + k]); LT[k] = orc_h2f(e->lam_t[4 * i + k]); }
   rcache C;
   const terrain_ctx* T = e->terrain_on ? &e->terrain : NULL;
-  footprints FP;
-  for (int s = 0; s < nsub; ++s) substep(D, mu, n, wt, p, q, v, wb, spin, LN, LL, LT, &C, s == 0, T, &e->env_origins[4 * i], &FP);
+  terrain_carry TC;
+  for (int s = 0; s < nsub; ++s) substep(D, mu, n, wt, p, q, v, wb, spin, LN, LL, LT, &C, s, T, &e->env_origins[4 * i], &TC);
   /* Safety net (build-defined): a Newton refresh diverges if a row's effective mass more than
    * doubles between two substeps (needs > ~50 rad/s of tumbling) and could leave a non-finite
    * state; such an arena would never reset (every comparison of is_done is false on NaN) and
@@ -1467,6 +1487,7 @@ int orc_terrain_attach(orc_env* e, const ois_terrain* t, const int16_t* heights,
   if (t->rows < 2 || t->cols < 2 || !(t->horizontal_scale > 0.0f) || t->num_levels < 1 || t->num_types < 1 ||
       t->max_level < 0 || t->max_level >= t->num_levels || !heights || !terrain_origins || !levels_types)
     return fail(OIS_EINVAL, "bad terrain description");
+  if (t->footprint_stride < 0 || t->footprint_stride > 2) return fail(OIS_EINVAL, "ois_terrain.footprint_stride must be 1 or 2 (0 = 1)");
   for (int i = 0; i < e->N; ++i)
     if (levels_types[2 * i] < 0 || levels_types[2 * i] >= t->num_levels || levels_types[2 * i + 1] < 0 ||
         levels_types[2 * i + 1] >= t->num_types)
@@ -1481,6 +1502,7 @@ int orc_terrain_attach(orc_env* e, const ois_terrain* t, const int16_t* heights,
   e->terrain.h = e->theights; e->terrain.rows = t->rows; e->terrain.cols = t->cols;
   e->terrain.hs = t->horizontal_scale; e->terrain.inv_hs = 1.0f / t->horizontal_scale;
   e->terrain.vs = t->vertical_scale; e->terrain.border = t->border_size;
+  e->terrain.stride = t->footprint_stride == 2 ? 2 : 1;
   for (int i = 0; i < e->N; ++i) {
     int lvl = levels_types[2 * i], typ = levels_types[2 * i + 1];
     e->terrain_idx[4 * i] = lvl; e->terrain_idx[4 * i + 1] = typ;

@@ -167,10 +167,12 @@ def same_state(dev, orc, where):
 
 
 @pytest.mark.gpu
-def test_level_curriculum_parity_on_the_field_across_level_changes():
+@pytest.mark.parametrize("stride", [1, 2], ids=["footprints every substep", "footprints every 2nd substep"])
+def test_level_curriculum_parity_on_the_field_across_level_changes(stride):
     """HIP path vs oracle, bit for bit, on the height field with curriculum = 1: the level generators,
     the fraction snapshot, update_SI_level moving arenas both ways at the timeouts, a fall in between
-    (a reset of ONE arena re-snapshots every arena's fraction), single steps and a fused rollout."""
+    (a reset of ONE arena re-snapshots every arena's fraction), single steps and a fused rollout (the FOLD shells of
+    step_kernel_terrain, for both footprint strides)."""
     from options_in_simulation_amd.vecenv import NativeEnv
     N = 333
     cfg = build_config(variant="KAMMA_medium", num_envs=N, seed=7, max_sim_steps=300.0)
@@ -179,7 +181,7 @@ def test_level_curriculum_parity_on_the_field_across_level_changes():
     lt = np.stack([np.arange(N) % 5, np.arange(N) % 2], 1).astype(np.int32)
     # r1 sums of a 99-step episode under these commands: about -3200 on level 0 (a 0.5 rad/s yaw command
     # the robot cannot follow), -940 ... -130 on the others
-    kw = dict(curriculum=True, threshold_low=-600.0, threshold_high=-330.0, max_level=4)
+    kw = dict(curriculum=True, threshold_low=-600.0, threshold_high=-330.0, max_level=4, footprint_stride=stride)
     dev.attach_terrain(T, lt, **kw); orc.attach_terrain(T, lt, **kw)
     dev.reset(7); orc.reset(7)
     same_state(dev, orc, "post_reset")

@@ -530,6 +530,13 @@ def test_save_load_with_replay_and_terrain_attached():
         with pytest.raises(RuntimeError, match=why):
             c.load_state(blob)
         c.close()
+    # the footprint stride is part of the terrain's identity: the same field under the other contact is another terrain
+    c = NativeEnv(build_config(variant="KAMMA_medium", num_envs=N, seed=8, max_sim_steps=90.0), "cuda:0")
+    c.attach_terrain(T, lt, footprint_stride=2, **kw)
+    c.reset(8); c.attach_replay(M)
+    with pytest.raises(RuntimeError, match="terrain attached"):
+        c.load_state(blob)
+    c.close()
     plane, _ = fresh(attach_terrain=False, memory=0)
     pb = plane.save_state()
     with pytest.raises(RuntimeError, match="saved on the plane"):

@@ -225,6 +225,60 @@ def test_random_terrain_soak_stays_finite_and_on_the_ground():
     assert falls > 0              # the has_fallen / bounds resets do fire on this terrain
 
 
+def test_footprint_stride_two_on_the_oracle():
+    """ois_terrain.footprint_stride = 2 (docs/SPEC.md section 3.8, build-defined): footprints every second substep, the plane kept
+    and the reciprocals refreshed by Newton in between. 0 and 1 are the default, bit for bit; 2 is another (cheaper) contact:
+    a robot meets an edge of the field up to one substep later, after which its trajectory is its own (the contact with 0.15 m
+    steps is chaotic: a 10 um shift of the start does the same to the default contact, only later) — what has to agree, and
+    does, is the ensemble: rewards, fall rate, speeds. Anything but 0, 1, 2 is refused."""
+    N = 1024
+    cfg = build_config(variant="KAMMA_medium", num_envs=N, seed=5)
+    T = tg.Terrain({"numLevels": 3, "numTerrains": 4, "mapLength": 8.0, "mapWidth": 8.0}, N, seed=3)
+    lt = T.sample_levels_types(N, rng=np.random.RandomState(2))
+    envs = {}
+    for stride in (None, 0, 1, 2):
+        e = OracleEnv(cfg, threads=4)
+        e.attach_terrain(T, lt, footprint_stride=stride)
+        e.reset(5)
+        envs[stride] = e
+    rng = np.random.default_rng(0)
+    stat = {1: np.zeros(4), 2: np.zeros(4)}
+    steps = 120
+    for t in range(steps):
+        a = rng.uniform(0, 1, size=(N, 4)).astype(np.float32)
+        for k, e in envs.items():
+            if k in (1, 2) or t < 12:
+                e.step(a)
+        if t < 12:
+            for bid in (_abi.BUF_POSE, _abi.BUF_QUAT, _abi.BUF_LINVEL, _abi.BUF_ANGVEL, _abi.BUF_WHEEL_VEL, _abi.BUF_OBS, _abi.BUF_REW):
+                assert np.array_equal(envs[None].buffer(bid), envs[0].buffer(bid)) and np.array_equal(envs[None].buffer(bid), envs[1].buffer(bid))
+        for k in (1, 2):
+            e = envs[k]
+            for bid in (_abi.BUF_POSE, _abi.BUF_QUAT, _abi.BUF_LINVEL, _abi.BUF_ANGVEL, _abi.BUF_WHEEL_VEL, _abi.BUF_OBS, _abi.BUF_REW):
+                assert np.isfinite(e.buffer(bid)).all(), (k, t, bid)
+            stat[k] += (e.buffer(_abi.BUF_REW).mean(), (e.done & ~e.timeout.astype(bool)).sum(), np.abs(e.buffer(_abi.BUF_LINVEL)[:, :3]).mean(),
+                        np.abs(e.buffer(_abi.BUF_ANGVEL)[:, :3]).mean())
+        if t == 1:  # 0.1 s in: most robots have not met an edge yet
+            near = np.abs(envs[2].buffer(_abi.BUF_POSE)[:, :3] - envs[1].buffer(_abi.BUF_POSE)[:, :3]).max(axis=1)
+            assert np.median(near) < 1e-5 and np.quantile(near, 0.9) < 5e-3 and near.max() > 0.0, (np.median(near), near.max())
+    r1, f1, v1, w1 = stat[1] / steps
+    r2, f2, v2, w2 = stat[2] / steps
+    assert abs(r2 - r1) < 0.02 * abs(r1) and abs(v2 - v1) < 0.03 * v1 and abs(w2 - w1) < 0.05 * w1, (stat[1] / steps, stat[2] / steps)
+    assert f1 > 0 and abs(f2 - f1) < 0.2 * f1, (f1, f2)
+    # a flat field has no edge to meet: the two differ by the Newton refresh of the reciprocals alone
+    flat = {}
+    for stride in (1, 2):
+        e = OracleEnv(build_config(variant="KAMMA_medium", num_envs=8, seed=1))
+        e.attach_terrain(big_tile_terrain(lambda t: tg.flat_terrain(t, 0.0)), np.zeros((8, 2), np.int32), footprint_stride=stride)
+        e.reset(1)
+        for t in range(20):
+            e.step(np.full((8, 4), 0.7, np.float32))
+        flat[stride] = e.buffer(_abi.BUF_POSE).copy()
+    np.testing.assert_allclose(flat[2], flat[1], atol=2e-4)
+    with pytest.raises(RuntimeError, match="footprint_stride"):
+        envs[1].attach_terrain(T, lt, footprint_stride=3)
+
+
 def test_terrain_curriculum_levels_and_extras():
     N = 40
     cfg = build_config(variant="KAMMA_medium", num_envs=N, seed=6)
@@ -365,6 +419,55 @@ def test_terrain_step_parity(env_vars, monkeypatch):
     # the field matters: the same run on the plane ends elsewhere
     flat = OracleEnv(cfg); flat.reset(12)
     assert not np.allclose(flat.buffer(_abi.BUF_POSE), orc.buffer(_abi.BUF_POSE))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("shape", ["20 substeps", "11 substeps", "2 substeps", "1 substep", "3 iterations"])
+@pytest.mark.parametrize("env_vars", [{"OIS_PACKED": "0"}, {"OIS_PACKED": "1"}], ids=["scalar", "packed"])
+def test_footprint_stride_two_parity(env_vars, shape, monkeypatch):
+    """the stride-2 shells (step_kernel_terrain<.., .., .., 2>: the later substeps in odd / even pairs, plus the odd one left over)
+    against the oracle, bit for bit, for every substep count that ends the pairs differently and both solver-iteration forms"""
+    from options_in_simulation_amd.vecenv import NativeEnv
+    from options_in_simulation_amd.config import default_task_cfg
+    for k, v in env_vars.items():
+        monkeypatch.setenv(k, v)
+    N = 203
+    task = default_task_cfg()
+    kw = {}
+    if shape == "11 substeps":
+        kw["extra_substeps"] = 1
+    elif shape in ("2 substeps", "1 substep"):
+        (task["task"] if "task" in task else task)["env"]["control"]["decimation"] = 1
+        kw["extra_substeps"] = 1 if shape == "2 substeps" else 0
+    cfg = build_config(task, variant="KAMMA_medium", num_envs=N, seed=12, max_sim_steps=150.0, **kw)
+    if shape == "3 iterations":
+        cfg.solver_iterations = 3
+    dev, orc = NativeEnv(cfg, "cuda:0"), OracleEnv(cfg)
+    T = tg.Terrain({"numLevels": 2, "numTerrains": 3, "mapLength": 8.0, "mapWidth": 8.0, "footprintStride": 2}, N, seed=4)
+    lt = T.sample_levels_types(N, rng=np.random.RandomState(0))
+    dev.attach_terrain(T, lt); orc.attach_terrain(T, lt)   # the stride comes from the terrain's own cfg
+    assert "+stride2" in dev.kernel_info()
+    dev.randomize_params(0.5, 1.0); orc.randomize_params(0.5, 1.0)
+    dev.reset(12); orc.reset(12)
+    rng = np.random.default_rng(1)
+    for t in range(40):
+        a = rng.uniform(0, 1, size=(N, 4)).astype(np.float32)
+        dev.step(torch.from_numpy(a).cuda()); orc.step(a)
+        if t % 8 == 0 or t == 39:
+            same_state(dev, orc, f"{env_vars} {shape} step {t}")
+    dev.rollout(12, _abi.POLICY_RANDOM); orc.rollout(12, _abi.POLICY_RANDOM)
+    same_state(dev, orc, "fused rollout")
+    # and it is not the default contact
+    ref = OracleEnv(cfg); ref.attach_terrain(T, lt, footprint_stride=1); ref.randomize_params(0.5, 1.0); ref.reset(12)
+    rng = np.random.default_rng(1)
+    for t in range(40):
+        ref.step(rng.uniform(0, 1, size=(N, 4)).astype(np.float32))
+    ref.rollout(12, _abi.POLICY_RANDOM)
+    # up to two substeps the two contacts are the same one: substep 0 samples its own footprints, substep 1 fits its plane to them
+    same_contact = shape in ("1 substep", "2 substeps")
+    assert np.array_equal(ref.buffer(_abi.BUF_POSE), orc.buffer(_abi.BUF_POSE)) == same_contact
+    with pytest.raises(RuntimeError, match="footprint_stride"):
+        dev.attach_terrain(T, lt, footprint_stride=5)
 
 
 @pytest.mark.gpu

@@ -27,8 +27,10 @@ def kernel_id(mangled):
     args = re.findall(r"L[ib](\d+)E", m.group(2))
     # the last template argument of the three shells is FOLD (continuation launches of a level-curriculum rollout): ois_kernel_info
     # names the shell an ois_step launches, i.e. without it
+    # step_kernel_terrain<PK, NIT, FOLD, TSTRIDE>: the last one is ois_terrain.footprint_stride ("+stride2", as ois_kernel_info names it)
+    stride = args.pop() if m.group(1) == "step_kernel_terrain" and len(args) == 4 else "1"
     fold = args.pop() if len(args) == {"step_kernel": 5, "step_kernel_w2": 4, "step_kernel_terrain": 3}.get(m.group(1), -1) else "0"
-    return m.group(1) + "<" + ",".join(args) + ">" + ("+fold" if fold == "1" else "")
+    return m.group(1) + "<" + ",".join(args) + ">" + ("+stride2" if stride == "2" else "") + ("+fold" if fold == "1" else "")
 
 
 def census(asm, want, quiet=False):
@@ -77,6 +79,8 @@ def census(asm, want, quiet=False):
                                     "lds_bytes": int(md.get("group_segment_fixed_size", 0)),
                                     "substep_valu": len(valu), "substep_valu_packed": sum(1 for i in valu if i.startswith("v_pk_")),
                                     "substep_flop_per_lane": flop, "substep_blocks": [len(b[2]) for b in inner], "substep_blocks_counted": len(main),
+                                    # footprint stride 2: the loop body is a PAIR of substeps (odd + even), the counts above are the pair's
+                                    "loop_substeps": 2 if "+stride2" in kernel_id(name) else 1,
                                     "whole_kernel_instructions": sum(len(b[2]) for b in blocks)}
             continue
         print(f"== {name[:100]}\n   vgpr {md.get('vgpr_count')} agpr {md.get('agpr_count')} sgpr {md.get('sgpr_count')} "

@@ -1,5 +1,6 @@
 """Wide one-off parity sweep, kernel vs CPU oracle, bit for bit (GPU box; the oracle runs on the
-host cores): every task variant x {plane, per-arena friction + slope, plane + level curriculum, height field, field + curriculum} x kernel
+host cores): every task variant x {plane, per-arena friction + slope, plane + level curriculum, height field, field + curriculum, the field under
+footprint stride 2 without / with the curriculum} x kernel
 shell (one lane per arena in its two register budgets, a lane pair per arena), N arenas x STEPS single steps with random actions, then one fused rollout.
     python tools/parity_fuzz.py [N] [STEPS]
 Prints one line per case; exits non-zero on the first difference."""
@@ -40,7 +41,7 @@ def same(dev, orc, where):
 cases = 0
 t0 = time.time()
 for variant in sorted(VARIANTS):
-    for ground in ("plane", "domain-rand", "plane+curriculum", "field", "field+curriculum"):
+    for ground in ("plane", "domain-rand", "plane+curriculum", "field", "field+curriculum", "field/stride2", "field/stride2+curriculum"):
         for shell in ("1", "2", "pair"):
             os.environ["OIS_STEP_WAVES"] = "1" if shell == "pair" else shell
             os.environ["OIS_LANES_PER_ARENA"] = "2" if shell == "pair" else "1"  # by size it would be the pair at this N
@@ -61,6 +62,8 @@ for variant in sorted(VARIANTS):
                 T = tg.Terrain({"numLevels": 3, "numTerrains": 2, "mapLength": 8.0, "mapWidth": 8.0}, N, seed=seed)
                 lt = T.sample_levels_types(N, rng=np.random.RandomState(seed))
                 kw = dict(curriculum=True, threshold_low=-600.0, threshold_high=-330.0, max_level=2) if ground.endswith("curriculum") else {}
+                if "stride2" in ground:
+                    kw["footprint_stride"] = 2  # ois_terrain.footprint_stride: footprints every second substep (SPEC 3.8)
                 dev.attach_terrain(T, lt, **kw); orc.attach_terrain(T, lt, **kw)  # with the curriculum: level moves + per-level commands
             dev.reset(seed); orc.reset(seed)
             rng = np.random.default_rng(seed)
@@ -76,5 +79,5 @@ for variant in sorted(VARIANTS):
                 print(f"DIFFERENCE {variant} {ground}: episode_info"); sys.exit(1)
             dev.close(); orc.close()
             cases += 1
-            print(f"ok {variant:16s} {ground:12s} shell {shell}: {N} arenas x {STEPS + 25} steps bit-identical", flush=True)
+            print(f"ok {variant:16s} {ground:24s} shell {shell}: {N} arenas x {STEPS + 25} steps bit-identical", flush=True)
 print(f"{cases} cases, {cases * N * (STEPS + 25)} arena-steps, all bit-identical, {time.time() - t0:.0f} s")

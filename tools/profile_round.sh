@@ -73,6 +73,8 @@ tail -c 400 $OUT/${R}_bench_gloo2.json
 python bench.py --fused 20 --steps 60 --warmup 5 --no-cpu-baseline > $OUT/${R}_bench_fused20.json 2>> $OUT/${R}_bench.err
 python bench.py --domain-rand --no-cpu-baseline > $OUT/${R}_bench_config4_domain_rand.json 2>> $OUT/${R}_bench.err
 python bench.py --terrain --no-cpu-baseline > $OUT/${R}_bench_config4_terrain.json 2>> $OUT/${R}_bench.err
+python bench.py --terrain --footprint-stride 2 --no-cpu-baseline > $OUT/${R}_bench_config4_terrain_stride2.json 2>> $OUT/${R}_bench.err
+python tools/terrain_probe.py > /dev/null 2>&1 && cp $OUT/terrain_probe.json $OUT/${R}_terrain_probe.json
 python bench.py --steps 20 --warmup 5 > $OUT/${R}_bench_driver_shape.json 2>> $OUT/${R}_bench.err
 # the reference trainer's per-step loop around the env (base_KA_DDPG.py:170-262): the four lines + where the host spends a step,
 # and the rocprofv3 kernel trace of the same loop

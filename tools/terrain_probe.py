@@ -1,4 +1,5 @@
-"""cost of the height-field contact: fused-rollout us/step on the plane vs on a terrain (GPU box)"""
+"""cost of the height-field contact: fused-rollout us/step on the plane vs on a terrain, with the wheel footprints sampled at every
+substep and (ois_terrain.footprint_stride = 2) at every second one; the height scan (GPU box)"""
 import json
 import os
 import sys
@@ -37,6 +38,11 @@ for packed in ("1", "0"):
     env.attach_terrain(T, lt)
     env.reset(1)
     ter = timed(env)
+    env.attach_terrain(T, lt, footprint_stride=2)
+    env.reset(1)
+    ter2 = timed(env)
+    env.attach_terrain(T, lt)
+    env.reset(1)
     scan = torch.empty((N, 140), device="cuda")
     env.height_scan(scan); torch.cuda.synchronize()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -44,7 +50,7 @@ for packed in ("1", "0"):
     for _ in range(20):
         env.height_scan(scan)
     e1.record(); torch.cuda.synchronize()
-    out["packed" if packed == "1" else "scalar"] = {"flat_us_per_step": round(flat, 2), "terrain_us_per_step": round(ter, 2),
+    out["packed" if packed == "1" else "scalar"] = {"flat_us_per_step": round(flat, 2), "terrain_us_per_step": round(ter, 2), "terrain_footprint_stride_2_us_per_step": round(ter2, 2),
                                                       "height_scan_us": round(e0.elapsed_time(e1) * 1e3 / 20, 2)}
     print(json.dumps(out), flush=True)
 out["field_MB"] = round(T.heightsamples.nbytes / 1e6, 1)
