@@ -53,49 +53,10 @@ OIS_DEV f2 newton_rcp2(f2 m, f2 k) {
   return fma2(m, e, m);
 }
 
-// terrain_footprints / terrain_plane (ois_physics.h) with the per-wheel arithmetic on the axle pairs: the same operations on the
-// same operands, element for element (the wheels of an axle share c_x and differ in the sign of c_y), so the same bits; the
-// integer cell / gather part stays per wheel (there is no packed integer or conversion instruction).
-template <bool FRESH>
-OIS_DEV void terrain_footprints_pk(const PhysK& K, const DevTerrain& T, const PhysT<1>& S, const float* R, Footprints& F) {
-  const float* origin = S.to;
-  const f2 cy = {K.wy, -K.wy};  // pair j = wheels (j, j + 2) = (left, right) of an axle
-#pragma unroll
-  for (int j = 0; j < 2; ++j) {
-    const float cx = j ? -K.wx : K.wx;
-    const f2 wx = fma2(R[2], (f2)(K.cz), fma2(R[1], cy, (f2)(__builtin_fmaf(R[0], cx, S.p[0]))));
-    const f2 wy = fma2(R[5], (f2)(K.cz), fma2(R[4], cy, (f2)(__builtin_fmaf(R[3], cx, S.p[1]))));
-    st2(F.wx, j, wx); st2(F.wy, j, wy);
-    const f2 fx = ((wx + origin[0]) + T.border) * T.inv_hs, fy = ((wy + origin[1]) + T.border) * T.inv_hs;  // terrain_cell
-    const float ex[2] = {fx.x, fx.y}, ey[2] = {fy.x, fy.y};
-#pragma unroll
-    for (int e = 0; e < 2; ++e) {
-      const int k = j + 2 * e;
-      F.px[k] = (int)__builtin_amdgcn_fmed3f(ex[e], 0.0f, (float)(T.rows - 2));
-      F.py[k] = (int)__builtin_amdgcn_fmed3f(ey[e], 0.0f, (float)(T.cols - 2));
-      int m = (!FRESH && F.px[k] == S.fpx[k] && F.py[k] == S.fpy[k]) ? -1 : 0;  // unchanged cell: see terrain_footprints
-      asm volatile("" : "+v"(m));
-      const float hh = terrain_cell_height(T, F.px[k] & ~m, F.py[k] & ~m) - origin[2];
-      F.h[k] = __int_as_float((__float_as_int(S.fh[k]) & m) | (__float_as_int(hh) & ~m));
-    }
-  }
-  F.r00 = R[0]; F.r10 = R[3]; F.r01 = R[1]; F.r11 = R[4];
-}
-OIS_DEV void terrain_plane_pk(const PhysK& K, const PhysT<1>& S, float* n, float* off) {
-  const float* h = S.fh;
-  const float g1 = ((h[0] + h[2]) - (h[1] + h[3])) * K.inv4wx;
-  const float g2 = ((h[0] + h[1]) - (h[2] + h[3])) * K.inv4wy;
-  const float nx = __builtin_fmaf(S.fr10, g2, -(g1 * S.fr11));
-  const float ny = __builtin_fmaf(g1, S.fr01, -(S.fr00 * g2));
-  const float nz = __builtin_fmaf(S.fr00, S.fr11, -(S.fr10 * S.fr01));
-  const float nn = fmaxf(__builtin_fmaf(nz, nz, __builtin_fmaf(ny, ny, nx * nx)), 1e-12f);
-  float inv = exact_rcp(sqrtf(nn));
-  if (nz < 0.0f) inv = -inv;
-  n[0] = nx * inv; n[1] = ny * inv; n[2] = nz * inv;
-#pragma unroll
-  for (int j = 0; j < 2; ++j) st2(*reinterpret_cast<float(*)[4]>(off), j, fma2(n[2], ld2(S.fh, j), fma2(n[1], ld2(S.fwy, j), n[0] * ld2(S.fwx, j))));
-}
-
+// (The footprints and the plane fit of the height field stay on scalar instructions here — terrain_footprints / terrain_plane of
+// ois_physics.h: their per-wheel arithmetic on the axle pairs was built in round 4, 26 instructions fewer per substep and
+// bit-identical, and measured SLOWER on the same box: 47.8 vs 45.5 us per fused step, 58.0 vs 52.1 us per launch behind the
+// actor's GEMMs. The four gathers then leave together, late, instead of one by one as each wheel's cell is known.)
 // FLAT: the ground is the default plane n = (0, 0, 1) for every arena (no ois_randomize_params slopes, no terrain —
 // the host knows): n_b is the third row of R and n.p is p_z; the 12 instructions that multiply by the zero components of n
 // are not issued (SPEC 3.2: the same IEEE values, a zero may carry the other sign).
@@ -110,13 +71,13 @@ OIS_DEV void substep_pk(const PhysK& K, const DevTerrain& T, PhysT<1>& S) {
   float n[3] = {S.n[0], S.n[1], S.n[2]}, off[4] = {0.0f, 0.0f, 0.0f, 0.0f};
   Footprints cur;
   if constexpr (TER) {  // one-substep-lagged footprints, see substep<> in ois_physics.h
-    if constexpr (TMODE != kOddSubstep) terrain_footprints_pk<EXACT>(K, T, S, R, cur);
+    if constexpr (TMODE != kOddSubstep) terrain_footprints<EXACT>(K, T, S, R, cur);
     if (EXACT) footprints_store(S, cur);
     if constexpr (TMODE == kEvenSubstep) {  // the plane of the substep before (ois_physics.h substep<>)
       n[0] = S.pn[0]; n[1] = S.pn[1]; n[2] = S.pn[2];
       off[0] = S.poff[0]; off[1] = S.poff[1]; off[2] = S.poff[2]; off[3] = S.poff[3];
     } else {
-      terrain_plane_pk(K, S, n, off);
+      terrain_plane(K, S, n, off);
       if constexpr (TMODE == kOddSubstep) {
         S.pn[0] = n[0]; S.pn[1] = n[1]; S.pn[2] = n[2];
         S.poff[0] = off[0]; S.poff[1] = off[1]; S.poff[2] = off[2]; S.poff[3] = off[3];
