@@ -78,7 +78,7 @@ python tools/terrain_probe.py > /dev/null 2>&1 && cp $OUT/terrain_probe.json $OU
 python bench.py --steps 20 --warmup 5 > $OUT/${R}_bench_driver_shape.json 2>> $OUT/${R}_bench.err
 # the reference trainer's per-step loop around the env (base_KA_DDPG.py:170-262): the four lines + where the host spends a step,
 # and the rocprofv3 kernel trace of the same loop
-(echo "# kernel sources sha256 $HASH"; python tools/trainer_loop_probe.py 65536 --breakdown) > $OUT/${R}_trainer_loop.txt 2>&1
+(echo "# kernel sources sha256 $HASH"; python tools/trainer_loop_probe.py 65536 --breakdown; python tools/trainer_loop_probe.py 65536) 2>&1 | grep -v amdgpu.ids > $OUT/${R}_trainer_loop.txt  # two runs: the host's wake-up moves by +-10 us
 (cd /tmp && rocprofv3 --kernel-trace --stats --output-format csv -d $P/tl -- python3 $OLDPWD/tools/trainer_loop_probe.py > $P/tl.log 2> $P/tl.err) || { tail -5 $P/tl.err; exit 1; }
 cp $(find $P/tl -name '*kernel_stats.csv' | head -1) $OUT/${R}_trainer_loop_kernel_stats.csv
 (echo "# kernel sources sha256 $HASH"; python tools/info_probe.py) > $OUT/${R}_info_probe.txt 2>&1
