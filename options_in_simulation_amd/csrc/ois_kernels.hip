@@ -302,7 +302,7 @@ OIS_DEV void step_body(const PhysK& K, const DevBuffers& B, const float* __restr
       for (int k = 0; k < 3; ++k) X.to[k] = tor[k];
       if constexpr (TER && TSTRIDE == 2) {
         // ois_terrain.footprint_stride = 2 (SPEC 3.8): the later substeps in pairs — an odd one fits the plane to the stored
-        // sample and samples nothing, the even one after it samples, keeps that plane and refreshes its reciprocals by Newton
+        // sample and samples nothing, the even one after it samples and keeps that plane
         int i = 1;
         if constexpr (PK) {
           substep_pk<true, true, NIT>(K, B.ter, X);

@@ -110,7 +110,7 @@ OIS_DEV void substep_pk(const PhysK& K, const DevTerrain& T, PhysT<1>& S) {
   // contact frame shared by the four wheels (common axle direction = body y)
   float s2 = __builtin_fmaf(nb[2], nb[2], nb[0] * nb[0]);
   s2 = fmaxf(s2, 1e-12f);
-  constexpr bool REX = EXACT || (TER && TMODE != kEvenSubstep);
+  constexpr bool REX = EXACT || TER;  // every substep on a height field (ois_physics.h substep<>)
   const float inv_s = REX ? exact_rcp(sqrtf(s2)) : newton_rsqrt(S.inv_s, s2);  // s2 >= 1e-12
   S.inv_s = inv_s;
   const float dx = -(nb[0] * inv_s), dz = -(nb[2] * inv_s);

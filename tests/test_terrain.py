@@ -227,12 +227,12 @@ def test_random_terrain_soak_stays_finite_and_on_the_ground():
 
 def test_footprint_stride_two_on_the_oracle():
     """ois_terrain.footprint_stride = 2 (docs/SPEC.md section 3.8, build-defined): footprints every second substep, the plane kept
-    and the reciprocals refreshed by Newton in between. 0 and 1 are the default, bit for bit; 2 is another (cheaper) contact:
+    in between. 0 and 1 are the default, bit for bit; 2 is another (cheaper) contact:
     a robot meets an edge of the field up to one substep later, after which its trajectory is its own (the contact with 0.15 m
     steps is chaotic: a 10 um shift of the start does the same to the default contact, only later) — what has to agree, and
     does, is the ensemble: rewards, fall rate, speeds. Anything but 0, 1, 2 is refused."""
-    N = 1024
-    cfg = build_config(variant="KAMMA_medium", num_envs=N, seed=5)
+    N = 4096
+    cfg = build_config(variant="KAMMA_eval", num_envs=N, seed=5)   # gamma = 0: the random torques are executed, robots tumble
     T = tg.Terrain({"numLevels": 3, "numTerrains": 4, "mapLength": 8.0, "mapWidth": 8.0}, N, seed=3)
     lt = T.sample_levels_types(N, rng=np.random.RandomState(2))
     envs = {}
@@ -243,7 +243,8 @@ def test_footprint_stride_two_on_the_oracle():
         envs[stride] = e
     rng = np.random.default_rng(0)
     stat = {1: np.zeros(4), 2: np.zeros(4)}
-    steps = 120
+    fastest = {1: 0.0, 2: 0.0}
+    steps = 100
     for t in range(steps):
         a = rng.uniform(0, 1, size=(N, 4)).astype(np.float32)
         for k, e in envs.items():
@@ -256,7 +257,8 @@ def test_footprint_stride_two_on_the_oracle():
             e = envs[k]
             for bid in (_abi.BUF_POSE, _abi.BUF_QUAT, _abi.BUF_LINVEL, _abi.BUF_ANGVEL, _abi.BUF_WHEEL_VEL, _abi.BUF_OBS, _abi.BUF_REW):
                 assert np.isfinite(e.buffer(bid)).all(), (k, t, bid)
-            stat[k] += (e.buffer(_abi.BUF_REW).mean(), (e.done & ~e.timeout.astype(bool)).sum(), np.abs(e.buffer(_abi.BUF_LINVEL)[:, :3]).mean(),
+            fastest[k] = max(fastest[k], float(np.abs(e.buffer(_abi.BUF_LINVEL)[:, :3]).max()))
+            stat[k] += (np.median(e.buffer(_abi.BUF_REW)), (e.done & ~e.timeout.astype(bool)).sum(), np.abs(e.buffer(_abi.BUF_LINVEL)[:, :3]).mean(),
                         np.abs(e.buffer(_abi.BUF_ANGVEL)[:, :3]).mean())
         if t == 1:  # 0.1 s in: most robots have not met an edge yet
             near = np.abs(envs[2].buffer(_abi.BUF_POSE)[:, :3] - envs[1].buffer(_abi.BUF_POSE)[:, :3]).max(axis=1)
@@ -265,7 +267,10 @@ def test_footprint_stride_two_on_the_oracle():
     r2, f2, v2, w2 = stat[2] / steps
     assert abs(r2 - r1) < 0.02 * abs(r1) and abs(v2 - v1) < 0.03 * v1 and abs(w2 - w1) < 0.05 * w1, (stat[1] / steps, stat[2] / steps)
     assert f1 > 0 and abs(f2 - f1) < 0.2 * f1, (f1, f2)
-    # a flat field has no edge to meet: the two differ by the Newton refresh of the reciprocals alone
+    # nobody is launched: the first version of the stride (Newton-refreshed reciprocals in the plane-keeping substeps) threw a robot
+    # that came to lie on its side off the field at 1 000 m/s, about once per 10^5 arena-steps
+    assert fastest[1] < 15.0 and fastest[2] < 15.0, fastest
+    # a flat field has no edge to meet: the same contact up to the rounding of n_z / |n_z| at two sampling times
     flat = {}
     for stride in (1, 2):
         e = OracleEnv(build_config(variant="KAMMA_medium", num_envs=8, seed=1))
@@ -274,7 +279,7 @@ def test_footprint_stride_two_on_the_oracle():
         for t in range(20):
             e.step(np.full((8, 4), 0.7, np.float32))
         flat[stride] = e.buffer(_abi.BUF_POSE).copy()
-    np.testing.assert_allclose(flat[2], flat[1], atol=2e-4)
+    np.testing.assert_allclose(flat[2], flat[1], atol=1e-4)
     with pytest.raises(RuntimeError, match="footprint_stride"):
         envs[1].attach_terrain(T, lt, footprint_stride=3)
 
