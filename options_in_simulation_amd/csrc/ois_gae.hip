@@ -11,8 +11,9 @@
 //
 // At the reference's own rollout lengths (ppo.py:23 rollouts = 16, ppoc.py:23: 20) the work is 27 MB at 65 536 arenas and the
 // launches cost more than the bytes: the scan is 4.5 us. So the normalisation is TWO launches, not three: every block of the
-// normalise kernel sums the per-wave moments itself (16 KB out of L2, the same fixed order as the separate moments kernel,
-// which stays for grids with more than kFoldParts waves). ONE launch was built and measured in round 4 (a lane keeps its T <= 32
+// normalise kernel sums the scan's per-block moments itself (4 KB out of L2 at 65 536 arenas — the scan runs four waves per block up
+// to kWideScanArenas arenas; the same fixed order as the separate moments kernel, which stays for grids with more than kFoldParts
+// blocks): 9.6-9.7 us at T = 16, 10.7-11.1 at T = 20. ONE launch was built and measured in round 4 (a lane keeps its T <= 32
 // advantages in registers across a grid-wide barrier, then writes them normalised) and is slower: the 8 XCDs' L2s are not
 // coherent with each other, a word crosses between them in ~2 us, and any barrier needs several such hops — 102 us with an
 // arrival counter (1024 same-address atomics serialise at the memory side), 43 us with per-wave flags under release / acquire
@@ -30,7 +31,10 @@ extern "C" int ois_fail_(int code, const char* msg);  // ois_kernels.hip: sets o
 
 namespace {
 
-constexpr int kGaeBlock = 64;   // one wave per block: 65 536 arenas spread over all 1024 SIMDs
+// scan blocks: four waves (one per SIMD of a CU) up to kWideScanArenas arenas — 65 536 arenas are then 256 blocks on the 256 CUs and
+// the normalisation folds 256 per-block moments instead of 1024 per-wave ones (T = 16: 11.9 -> 10.1 us for scan + normalise, same
+// scan time); one wave per block above, where the wider blocks place worse (524 288 arenas: 23 vs 30 us for the scan)
+constexpr int kWideScanArenas = 262144;
 constexpr int kNormBlock = 256;
 constexpr int kChunk = 8;      // rollout steps per pipeline stage: 24 loads per lane, two stages in flight
 
@@ -40,7 +44,7 @@ __device__ inline double wave_sum(double x) {
   return x;
 }
 
-template <int MODE>
+template <int MODE, int kGaeBlock>
 __global__ __launch_bounds__(kGaeBlock) void gae_scan_kernel(
     int T, int N, const float* __restrict__ rew, const uint8_t* __restrict__ term,
     const float* __restrict__ val, const float* __restrict__ last, float gamma, float lam_or_gl,
@@ -95,13 +99,24 @@ __global__ __launch_bounds__(kGaeBlock) void gae_scan_kernel(
       for (int k = 0; k < kChunk; ++k) { r[k] = rn[k]; v[k] = vn[k]; d[k] = dn[k]; }
     }
   }
-  if (partials) {
+  if (partials) {  // per-block moments: the wave sums, added in a fixed order
     s1 = wave_sum(s1); s2 = wave_sum(s2);
-    if (threadIdx.x == 0) { partials[2 * blockIdx.x + 0] = s1; partials[2 * blockIdx.x + 1] = s2; }
+    if constexpr (kGaeBlock == 64) {
+      if (threadIdx.x == 0) { partials[2 * blockIdx.x + 0] = s1; partials[2 * blockIdx.x + 1] = s2; }
+    } else {
+      __shared__ double sh[2][kGaeBlock / 64];
+      if ((threadIdx.x & 63) == 0) { sh[0][threadIdx.x >> 6] = s1; sh[1][threadIdx.x >> 6] = s2; }
+      __syncthreads();
+      if (threadIdx.x == 0) {
+        double a = 0.0, b = 0.0;
+        for (int w = 0; w < kGaeBlock / 64; ++w) { a += sh[0][w]; b += sh[1][w]; }
+        partials[2 * blockIdx.x + 0] = a; partials[2 * blockIdx.x + 1] = b;
+      }
+    }
   }
 }
 
-// the moments of the normalisation from the per-wave partials: one fixed order (strided accumulate, then a tree), std unbiased
+// the moments of the normalisation from the scan's per-block partials: one fixed order (strided accumulate, then a tree), std unbiased
 // like torch.std. Called by all kNormBlock threads of a block; every thread returns the same pair.
 __device__ inline void moments_of(size_t count, int nparts, const double* __restrict__ partials, float& mean_f, float& den) {
   __shared__ double sh[2][kNormBlock];
@@ -129,19 +144,30 @@ __global__ __launch_bounds__(kNormBlock) void gae_moments_kernel(size_t count, i
 }
 
 // advantages = (advantages - mean) / (std + 1e-8), in place, IEEE division. FOLD: the block sums the partials itself
-template <bool FOLD>
+template <bool FOLD, bool VEC>
 __global__ __launch_bounds__(kNormBlock) void gae_normalize_kernel(size_t count, int nparts, const double* __restrict__ partials,
                                                                   const float* __restrict__ mean_den, float* __restrict__ adv) {
   float mean_f, den;
   if (FOLD) moments_of(count, nparts, partials, mean_f, den);
   else { mean_f = mean_den[0]; den = mean_den[1]; }
   const size_t stride = (size_t)gridDim.x * kNormBlock;
-  for (size_t o = (size_t)blockIdx.x * kNormBlock + threadIdx.x; o < count; o += stride) adv[o] = (adv[o] - mean_f) / den;
+  // four advantages per lane and access (the host checks the alignment); the division stays the IEEE one, element by element
+  const size_t quads = VEC ? count / 4 : 0;
+  if (VEC) {
+    float4* a4 = reinterpret_cast<float4*>(adv);
+    for (size_t o = (size_t)blockIdx.x * kNormBlock + threadIdx.x; o < quads; o += stride) {
+      float4 v = a4[o];
+      v.x = (v.x - mean_f) / den; v.y = (v.y - mean_f) / den; v.z = (v.z - mean_f) / den; v.w = (v.w - mean_f) / den;
+      a4[o] = v;
+    }
+  }
+  for (size_t o = quads * 4 + (size_t)blockIdx.x * kNormBlock + threadIdx.x; o < count; o += stride) adv[o] = (adv[o] - mean_f) / den;
 }
 
-constexpr int kFoldParts = 2048;  // up to this many per-wave partials (32 KB) every normalise block sums them itself
+constexpr int kFoldParts = 2048;  // up to this many per-block partials (32 KB) every normalise block sums them itself
 
-int gae_blocks(int N) { return (N + kGaeBlock - 1) / kGaeBlock; }
+int gae_block_size(int N) { return N <= kWideScanArenas ? 256 : 64; }
+int gae_blocks(int N) { const int bs = gae_block_size(N); return (N + bs - 1) / bs; }
 
 }  // namespace
 
@@ -149,7 +175,7 @@ extern "C" {
 
 size_t ois_gae_scratch_bytes(int num_envs) {
   if (num_envs <= 0) return 0;
-  return ((size_t)gae_blocks(num_envs) * 2 + 1) * sizeof(double);  // per-wave (sum, sum of squares) + (mean, denominator)
+  return ((size_t)((num_envs + 63) / 64) * 2 + 1) * sizeof(double);  // per-block (sum, sum of squares), sized for one-wave blocks, + (mean, denominator)
 }
 
 int ois_gae(int mode, int T, int num_envs, const float* rewards, const uint8_t* terminated, const float* values,
@@ -166,23 +192,28 @@ int ois_gae(int mode, int T, int num_envs, const float* rewards, const uint8_t* 
   double* partials = normalize ? (double*)scratch_device : nullptr;
   hipStream_t s = (hipStream_t)stream;
   const float g = (float)gamma;
-  if (mode == OIS_GAE_PPO)
-    hipLaunchKernelGGL(gae_scan_kernel<OIS_GAE_PPO>, dim3(blocks), dim3(kGaeBlock), 0, s, T, num_envs, rewards, terminated,
-                       values, last_values, g, (float)lambda, returns_out, advantages_out, partials);
-  else
-    hipLaunchKernelGGL(gae_scan_kernel<OIS_GAE_PPOC>, dim3(blocks), dim3(kGaeBlock), 0, s, T, num_envs, rewards, terminated,
-                       values, last_values, g, (float)(gamma * lambda), returns_out, advantages_out, partials);
+  const int bs = gae_block_size(num_envs);
+#define OIS_GAE_SCAN(MODE_, BS_, LAM_)                                                                                         \
+  hipLaunchKernelGGL((gae_scan_kernel<MODE_, BS_>), dim3(blocks), dim3(BS_), 0, s, T, num_envs, rewards, terminated, values, \
+                     last_values, g, (float)(LAM_), returns_out, advantages_out, partials)
+  if (mode == OIS_GAE_PPO) { if (bs == 256) OIS_GAE_SCAN(OIS_GAE_PPO, 256, lambda); else OIS_GAE_SCAN(OIS_GAE_PPO, 64, lambda); }
+  else { if (bs == 256) OIS_GAE_SCAN(OIS_GAE_PPOC, 256, gamma * lambda); else OIS_GAE_SCAN(OIS_GAE_PPOC, 64, gamma * lambda); }
+#undef OIS_GAE_SCAN
   if (normalize) {
     const size_t count = (size_t)T * (size_t)num_envs;
-    size_t nb = (count + kNormBlock - 1) / kNormBlock;
-    if (nb > 2048) nb = 2048;  // 8 blocks per CU, grid-stride
-    float* mean_den = (float*)(partials + 2 * (size_t)blocks);
+    // four advantages per access from 4 Mi entries on (T = 96 at 65 536 arenas: 32.2 -> 30.7 us; below that it measured equal or slower)
+    const bool vec = (((uintptr_t)advantages_out) & 15) == 0 && count >= ((size_t)1 << 22);
+    size_t nb = ((vec ? count / 4 : count) + kNormBlock - 1) / kNormBlock;
+    if (nb > 1024) nb = 1024;  // 4 blocks per CU, grid-stride (2048: +0.4 us at T = 16, 512: +0.4, 256: +1.6)
+    float* mean_den = (float*)(partials + 2 * (size_t)((num_envs + 63) / 64));
+#define OIS_GAE_NORM(FOLD_, VEC_) hipLaunchKernelGGL((gae_normalize_kernel<FOLD_, VEC_>), dim3((unsigned)nb), dim3(kNormBlock), 0, s, count, blocks, partials, mean_den, advantages_out)
     if (blocks <= kFoldParts) {
-      hipLaunchKernelGGL(gae_normalize_kernel<true>, dim3((unsigned)nb), dim3(kNormBlock), 0, s, count, blocks, partials, mean_den, advantages_out);
+      if (vec) OIS_GAE_NORM(true, true); else OIS_GAE_NORM(true, false);
     } else {
       hipLaunchKernelGGL(gae_moments_kernel, dim3(1), dim3(kNormBlock), 0, s, count, blocks, partials, mean_den);
-      hipLaunchKernelGGL(gae_normalize_kernel<false>, dim3((unsigned)nb), dim3(kNormBlock), 0, s, count, blocks, partials, mean_den, advantages_out);
+      if (vec) OIS_GAE_NORM(false, true); else OIS_GAE_NORM(false, false);
     }
+#undef OIS_GAE_NORM
   }
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) {

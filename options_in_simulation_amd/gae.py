@@ -14,6 +14,7 @@ import torch
 from . import _native
 
 GAE_PPO, GAE_PPOC = 0, 1
+_SCRATCH = {}  # (device index, stream, arenas) -> moments scratch of ois_gae_scratch_bytes()
 
 
 def _run(mode: int, rewards: torch.Tensor, dones: torch.Tensor, values: torch.Tensor, last_values: torch.Tensor,
@@ -33,17 +34,30 @@ def _run(mode: int, rewards: torch.Tensor, dones: torch.Tensor, values: torch.Te
     if v.numel() != T * N or d.numel() != T * N or lv.numel() != N:
         raise ValueError(f"shape mismatch: rewards {tuple(rewards.shape)}, values {tuple(values.shape)}, "
                          f"dones {tuple(dones.shape)}, last values {tuple(last_values.shape)}")
-    returns, advantages = torch.empty_like(r), torch.empty_like(r)
+    # one allocation for both outputs; the moments scratch is kept per (device, stream, N): at the reference's rollout lengths
+    # the launches take ~10 us and every allocation of the wrapper costs a third of that on the host
+    both = torch.empty((2,) + tuple(r.shape), dtype=torch.float32, device=r.device)
+    returns, advantages = both[0], both[1]
+    stream = torch.cuda.current_stream(r.device).cuda_stream
     scratch, nbytes = None, 0
     if normalize:
-        nbytes = L.ois_gae_scratch_bytes(N)
-        scratch = torch.empty(nbytes // 8, dtype=torch.float64, device=r.device)
-    with torch.cuda.device(r.device):
-        stream = torch.cuda.current_stream().cuda_stream
+        key = (r.device.index, stream, N)
+        scratch = _SCRATCH.get(key)
+        if scratch is None:
+            if len(_SCRATCH) > 16:
+                _SCRATCH.clear()
+            scratch = _SCRATCH[key] = torch.empty(L.ois_gae_scratch_bytes(N) // 8, dtype=torch.float64, device=r.device)
+        nbytes = scratch.numel() * 8
+    def launch():
         _native.check(L.ois_gae(mode, T, N, r.data_ptr(), d.data_ptr(), v.data_ptr(), lv.data_ptr(),
                                 float(discount_factor), float(lambda_coefficient), int(normalize),
                                 returns.data_ptr(), advantages.data_ptr(),
                                 scratch.data_ptr() if scratch is not None else None, nbytes, stream))
+    if torch.cuda.current_device() == r.device.index:
+        launch()
+    else:  # ois_gae launches on the calling thread's current device: the tensors' device for the call
+        with torch.cuda.device(r.device):
+            launch()
     return returns, advantages
 
 
