@@ -345,7 +345,9 @@ OIS_DEV void step_body(const PhysK& K, const DevBuffers& B, const float* __restr
 #pragma unroll
       for (int k = 0; k < W; ++k) cw[k] = fabsf(X.spin[k]) + fabsf(X.ln[k]) + fabsf(X.l1[k]) + fabsf(X.l2[k]);
       chk += sum_wheels<LPA>(cw);
-      blown = !(chk < 3.0e38f);
+      // ... or a linear speed beyond 50 m/s: the finite garbage of a Newton refresh in a singular pose (oracle step_arena, SPEC 3.9)
+      const float v2 = __builtin_fmaf(X.v[2], X.v[2], __builtin_fmaf(X.v[1], X.v[1], X.v[0] * X.v[0]));
+      blown = !(chk < 3.0e38f) || !(v2 < 2500.0f);
       // A blown arena is reset below (reset |= blown), and reset_arena overwrites every state value the oracle restores or
       // zeroes for it here (pose, velocities, wheel speeds, impulses: oracle step_arena). What its metrics still see of
       // this step's outcome is the yaw rate alone (ang_acc, prev_ang): zeroed after the rotation. The rest may hold NaN

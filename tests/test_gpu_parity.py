@@ -331,7 +331,8 @@ def test_every_kernel_instantiation_is_bit_identical_to_the_oracle(env_vars, mon
                                       {"OIS_LANES_PER_ARENA": "2"}, {"OIS_LANES_PER_ARENA": "2", "OIS_PACKED": "0"}],
                          ids=["scalar", "packed", "lane-pair-packed", "lane-pair-scalar"])
 def test_non_finite_outcome_guard_parity(env_vars, monkeypatch):
-    """docs/SPEC.md §3.9: injected NaN / inf velocities -> the arena is reset as fallen, outputs
+    """docs/SPEC.md §3.9: injected NaN / inf velocities, and a finite linear speed beyond 50 m/s (the launch a Newton refresh in
+    a singular pose can produce) -> the arena is reset as fallen, outputs
     finite, kernel == oracle bit for bit (also for the untouched arenas). Lane-pair layout on the
     plane only; the other two also on the height field (NaN positions must not index outside it)."""
     for k, v in env_vars.items():
@@ -354,13 +355,14 @@ def _guard_case(env_vars, field):
         dev.step(torch.from_numpy(z).cuda()); orc.step(z)
     torch.cuda.synchronize()
     for bid, i, j, val in [(_abi.BUF_LINVEL, 3, 1, np.nan), (_abi.BUF_ANGVEL, 64, 0, np.inf), (_abi.BUF_WHEEL_VEL, 129, 2, -np.inf),
-                           (_abi.BUF_QUAT, 77, 3, np.nan), (_abi.BUF_POSE, 100, 0, np.nan), (_abi.BUF_POSE, 101, 1, np.inf)]:
+                           (_abi.BUF_QUAT, 77, 3, np.nan), (_abi.BUF_POSE, 100, 0, np.nan), (_abi.BUF_POSE, 101, 1, np.inf),
+                           (_abi.BUF_LINVEL, 10, 2, 80.0), (_abi.BUF_LINVEL, 11, 2, 30.0)]:   # straight up: 80 m/s is discarded, 30 m/s is a flight
         dev.buffer(bid)[i, j] = float(val); orc.buffer(bid)[i, j] = val
     dev.step(torch.from_numpy(z).cuda()); orc.step(z)
     worst = compare(dev, orc, f"{env_vars} guard step", exact_float=True)
     assert np.isfinite(worst)
     done = dev.buffer(_abi.BUF_DONE).cpu().numpy().astype(bool)
-    assert done[[3, 64, 129, 77, 100, 101]].all() and done.sum() == 6
+    assert done[[3, 64, 129, 77, 100, 101, 10]].all() and done.sum() == 7 and not done[11]
     for bid in STATE_BUFS:
         assert torch.isfinite(dev.buffer(bid)).all(), bid
     for _ in range(3):

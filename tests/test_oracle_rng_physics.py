@@ -141,6 +141,34 @@ def test_angular_velocity_cap():
     np.testing.assert_allclose(np.linalg.norm(env.buffer(_abi.BUF_QUAT)[0]), 1.0, atol=1e-5)
 
 
+def test_tipped_robots_are_not_launched():
+    """docs/SPEC.md section 3.9 (round 4): the Newton refresh of the reciprocals assumes effective masses that move by O(1e-3) per
+    substep, which fails for a robot on its side (n_b along the axle: the contact points jump within a substep) — finite garbage,
+    launches of 180 ... 4 000 m/s. Robots of this task do not get there by themselves on the plane, so they are shoved over here
+    (lateral kicks + roll rates written into the state); whatever the solver then does, no arena ends a policy step beyond the
+    speed bound of the guard, and every value stays finite. (Without the bound this run ends with |v| = 4 162 m/s.)"""
+    N = 4096
+    cfg = build_config(variant="KAMMA_eval", num_envs=N, seed=3)   # gamma = 0: the random torques are executed
+    e = OracleEnv(cfg, threads=8)
+    e.randomize_params(0.5, 1.0, [-0.3, -0.2, 0.0, 0.2, 0.3])
+    e.reset(3)
+    rng = np.random.default_rng(0)
+    worst, tipped = 0.0, 0
+    for t in range(200):
+        if t % 7 == 0:
+            idx = rng.choice(N, N // 10, replace=False)
+            v, w = e.buffer(_abi.BUF_LINVEL), e.buffer(_abi.BUF_ANGVEL)
+            v[idx, 0] += rng.uniform(-3, 3, len(idx)); v[idx, 1] += rng.uniform(-3, 3, len(idx)); v[idx, 2] += rng.uniform(0, 2, len(idx))
+            w[idx, 0] += rng.uniform(-8, 8, len(idx)); w[idx, 1] += rng.uniform(-8, 8, len(idx))
+        e.rollout(1, _abi.POLICY_RANDOM)
+        for bid in (_abi.BUF_POSE, _abi.BUF_QUAT, _abi.BUF_LINVEL, _abi.BUF_ANGVEL, _abi.BUF_WHEEL_VEL, _abi.BUF_REW, _abi.BUF_OBS):
+            assert np.isfinite(e.buffer(bid)).all(), (t, bid)
+        worst = max(worst, float(np.abs(e.buffer(_abi.BUF_LINVEL)[:, :3]).max()))
+        tipped += int((e.done & ~e.timeout.astype(bool)).sum())
+    assert tipped > 500          # the shoves do tip robots over (has_fallen) or off the arena
+    assert worst < 50.0, worst   # and nobody leaves at a speed the guard should have discarded
+
+
 def test_substep_entry_point_matches_env(oracle_lib):
     """orc_substep (world-frame angular velocity in/out) composes to the same motion as the env."""
     cfg = build_config(variant="KAMMA_eval", num_envs=1)
