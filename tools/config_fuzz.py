@@ -1,0 +1,104 @@
+"""Random-configuration parity sweep, kernel vs CPU oracle, bit for bit (GPU box): every case draws the physics, task and reset
+constants of `ois_config` at random inside ranges the library accepts (masses, inertias, wheel geometry, time step, substep and
+iteration counts, Baumgarte factor, joint resistance, reward weights, command ranges, spawn state ...), a variant, a ground (plane /
+friction + slopes / height field with either footprint stride) and a shell, and runs STEPS single steps + one fused rollout.
+What it exercises beyond tools/parity_fuzz.py: the host-side derivation of the kernels' constants (derive() in ois_kernels.hip
+against the oracle's), the run-time substep / iteration counts, reset constants off their defaults.
+    python tools/config_fuzz.py [CASES] [N] [STEPS]"""
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+sys.path.insert(0, ".")
+from options_in_simulation_amd import _abi, build_config, _native  # noqa: E402
+from options_in_simulation_amd import terrain as tg  # noqa: E402
+from options_in_simulation_amd.config import VARIANTS  # noqa: E402
+from options_in_simulation_amd.vecenv import NativeEnv  # noqa: E402
+from oracle.binding import OracleEnv  # noqa: E402
+
+CASES = int(sys.argv[1]) if len(sys.argv) > 1 else 200
+N = int(sys.argv[2]) if len(sys.argv) > 2 else 517
+STEPS = int(sys.argv[3]) if len(sys.argv) > 3 else 130
+STATE = [_abi.BUF_OBS, _abi.BUF_REW, _abi.BUF_DONE, _abi.BUF_TIMEOUT, _abi.BUF_WHEEL_TORQS, _abi.BUF_COMMANDS, _abi.BUF_POSE, _abi.BUF_QUAT,
+         _abi.BUF_LINVEL, _abi.BUF_ANGVEL, _abi.BUF_WHEEL_VEL, _abi.BUF_COUNTERS, _abi.BUF_SUMS_A, _abi.BUF_SUMS_B, _abi.BUF_LAMBDA_N,
+         _abi.BUF_LAMBDA_L, _abi.BUF_LAMBDA_T, _abi.BUF_ENV0_DIAG]
+
+
+def same(dev, orc, where):
+    torch.cuda.synchronize()
+    for bid in STATE:
+        got = dev.buffer(bid).cpu().numpy()
+        if got.dtype == np.bool_:
+            got = got.astype(np.uint8)
+        if not np.array_equal(got, orc.buffer(bid), equal_nan=True):
+            bad = np.argwhere(got != orc.buffer(bid))[:3]
+            print(f"DIFFERENCE {where}: buffer {bid} at {bad.tolist()}"); sys.exit(1)
+
+
+L = _native.load()
+variants = sorted(VARIANTS)
+t0 = time.time()
+done = 0
+case = 0
+while done < CASES:
+    case += 1
+    rng = np.random.default_rng(9000 + case)
+    variant = variants[rng.integers(len(variants))]
+    ground = ("plane", "domain-rand", "field", "field/stride2")[rng.integers(4)]
+    shell = ("1", "2", "pair")[rng.integers(3)] if not ground.startswith("field") else "1"
+    os.environ["OIS_STEP_WAVES"] = "1" if shell == "pair" else shell
+    os.environ["OIS_LANES_PER_ARENA"] = "2" if shell == "pair" else "1"
+    os.environ["OIS_PACKED"] = str(rng.integers(2))
+    cfg = build_config(variant=variant, num_envs=N, seed=int(rng.integers(1 << 30)), max_sim_steps=float(rng.uniform(50, 400)),
+                       extra_substeps=int(rng.integers(0, 14)))
+    u = rng.uniform
+    cfg.sim_dt = float(u(0.002, 0.006)); cfg.policy_dt = cfg.decimation * cfg.sim_dt
+    cfg.body_mass = float(u(12, 40)); cfg.vehicle_mass = float(u(15, 35)); cfg.vehicle_inertia = float(u(0.6, 1.6))
+    for k in range(3):
+        cfg.body_inertia[k] = float(u(0.3, 2.5))
+    cfg.com_height = float(u(0.04, 0.12)); cfg.wheel_radius = float(u(0.06, 0.11))
+    cfg.wheel_pos[0] = float(u(0.12, 0.25)); cfg.wheel_pos[1] = float(u(0.15, 0.3)); cfg.wheel_pos[2] = float(u(-0.01, 0.03))
+    cfg.wheel_spin_inertia = float(u(0.004, 0.03)); cfg.wheel_damping = float(u(0.0, 0.3))
+    cfg.wheel_limit_velocity = float(u(5, 40)); cfg.wheel_limit_damping = float(u(0.0, 0.5))
+    cfg.friction = float(u(0.3, 1.2)); cfg.baumgarte = float(u(0.05, 0.6)); cfg.max_depenetration_velocity = float(u(0.0, 3.0))
+    cfg.max_angular_velocity = float(u(20, 80)); cfg.solver_iterations = int(rng.integers(1, 9)); cfg.gravity = float(u(3.0, 12.0))
+    cfg.Kp = float(u(0.5, 4.0)); cfg.Kp_omega = float(u(0.2, 1.5)); cfg.action_scale = float(u(1.0, 6.0)); cfg.torque_clip = float(u(2.0, 8.0))
+    cfg.w1, cfg.w2, cfg.w3 = float(u(-3, 0)), float(u(-0.1, 0)), float(u(-0.05, 0))
+    cfg.sparse_bonus = float(u(0, 3)); cfg.sparse_threshold = float(u(0.01, 0.2)); cfg.terminal_reward = float(u(0, 3))
+    cfg.cmd_x_lo, cfg.cmd_x_hi = float(u(-1, 0.5)), float(u(0.6, 2.5)); cfg.cmd_x_span = cfg.cmd_x_hi - cfg.cmd_x_lo
+    cfg.spawn_xy_range = float(u(0.0, 1.5)); cfg.bounds = float(u(3.0, 12.0)); cfg.clip_obs = float(u(2.0, 10.0))
+    cfg.init_pos[2] = cfg.com_height + float(u(0.0, 0.05)); cfg.init_lin_vel[0] = float(u(-0.5, 0.5)); cfg.init_ang_vel[2] = float(u(-0.5, 0.5))
+    cfg.max_episode_length = int(rng.integers(20, 120))
+    if L.ois_workspace_bytes(cfg) == 0:
+        continue  # a draw the library refuses (e.g. the explicit joint-resistance stability bound): not a case
+    dev, orc = NativeEnv(cfg, "cuda:0"), OracleEnv(cfg, threads=16)
+    if ground == "domain-rand":
+        sl = [-0.3, -0.1, 0.0, 0.2]
+        dev.randomize_params(0.4, 1.1, sl); orc.randomize_params(0.4, 1.1, sl)
+    if ground.startswith("field"):
+        T = tg.Terrain({"numLevels": 2, "numTerrains": 2, "mapLength": 8.0, "mapWidth": 8.0}, N, seed=case)
+        lt = T.sample_levels_types(N, rng=np.random.RandomState(case))
+        kw = {"footprint_stride": 2} if ground.endswith("stride2") else {}
+        dev.attach_terrain(T, lt, **kw); orc.attach_terrain(T, lt, **kw)
+    seed = int(rng.integers(1 << 30))
+    dev.reset(seed); orc.reset(seed)
+    lo = -1.0 if variant.startswith("KA_DDPG") else 0.0
+    for t in range(STEPS):
+        a = rng.uniform(lo, 1.0, size=(N, cfg.action_dim)).astype(np.float32)
+        dev.step(torch.from_numpy(a).cuda()); orc.step(a)
+        if t % 41 == 0 or t == STEPS - 1:
+            same(dev, orc, f"case {case} {variant} {ground} shell {shell} step {t}")
+    if not cfg.eval_sums:
+        dev.rollout(7, _abi.POLICY_RANDOM); orc.rollout(7, _abi.POLICY_RANDOM)
+        same(dev, orc, f"case {case} {variant} {ground} shell {shell} fused rollout")
+    if not np.array_equal(dev.episode_info().cpu().numpy(), orc.episode_info(), equal_nan=True):
+        print(f"DIFFERENCE case {case}: episode_info"); sys.exit(1)
+    resets = int(orc.buffer(_abi.BUF_COUNTERS)[:, 2].sum())
+    dev.close(); orc.close()
+    done += 1
+    print(f"ok case {case:4d} {variant:16s} {ground:14s} shell {shell:4s} packed {os.environ['OIS_PACKED']} substeps {cfg.decimation + cfg.extra_substeps:2d} "
+          f"iterations {cfg.solver_iterations} dt {cfg.sim_dt:.4f} episodes {resets}", flush=True)
+print(f"{done} random configurations x {N} arenas x {STEPS + 7} steps, all bit-identical, {time.time() - t0:.0f} s")
