@@ -447,8 +447,8 @@ OIS_DEV void contrib_identity(ResetContrib& c) {
   for (int k = 0; k < 4; ++k) c.m[k] = -__builtin_inff();
 }
 
-// reset_idx for one arena (KAMMA.py:417-498). wheel0 = index of this lane's first wheel.
-template <int LPA>
+// reset_idx for one arena (KAMMA.py:417-498). wheel0 = index of this lane's first wheel. ALIGN: S.n holds the arena's plane (below).
+template <int LPA, bool ALIGN>
 OIS_DEV void reset_arena(const TaskK& T, const ResetK& Rk, int64_t gid, int wheel0, float gamma1, float gamma2, ArenaT<LPA>& S,
                          ResetContrib& rc) {
   // by value, read at constant offsets HERE: behind the reference the optimiser folds the select chain below into one
@@ -521,11 +521,29 @@ OIS_DEV void reset_arena(const TaskK& T, const ResetK& Rk, int64_t gid, int whee
     S.cmd[0] = cx * keep;
     S.cmd[2] = cmd2_kept;
   }
+  // ALIGN (the arena's own plane of OIS_BUF_PARAMS; not the FLAT shells, whose plane is z = 0, nor a height field): the robot is set
+  // down ON the plane — base link at its height above the ground point under (x, y), along n; the drawn orientation turned by the
+  // shortest rotation from world z to n (plain Hamilton product: exact for n = (0, 0, 1)). Oracle reset_arena; SPEC 3.2.
+  float bx = px, by = py, bz = pz;
+  if constexpr (ALIGN) {
+    const float nx = S.n[0], ny = S.n[1], nz = S.n[2], h = pz;
+    const float zg = -(__builtin_fmaf(ny, py, nx * px) / nz);
+    const float a = 1.0f + nz, d = sqrtf(a + a);
+    const float w1 = a / d, x1 = -ny / d, y1 = nx / d;
+    const float w2 = S.q[0], x2 = S.q[1], y2 = S.q[2], z2 = S.q[3];
+    S.q[0] = __builtin_fmaf(-y1, y2, __builtin_fmaf(-x1, x2, w1 * w2));
+    S.q[1] = __builtin_fmaf(y1, z2, __builtin_fmaf(x1, w2, w1 * x2));
+    S.q[2] = __builtin_fmaf(-x1, z2, __builtin_fmaf(y1, w2, w1 * y2));
+    S.q[3] = __builtin_fmaf(x1, y2, __builtin_fmaf(-y1, x2, w1 * z2));
+    bx = __builtin_fmaf(h, nx, px);
+    by = __builtin_fmaf(h, ny, py);
+    bz = __builtin_fmaf(h, nz, zg);
+  }
   float R[9];
   rotmat(S.q, R);
-  S.p[0] = __builtin_fmaf(R[2], T.com_height, px);
-  S.p[1] = __builtin_fmaf(R[5], T.com_height, py);
-  S.p[2] = __builtin_fmaf(R[8], T.com_height, pz);
+  S.p[0] = __builtin_fmaf(R[2], T.com_height, bx);
+  S.p[1] = __builtin_fmaf(R[5], T.com_height, by);
+  S.p[2] = __builtin_fmaf(R[8], T.com_height, bz);
   S.v[0] = Rk.init_lin_vel0; S.v[1] = Rk.init_lin_vel1; S.v[2] = Rk.init_lin_vel2;  // :435
   S.w[0] = Rk.init_ang_vel0; S.w[1] = Rk.init_ang_vel1; S.w[2] = Rk.init_ang_vel2;
 #pragma unroll

@@ -415,7 +415,7 @@ OIS_DEV void step_body(const PhysK& K, const DevBuffers& B, const float* __restr
     }
     if (reset) {
       const ResetK Rk = late_reset(kp);
-      reset_arena<LPA>(T2, Rk, gid, wheel0, gamma1, gamma2, S, rc);
+      reset_arena<LPA, !FLAT && !TER>(T2, Rk, gid, wheel0, gamma1, gamma2, S, rc);
     }
     cmd_dirty |= reset;
     if (!valid) contrib_identity(rc);
@@ -723,7 +723,12 @@ __global__ __launch_bounds__(kBlock) void reset_kernel(DevConsts K, DevBuffers B
   const float g1 = K.task.gamma1_mode == OIS_GAMMA_CONST ? K.task.gamma1_const : 1.0f;
   const float g2 = K.task.gamma2_mode == OIS_GAMMA_CONST ? K.task.gamma2_const : 1.0f;
   ResetContrib rc;
-  reset_arena<1>(K.task, K.reset, K.task.arena_offset + la, 0, g1, g2, S, rc);
+  if (B.ter.on) reset_arena<1, false>(K.task, K.reset, K.task.arena_offset + la, 0, g1, g2, S, rc);
+  else {  // on the arena's own plane (params are owned by ois_create / ois_randomize_params)
+    const float4 pr = B.params[la];
+    S.n[0] = pr.y; S.n[1] = pr.z; S.n[2] = pr.w;
+    reset_arena<1, true>(K.task, K.reset, K.task.arena_offset + la, 0, g1, g2, S, rc);
+  }
   if (!valid) contrib_identity(rc);
   if ((lane & (kGroup - 1)) == 0 && valid) {  // clear the finished-episode accumulators of this group
     double* Acc = B.stat_acc + (size_t)(arena / kGroup) * 8;

@@ -1059,6 +1059,28 @@ static void reset_arena(orc_env* e, int i, uint32_t step_ctr, float gamma2, rese
     }
     cmd[0] = orc_grid_command(cnt[1], c->max_sim_steps, c->cmd_x_lo, c->cmd_x_hi, u[6], z);
   }
+  /* On the arena's own plane (OIS_BUF_PARAMS: unit normal n, through the origin; build-defined, SPEC 3.2) the robot is set down ON
+   * that plane: the base link at its height above the ground point under (x, y), along n, and the drawn orientation turned by the
+   * shortest rotation that takes the world z axis to n. With n = (0, 0, 1) — the reference's ground plane — this is the identity
+   * (up to the sign of a zero). Before round 4 the pose ignored the plane: on a slope of 0.3 a robot drawn 1 m uphill started
+   * 0.3 m inside the ground and was thrown out tumbling. Not on a height field, whose tiles carry their own origins (SPEC 3.8). */
+  if (!e->terrain_on) {
+    const float* prm = &e->params[4 * i];
+    const float nx = prm[1], ny = prm[2], nz = prm[3], h = pos[2];
+    const float zg = -(fmaf(ny, pos[1], nx * pos[0]) / nz);
+    const float a = 1.0f + nz, d = sqrtf(a + a);
+    /* q <- q_n (x) q with q_n = (a, -n_y, n_x, 0) / d, as the plain Hamilton product (exact for the identity, which the
+     * reference's sum-of-products form :434 is not) */
+    const float w1 = a / d, x1 = -ny / d, y1 = nx / d;
+    const float w2 = q[0], x2 = q[1], y2 = q[2], z2 = q[3];
+    q[0] = fmaf(-y1, y2, fmaf(-x1, x2, w1 * w2));
+    q[1] = fmaf(y1, z2, fmaf(x1, w2, w1 * x2));
+    q[2] = fmaf(-x1, z2, fmaf(y1, w2, w1 * y2));
+    q[3] = fmaf(x1, y2, fmaf(-y1, x2, w1 * z2));
+    pos[0] = fmaf(h, nx, pos[0]);
+    pos[1] = fmaf(h, ny, pos[1]);
+    pos[2] = fmaf(h, nz, zg);
+  }
   /* pose: the reference sets the base-link pose (:441-443); the state stores the COM */
   float* P = &e->pose[4 * i];
   float R[9];

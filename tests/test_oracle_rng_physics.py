@@ -141,6 +141,41 @@ def test_angular_velocity_cap():
     np.testing.assert_allclose(np.linalg.norm(env.buffer(_abi.BUF_QUAT)[0]), 1.0, atol=1e-5)
 
 
+def test_robots_are_set_down_on_their_own_plane():
+    """docs/SPEC.md section 3.2 (round 4): on the per-arena plane of OIS_BUF_PARAMS (BASELINE.json configs[3]: friction + slope) a
+    reset puts the robot ON that plane, aligned with it — before, the pose ignored the plane, a robot drawn uphill of the origin
+    started inside the ground and was thrown out tumbling (tilts up to 86 degrees, 58 of 16 384 robots beyond 30 degrees at any
+    time). On the reference's own ground plane (n = e_z) the alignment is the identity: same state, bit for bit."""
+    N = 2048
+    cfg = build_config(variant="KAMMA_eval", num_envs=N, seed=3)
+    flat, flat2, e = OracleEnv(cfg), OracleEnv(cfg), OracleEnv(cfg, threads=8)
+    flat2.randomize_params(cfg.friction, cfg.friction, [0.0])   # the same plane, written through the randomiser
+    e.randomize_params(0.5, 1.0, [-0.3, -0.2, 0.0, 0.2, 0.3])
+    for env in (flat, flat2, e):
+        env.reset(3)
+    for bid in (_abi.BUF_POSE, _abi.BUF_QUAT):
+        assert np.array_equal(flat.buffer(bid), flat2.buffer(bid))
+    prm = e.buffer(_abi.BUF_PARAMS).copy()
+    assert (np.abs(prm[:, 1:3]).max(axis=1) > 0.05).sum() > N // 2     # most arenas are tilted
+
+    def tilt_and_clearance():
+        q, p = e.buffer(_abi.BUF_QUAT), e.buffer(_abi.BUF_POSE)
+        zx = 2 * (q[:, 1] * q[:, 3] + q[:, 0] * q[:, 2]); zy = 2 * (q[:, 2] * q[:, 3] - q[:, 0] * q[:, 1]); zz = 1 - 2 * (q[:, 1] ** 2 + q[:, 2] ** 2)
+        c = np.clip(zx * prm[:, 1] + zy * prm[:, 2] + zz * prm[:, 3], -1, 1)
+        return np.degrees(np.arccos(c)), (p[:, :3] * prm[:, 1:4]).sum(axis=1)   # body z against n; COM distance from the plane
+
+    tilt, dist = tilt_and_clearance()
+    rest = float(cfg.init_pos[2] + cfg.com_height)
+    assert tilt.max() < 0.05 and np.abs(dist - rest).max() < 1e-5, (tilt.max(), np.abs(dist - rest).max())
+    worst = 0.0
+    for t in range(120):   # past the first timeouts: the later resets, too
+        e.rollout(1, _abi.POLICY_RANDOM)
+        tilt, dist = tilt_and_clearance()
+        worst = max(worst, float(tilt.max()))
+        assert dist.min() > 0.5 * rest and dist.max() < 1.5 * rest, (t, dist.min(), dist.max())
+    assert worst < 10.0, worst
+
+
 def test_tipped_robots_are_not_launched():
     """docs/SPEC.md section 3.9 (round 4): the Newton refresh of the reciprocals assumes effective masses that move by O(1e-3) per
     substep, which fails for a robot on its side (n_b along the axle: the contact points jump within a substep) — finite garbage,
