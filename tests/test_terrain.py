@@ -543,6 +543,16 @@ def test_task_terrain_surface():
     cl = p[:, 2] + o[:, 2] - g
     assert np.median(cl) == pytest.approx(0.0705, abs=0.03) and (cl > -0.35).all() and (cl < 0.6).all()
     assert float(info["episode"]["terrain_level"]) == pytest.approx(lv.mean(), rel=1e-6)
+    assert "+stride2" not in env.task.native.kernel_info()
+    env.close()
+    # the build's own key of that dict: footprints every second substep (docs/SPEC.md section 3.8)
+    cfg["task"]["env"]["terrain"]["footprintStride"] = 2
+    env = VecEnv(cfg, device="cuda:0", variant="KAMMA_medium", seed=11)
+    env.task.get_terrain()
+    assert "+stride2" in env.task.native.kernel_info()
+    env.reset()
+    obs, rew, term, trunc, info = env.step(torch.rand((N, 4), device="cuda"))
+    assert torch.isfinite(obs).all() and torch.isfinite(rew).all()
     env.close()
 
 
