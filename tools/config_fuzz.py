@@ -3,7 +3,8 @@ constants of `ois_config` at random inside ranges the library accepts (masses, i
 iteration counts, Baumgarte factor, joint resistance, reward weights, command ranges, spawn state ...), a variant, a ground (plane /
 friction + slopes / height field with either footprint stride) and a shell, and runs STEPS single steps + one fused rollout.
 What it exercises beyond tools/parity_fuzz.py: the host-side derivation of the kernels' constants (derive() in ois_kernels.hip
-against the oracle's), the run-time substep / iteration counts, reset constants off their defaults.
+against the oracle's), the run-time substep / iteration counts, reset constants off their defaults, and ois_save_state / ois_load_state
+under every such configuration (a second environment resumes from a blob taken half way and must end where the oracle does).
     python tools/config_fuzz.py [CASES] [N] [STEPS]"""
 import os
 import sys
@@ -86,11 +87,27 @@ while done < CASES:
     seed = int(rng.integers(1 << 30))
     dev.reset(seed); orc.reset(seed)
     lo = -1.0 if variant.startswith("KA_DDPG") else 0.0
+    half, blob, later = STEPS // 2, None, []
     for t in range(STEPS):
         a = rng.uniform(lo, 1.0, size=(N, cfg.action_dim)).astype(np.float32)
+        if t == half:
+            blob = dev.save_state()   # checkpoint / resume under this configuration: a second environment continues from here
+        if t >= half:
+            later.append(a)
         dev.step(torch.from_numpy(a).cuda()); orc.step(a)
         if t % 41 == 0 or t == STEPS - 1:
             same(dev, orc, f"case {case} {variant} {ground} shell {shell} step {t}")
+    dev2 = NativeEnv(cfg, "cuda:0")
+    if ground == "domain-rand":
+        dev2.randomize_params(0.4, 1.1, sl)
+    if ground.startswith("field"):
+        dev2.attach_terrain(T, lt, **kw)
+    dev2.reset(seed + 1)          # any state: the blob replaces it
+    dev2.load_state(blob)
+    for a in later:
+        dev2.step(torch.from_numpy(a).cuda())
+    same(dev2, orc, f"case {case} {variant} {ground} shell {shell} resumed from the blob of step {half}")
+    dev2.close()
     if not cfg.eval_sums:
         dev.rollout(7, _abi.POLICY_RANDOM); orc.rollout(7, _abi.POLICY_RANDOM)
         same(dev, orc, f"case {case} {variant} {ground} shell {shell} fused rollout")
@@ -101,4 +118,4 @@ while done < CASES:
     done += 1
     print(f"ok case {case:4d} {variant:16s} {ground:14s} shell {shell:4s} packed {os.environ['OIS_PACKED']} substeps {cfg.decimation + cfg.extra_substeps:2d} "
           f"iterations {cfg.solver_iterations} dt {cfg.sim_dt:.4f} episodes {resets}", flush=True)
-print(f"{done} random configurations x {N} arenas x {STEPS + 7} steps, all bit-identical, {time.time() - t0:.0f} s")
+print(f"{done} random configurations x {N} arenas x {STEPS + 7} steps (+ a resume from a state blob taken half way), all bit-identical, {time.time() - t0:.0f} s")
