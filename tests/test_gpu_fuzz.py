@@ -1,4 +1,4 @@
-"""Short runs of the round-4 sweeps (tools/config_fuzz.py, tools/api_fuzz.py) inside the GPU suite: random configurations of
+"""Short runs of the round-4 sweeps (tools/config_fuzz.py, tools/api_fuzz.py, tools/wrapper_fuzz.py) inside the GPU suite: random configurations of
 ois_config and random interleavings of the ABI's calls, kernel vs oracle, bit for bit. The long runs are profiles/r4_config_fuzz.txt
 (3 000 configurations) and profiles/r4_api_fuzz.txt (36 000 operations)."""
 import os
@@ -26,3 +26,9 @@ def test_random_configurations_match_the_oracle():
 def test_random_call_orders_match_the_oracle():
     out = run("api_fuzz.py", "24", "40")
     assert "24 sequences x 40 operations" in out and "all equal to the oracle" in out
+
+
+@pytest.mark.gpu
+def test_random_read_patterns_through_the_python_mirror_match_the_oracle():
+    out = run("wrapper_fuzz.py", "20", "90")
+    assert "20 sequences x 90 steps" in out and "all equal to the oracle" in out
