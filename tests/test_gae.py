@@ -82,10 +82,13 @@ def test_kernel_matches_fixture_and_oracle_bit_exact():
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("T,N", [(1, 1), (2, 1), (7, 300), (16, 65536), (16, 4099), (20, 65536), (32, 40000), (33, 5000), (96, 4099), (16, 200000)])
+@pytest.mark.parametrize("T,N", [(1, 1), (2, 1), (7, 300), (16, 65536), (16, 4099), (20, 65536), (32, 40000), (33, 5000), (96, 4099), (16, 200000),
+                                 (70, 65536), (16, 262144), (17, 262145), (5, 1000003)])
 def test_kernel_vs_oracle_sizes(T, N):
-    """incl. the reference's rollouts of 16 and 20 steps at 65 536 arenas, a ragged last wave, and both normalisation paths: the
-    normalise kernel summing the per-wave moments itself (<= 2048 waves) and the separate moments kernel (200 000 arenas)"""
+    """incl. the reference's rollouts of 16 and 20 steps at 65 536 arenas, a ragged last block, and every path of the launch logic
+    (ois_gae.hip): scan in four-wave blocks up to 262 144 arenas and in one-wave blocks above; the normalise kernel summing the
+    per-block moments itself (<= 2048 of them) and the separate moments kernel (262 145 and 1 000 003 arenas); four advantages per
+    access from 2^22 entries on (70 x 65 536; exactly 2^22 = 16 x 262 144; a count that is not a multiple of four)"""
     from options_in_simulation_amd import compute_advantages_and_returns, compute_gae
     rng = np.random.default_rng(T * 1000 + N)
     r = rng.normal(size=(T, N, 1)).astype(np.float32)
@@ -109,6 +112,35 @@ def test_kernel_vs_oracle_sizes(T, N):
         raw = torch.from_numpy(ob.gae(0, r, term, v, lv, 0.99, 0.95, False)[1]).cuda()
         ref = (raw - raw.mean()) / (raw.std() + 1e-8)
         np.testing.assert_allclose(k_adv.cpu().numpy(), ref.cpu().numpy(), rtol=1e-4, atol=1e-5)
+
+
+@pytest.mark.gpu
+def test_normalisation_with_an_output_that_is_not_16_byte_aligned():
+    """the four-per-access normalisation needs a 16-byte aligned advantages array; any other (here: 4 bytes into an allocation)
+    takes the element-wise form: same values"""
+    import ctypes as C
+    from options_in_simulation_amd import _native
+    L = _native.load()
+    T, N = 72, 65536   # 4.7 Mi entries: above the threshold of the vector form
+    rng = np.random.default_rng(3)
+    r = torch.from_numpy(rng.normal(size=(T, N)).astype(np.float32)).cuda()
+    v = torch.from_numpy(rng.normal(size=(T, N)).astype(np.float32)).cuda()
+    lv = torch.from_numpy(rng.normal(size=(N,)).astype(np.float32)).cuda()
+    d = torch.from_numpy((rng.uniform(size=(T, N)) < 0.05).astype(np.uint8)).cuda()
+    nb = L.ois_gae_scratch_bytes(N)
+    scratch = torch.empty(nb // 8, dtype=torch.float64, device="cuda")
+    out = {}
+    for shift in (0, 1):
+        ret = torch.empty(T * N + 4, dtype=torch.float32, device="cuda")
+        adv = torch.empty(T * N + 4, dtype=torch.float32, device="cuda")
+        rc = L.ois_gae(0, T, N, r.data_ptr(), d.data_ptr(), v.data_ptr(), lv.data_ptr(), 0.99, 0.95, 1, ret.data_ptr() + 4 * shift,
+                       adv.data_ptr() + 4 * shift, scratch.data_ptr(), nb, torch.cuda.current_stream().cuda_stream)
+        assert rc == 0, L.ois_last_error()
+        torch.cuda.synchronize()
+        out[shift] = (ret[shift:shift + T * N].clone(), adv[shift:shift + T * N].clone())
+    assert torch.equal(out[0][0], out[1][0]) and torch.equal(out[0][1], out[1][1])
+    _, o_adv = ob.gae(0, r.cpu().numpy()[..., None], d.cpu().numpy().astype(bool)[..., None], v.cpu().numpy()[..., None], lv.cpu().numpy()[..., None], 0.99, 0.95, True)
+    np.testing.assert_allclose(out[1][1].cpu().numpy().reshape(T, N, 1), o_adv, rtol=RTOL, atol=ATOL)
 
 
 @pytest.mark.gpu
