@@ -1,6 +1,7 @@
 """Random interleavings of the C-ABI's calls, kernel vs CPU oracle (GPU box): per sequence an environment of a random size and
 variant, then OPS random operations — ois_step, ois_rollout (EXTERNAL / RANDOM, 1-5 steps), ois_reset, ois_push_robots,
-ois_randomize_params, ois_save_state / ois_load_state round trips, attach / detach of a height field (either footprint stride) —
+ois_randomize_params, ois_save_state / ois_load_state round trips, attach / detach of a height field (either footprint stride),
+attach / detach of a transition memory (ois_replay_*: every tensor, the cursor and a sampled mini-batch compared) —
 and, after every one of them, a random subset of the reads a trainer makes: the published logs (ois_logs_fetch through
 NativeEnv.host_logs), ois_episode_info, ois_env0_diag, ois_stats_fetch (with and without reset), ois_outputs_copy. Every read and
 every state buffer must equal the oracle's, bit for bit. What it is after: the host-side bookkeeping around the kernels (which
@@ -67,6 +68,7 @@ for seq in range(SEQ):
     trace[:] = [f"seq {seq}: {variant} N={N} waves={os.environ['OIS_STEP_WAVES']}", "reset"]
     lo = -1.0 if variant.startswith("KA_DDPG") else 0.0
     stepped = False
+    mem_dev = mem_orc = None
     for op in range(OPS):
         r = rng.random()
         if r < 0.45:
@@ -93,9 +95,13 @@ for seq in range(SEQ):
             dev.randomize_params(0.4, 1.1, sl); orc.randomize_params(0.4, 1.1, sl); trace.append(f"randomize_params(slopes={len(sl)})")
         elif r < 0.82:
             blob = dev.save_state()
+            snap = {k: v.clone() for k, v in mem_dev.items()} if mem_dev is not None else None   # the memory tensors are the caller's
             a = rng.uniform(lo, 1.0, size=(N, cfg.action_dim)).astype(np.float32)
             dev.step(torch.from_numpy(a).cuda())            # wander off ...
             dev.load_state(blob); trace.append("save, step, load")   # ... and come back: the oracle never left
+            if snap is not None:
+                for k in snap:
+                    mem_dev[k].copy_(snap[k])
         elif r < 0.88 and os.environ["OIS_LANES_PER_ARENA"] == "1":
             if getattr(dev, "_terrain", None) is None:
                 kw = {"footprint_stride": int(rng.integers(1, 3))}
@@ -104,10 +110,33 @@ for seq in range(SEQ):
                 dev.detach_terrain(); orc.detach_terrain(); trace.append("detach_terrain")
             seed = int(rng.integers(1 << 30))
             dev.reset(seed); orc.reset(seed); trace.append("reset"); stepped = False
+        elif r < 0.93:
+            if mem_dev is None:
+                M = int(rng.integers(1, 10))
+                mem_dev, mem_orc = dev.attach_replay(M), orc.attach_replay(M); trace.append(f"attach_replay({M})")
+            else:
+                dev.detach_replay(); orc.attach_replay(0); mem_dev = mem_orc = None; trace.append("detach_replay")
         else:
             trace.append("(reads only)")
         nops += 1
         same(dev, orc, f"seq {seq} op {op}")
+        if mem_dev is not None:   # the FIFO transition memory the step kernel writes (train_kaddpg_4d_nofifo_random_RLIL.py:147-156)
+            torch.cuda.synchronize()
+            if dev.replay_cursor() != orc.replay_cursor():
+                fail(f"seq {seq} op {op}: memory cursor {dev.replay_cursor()} vs {orc.replay_cursor()}")
+            for k in mem_dev:
+                got = mem_dev[k].cpu().numpy()
+                if not np.array_equal(got.astype(mem_orc[k].dtype), mem_orc[k], equal_nan=True):
+                    fail(f"seq {seq} op {op}: transition memory '{k}'")
+            if rng.random() < 0.3:
+                rows = mem_orc["rewards"].shape[0] * N
+                idx = rng.integers(0, rows, size=int(rng.integers(1, 300)))
+                batch = dev.replay_sample(torch.from_numpy(idx))
+                torch.cuda.synchronize()
+                for k in batch:
+                    want = mem_orc[k].reshape(rows, -1)[idx]
+                    if not np.array_equal(batch[k].cpu().numpy().astype(want.dtype), want, equal_nan=True):
+                        fail(f"seq {seq} op {op}: sampled '{k}'")
         # the reads of a trainer, in a random subset and order
         reads = [x for x in ("logs", "episode_info", "diag", "stats", "stats_reset", "outputs", "logs") if rng.random() < 0.4]
         rng.shuffle(reads)
