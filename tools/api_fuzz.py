@@ -105,6 +105,10 @@ for seq in range(SEQ):
         elif r < 0.88 and os.environ["OIS_LANES_PER_ARENA"] == "1":
             if getattr(dev, "_terrain", None) is None:
                 kw = {"footprint_stride": int(rng.integers(1, 3))}
+                if VARIANTS[variant].get("cmd_sampler") != _abi.CMD_EVAL and rng.random() < 0.5:
+                    # the level curriculum: levels move at the resets, the commands follow the per-level generators, and the logging
+                    # reductions cannot take the level mean from the host any more (two launches)
+                    kw.update(curriculum=True, threshold_low=-60.0, threshold_high=-20.0, max_level=1)
                 dev.attach_terrain(T, lt, **kw); orc.attach_terrain(T, lt, **kw); trace.append(f"attach_terrain({kw})")
             else:
                 dev.detach_terrain(); orc.detach_terrain(); trace.append("detach_terrain")
