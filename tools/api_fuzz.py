@@ -3,7 +3,7 @@ variant, then OPS random operations — ois_step, ois_rollout (EXTERNAL / RANDOM
 ois_randomize_params, ois_save_state / ois_load_state round trips, attach / detach of a height field (either footprint stride),
 attach / detach of a transition memory (ois_replay_*: every tensor, the cursor and a sampled mini-batch compared) —
 and, after every one of them, a random subset of the reads a trainer makes: the published logs (ois_logs_fetch through
-NativeEnv.host_logs), ois_episode_info, ois_env0_diag, ois_stats_fetch (with and without reset), ois_outputs_copy. Every read and
+NativeEnv.host_logs), ois_episode_info, ois_env0_diag, ois_stats_fetch (with and without reset), ois_outputs_copy, ois_height_scan. Every read and
 every state buffer must equal the oracle's, bit for bit. What it is after: the host-side bookkeeping around the kernels (which
 reduction is current, what a cached record belongs to, which shell a changed environment launches).
     python tools/api_fuzz.py [SEQUENCES] [OPS]"""
@@ -142,7 +142,7 @@ for seq in range(SEQ):
                     if not np.array_equal(batch[k].cpu().numpy().astype(want.dtype), want, equal_nan=True):
                         fail(f"seq {seq} op {op}: sampled '{k}'")
         # the reads of a trainer, in a random subset and order
-        reads = [x for x in ("logs", "episode_info", "diag", "stats", "stats_reset", "outputs", "logs") if rng.random() < 0.4]
+        reads = [x for x in ("logs", "episode_info", "diag", "stats", "stats_reset", "outputs", "logs", "height_scan") if rng.random() < 0.4]
         rng.shuffle(reads)
         for what in reads:
             trace.append("read " + what)
@@ -165,6 +165,9 @@ for seq in range(SEQ):
                     x, y = getattr(a_, f), getattr(b_, f)
                     if not (x == y or (np.isnan(x) and np.isnan(y)) or abs(x - y) <= 1e-9 * max(1.0, abs(y))):
                         fail(f"seq {seq} op {op}: statistics {f}: {x} vs {y}")
+            elif what == "height_scan":
+                if getattr(dev, "_terrain", None) is not None and not np.array_equal(dev.height_scan().cpu().numpy(), orc.height_scan()):
+                    fail(f"seq {seq} op {op}: ois_height_scan")
             elif what == "outputs":
                 o, rw, te, tr = dev.outputs_copy()
                 torch.cuda.synchronize()
