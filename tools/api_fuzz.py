@@ -56,8 +56,9 @@ for seq in range(SEQ):
     N = int(rng.choice([1, 2, 63, 65, 300, 1000, 4097, 20000, 40000, 70000, 140000], p=[.12, .08, .1, .1, .14, .14, .1, .1, .05, .04, .03]))
     variant = variants[rng.integers(len(variants))]
     os.environ["OIS_STEP_WAVES"] = str(rng.integers(1, 3))
-    os.environ.pop("OIS_LANES_PER_ARENA", None)   # by size: the lane pair below 32 768 arenas, refused on a height field
-    os.environ["OIS_LANES_PER_ARENA"] = "1" if rng.random() < 0.5 else os.environ.get("OIS_LANES_PER_ARENA", "1")
+    os.environ.pop("OIS_LANES_PER_ARENA", None)   # unset = by size: a lane pair per arena up to 32 768 arenas, one lane on a height field
+    if rng.random() < 0.5:
+        os.environ["OIS_LANES_PER_ARENA"] = "1"
     cfg = build_config(variant=variant, num_envs=N, seed=int(rng.integers(1 << 30)), max_sim_steps=float(rng.uniform(30, 200)))
     cfg.max_episode_length = int(rng.integers(4, 30))   # resets all the time: the records change often
     dev, orc = NativeEnv(cfg, "cuda:0"), OracleEnv(cfg, threads=16)
@@ -65,7 +66,7 @@ for seq in range(SEQ):
     lt = T.sample_levels_types(N, rng=np.random.RandomState(seq))
     seed = int(rng.integers(1 << 30))
     dev.reset(seed); orc.reset(seed)
-    trace[:] = [f"seq {seq}: {variant} N={N} waves={os.environ['OIS_STEP_WAVES']}", "reset"]
+    trace[:] = [f"seq {seq}: {variant} N={N} waves={os.environ['OIS_STEP_WAVES']} lanes={os.environ.get('OIS_LANES_PER_ARENA', 'by size')}", "reset"]
     lo = -1.0 if variant.startswith("KA_DDPG") else 0.0
     stepped = False
     mem_dev = mem_orc = None
@@ -102,7 +103,7 @@ for seq in range(SEQ):
             if snap is not None:
                 for k in snap:
                     mem_dev[k].copy_(snap[k])
-        elif r < 0.88 and os.environ["OIS_LANES_PER_ARENA"] == "1":
+        elif r < 0.88:
             if getattr(dev, "_terrain", None) is None:
                 kw = {"footprint_stride": int(rng.integers(1, 3))}
                 if VARIANTS[variant].get("cmd_sampler") != _abi.CMD_EVAL and rng.random() < 0.5:
