@@ -288,6 +288,43 @@ def side_measurements(torch, env, _abi, fixed_actions, N, flop_exec, launches=20
     return res
 
 
+def trainer_loop(torch, actor, N, variant, device, steps=300):
+    """The loop the reference's trainer runs around the env (src/my_trainers/base_KA_DDPG.py:170-262) through the Python mirror of
+    its interface: actor -> VecEnv.step, then — after EVERY step — the 26 env-0 diagnostics, wheel_torqs / action_scale and every
+    value of infos["episode"] with .item(). Three lines, `steps` steps each, after the timed region: without the reads, with a bare
+    stream synchronisation in their place (the floor of ANY per-step host read: the host can no longer run ahead of the GPU), and
+    with the reads. tools/trainer_loop_probe.py is the longer form (profiles/*_trainer_loop.txt)."""
+    from options_in_simulation_amd import VecEnv
+    from options_in_simulation_amd.tracking import ENV0_TAGS
+    env = VecEnv(num_envs=N, device=str(device), variant=variant, seed=1)
+
+    def loop(reads, bare_sync):
+        states, _ = env.reset()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            with torch.no_grad():
+                actions = actor(states)
+            states, _rew, _term, _trunc, infos = env.step(actions)
+            if bare_sync:
+                torch.cuda.current_stream().synchronize()
+            if reads:
+                _ = [env.task.observed_components[k] for k in ENV0_TAGS]      # :184-209
+                _ = env.task.wheel_torqs / env.task.action_scale             # :212
+                for _k, v in infos["episode"].items():                       # :259-262
+                    if isinstance(v, torch.Tensor) and v.numel() == 1:
+                        v.item()
+        torch.cuda.synchronize()
+        return (time.perf_counter() - t0) / steps * 1e6
+
+    loop(True, False)
+    res = {"what": "reference trainer's per-step loop around the env (base_KA_DDPG.py:170-262) through VecEnv, us per step",
+           "steps_per_line": steps, "no_reads": loop(False, False), "bare_stream_synchronisation": loop(False, True),
+           "with_the_trainers_reads": loop(True, False)}
+    env.close()
+    return res
+
+
 def merge_raw(sts):
     """the finished-episode statistics of several shards of one rank as one record (sums add, extremes combine)"""
     from options_in_simulation_amd import _abi
@@ -616,6 +653,8 @@ def main(argv=None):
                                     "episodes_per_rank": [g.episodes for g in gathered]}
         if not args.no_extras and not K_fused and not args.terrain and shards == 1:
             out["env_only"] = side_measurements(torch, env, _abi, fixed_actions, N, flop_exec)
+            if world == 1 and not args.no_actor:
+                out["trainer_loop"] = trainer_loop(torch, actor, N, args.variant, device)
         if world == 1 and not args.no_cpu_baseline:
             try:
                 out["cpu_baseline"] = cpu_baseline(N)
