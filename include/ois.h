@@ -304,7 +304,8 @@ int ois_outputs_copy(ois_env* env, float* obs_out, float* rew_out, uint8_t* term
 
 /* Per-arena domain randomisation (BASELINE.json config 4): mu ~ U(mu_lo, mu_hi) and plane
  * slope drawn from `slopes[n_slopes]` (tan of the incline about a random heading), both
- * from Philox keyed by the global arena id. n_slopes == 0 keeps the flat plane. The plane passes through the arena's origin;
+ * from Philox keyed by the global arena id. n_slopes == 0 keeps the flat plane. 0 <= mu_lo <= mu_hi (finite), at most 16
+ * slopes with |slope| <= 10 (OIS_EINVAL otherwise; ois_config.friction likewise >= 0). The plane passes through the arena's origin;
  * a reset (ois_reset, and every reset_idx inside a step) sets the robot down ON it, aligned with it (docs/SPEC.md 3.2) — so
  * call this BEFORE ois_reset: a robot already standing keeps its pose and meets the new plane where it is until its next reset. */
 int ois_randomize_params(ois_env* env, float mu_lo, float mu_hi, const float* slopes_host,

@@ -1190,6 +1190,8 @@ int validate(const ois_config* c) {
     return fail(OIS_EINVAL, "(wheel_damping + wheel_limit_damping) * sim_dt / wheel_spin_inertia must be < 2 (explicit integration)");
   // the normal-row bias is min(-gap / dt, -beta gap / dt, v_dep) (SPEC 3.4): v_dep < 0 would push separating contacts
   if (!(c->max_depenetration_velocity >= 0.0f)) return fail(OIS_EINVAL, "max_depenetration_velocity must be >= 0");
+  // the friction cone's half-width is mu * lambda_n (SPEC 3.5): a negative or non-finite coefficient turns the clamp inside out
+  if (!(c->friction >= 0.0f) || !(c->friction < 1e6f)) return fail(OIS_EINVAL, "friction must be >= 0 (finite)");
   return OIS_OK;
 }
 
@@ -1705,6 +1707,9 @@ int ois_buffer(ois_env* e, int id, void** ptr_device, size_t* bytes) {
 int ois_randomize_params(ois_env* e, float mu_lo, float mu_hi, const float* slopes_host, int n_slopes, void* stream) {
   if (!e) return fail(OIS_EINVAL, "null env");
   if (n_slopes < 0 || n_slopes > 16 || (n_slopes > 0 && !slopes_host)) return fail(OIS_EINVAL, "bad slopes (0..16 values)");
+  if (!(mu_lo >= 0.0f) || !(mu_hi >= mu_lo) || !(mu_hi < 1e6f)) return fail(OIS_EINVAL, "friction range: 0 <= mu_lo <= mu_hi (finite)");
+  for (int k = 0; k < n_slopes; ++k)  // tan of the incline: the plane has to face up (n_z > 0) for a robot to be set down on it
+    if (!(std::fabs(slopes_host[k]) <= 10.0f)) return fail(OIS_EINVAL, "slopes: |tan(incline)| <= 10, finite");
   OIS_ON_DEVICE(e->device);
   float* tbl = (float*)(e->ws + e->L.stat_out);  // scratch shared with ois_stats_fetch
   if (n_slopes > 0) HIP_TRY(hipMemcpyAsync(tbl, slopes_host, (size_t)n_slopes * sizeof(float), hipMemcpyHostToDevice, (hipStream_t)stream));

@@ -869,6 +869,7 @@ int orc_create(const ois_config* cfg, orc_env** out) {
   if (!((cfg->wheel_damping + cfg->wheel_limit_damping) * cfg->sim_dt / cfg->wheel_spin_inertia < 2.0f))
     return fail(OIS_EINVAL, "(wheel_damping + wheel_limit_damping) * sim_dt / wheel_spin_inertia must be < 2 (explicit integration)");
   if (!(cfg->max_depenetration_velocity >= 0.0f)) return fail(OIS_EINVAL, "max_depenetration_velocity must be >= 0");
+  if (!(cfg->friction >= 0.0f) || !(cfg->friction < 1e6f)) return fail(OIS_EINVAL, "friction must be >= 0 (finite)");
   orc_env* e = (orc_env*)zalloc(sizeof *e);
   if (!e) return fail(OIS_ENOMEM, "host alloc");
   e->cfg = *cfg;
@@ -1675,6 +1676,9 @@ int orc_push_robots(orc_env* e) {
 int orc_randomize_params(orc_env* e, float mu_lo, float mu_hi, const float* slopes, int n_slopes) {
   if (!e) return fail(OIS_EINVAL, "null env");
   if (n_slopes < 0 || (n_slopes > 0 && !slopes)) return fail(OIS_EINVAL, "bad slopes");
+  if (!(mu_lo >= 0.0f) || !(mu_hi >= mu_lo) || !(mu_hi < 1e6f)) return fail(OIS_EINVAL, "friction range: 0 <= mu_lo <= mu_hi (finite)");
+  for (int k = 0; k < n_slopes; ++k)
+    if (!(fabsf(slopes[k]) <= 10.0f)) return fail(OIS_EINVAL, "slopes: |tan(incline)| <= 10, finite");
   for (int i = 0; i < e->N; ++i) {
     float u[4];
     draw4(e->cfg.seed, e->cfg.arena_offset + i, 0u, PURPOSE_PARAMS, u);

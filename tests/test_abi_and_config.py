@@ -61,12 +61,13 @@ def test_workspace_size_and_config_validation(lib):
                        ("body_mass", -1.0), ("struct_bytes", 12), ("cmd_sampler", 9),
                        # the explicit joint-resistance step diverges at (c1 + c2) dt / Is >= 2; a negative depenetration
                        # velocity would push separating contacts (SPEC 3.3, 3.4)
-                       ("wheel_limit_damping", 2.0), ("wheel_damping", 2.5), ("max_depenetration_velocity", -1.0)):
+                       ("wheel_limit_damping", 2.0), ("wheel_damping", 2.5), ("max_depenetration_velocity", -1.0),
+                       ("friction", -0.1), ("friction", float("nan"))):
         c = build_config(variant="KAMMA_medium", num_envs=8)
         setattr(c, field, bad)
         assert lib.ois_workspace_bytes(C.byref(c)) == 0, field
         assert lib.ois_last_error().decode() != ""
-        if field in ("wheel_limit_damping", "wheel_damping", "max_depenetration_velocity"):   # the oracle refuses the same
+        if field in ("wheel_limit_damping", "wheel_damping", "max_depenetration_velocity", "friction"):   # the oracle refuses the same
             from oracle.binding import lib as orc
             h = C.c_void_p()
             assert orc().orc_create(C.byref(c), C.byref(h)) != 0, field

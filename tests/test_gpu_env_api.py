@@ -593,3 +593,24 @@ def test_flat_plane_shell_follows_the_params_and_the_state_blob():
     assert big.kernel_info().startswith("step_kernel_w2<1,4,1>")    # two waves per SIMD above 65 536
     for e in (a, b, small, big):
         e.close()
+
+
+@pytest.mark.gpu
+def test_randomize_params_refuses_what_the_contact_model_cannot_take():
+    """a negative / non-finite friction turns the friction cone's clamp inside out, a plane that does not face up cannot carry a
+    robot: OIS_EINVAL from the library and from the oracle alike, the environment unchanged"""
+    from options_in_simulation_amd.vecenv import NativeEnv
+    from oracle.binding import OracleEnv
+    cfg = build_config(variant="KAMMA_medium", num_envs=8, seed=1)
+    dev, orc = NativeEnv(cfg, "cuda:0"), OracleEnv(cfg)
+    dev.reset(1); orc.reset(1)
+    before = dev.buffer(_abi.BUF_PARAMS).clone()
+    for args in ((-0.1, 1.0, []), (1.0, 0.5, []), (0.5, float("nan"), []), (0.5, float("inf"), []), (0.5, 1.0, [0.1, 20.0]), (0.5, 1.0, [float("nan")])):
+        for env in (dev, orc):
+            with pytest.raises(RuntimeError):
+                env.randomize_params(*args)
+    torch.cuda.synchronize()
+    assert torch.equal(dev.buffer(_abi.BUF_PARAMS), before)
+    dev.randomize_params(0.0, 0.0, [10.0]); orc.randomize_params(0.0, 0.0, [10.0])   # the edges of the accepted ranges
+    assert np.array_equal(dev.buffer(_abi.BUF_PARAMS).cpu().numpy(), orc.buffer(_abi.BUF_PARAMS))
+    dev.close(); orc.close()
