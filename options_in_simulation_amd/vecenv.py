@@ -44,7 +44,14 @@ _DTYPES = {
 }
 
 
+_raw_stream = getattr(torch._C, "_cuda_getCurrentRawStream", None)  # the handle without building a Stream object: 0.3 instead of 2 us
+
+
 def _stream_ptr(device: torch.device) -> int:
+    """the caller's current HIP stream on ``device`` as an integer handle (three calls per step of a reading loop: at the reference's
+    own size, numEnvs = 1, the loop is host-bound and every microsecond of the mirror shows)"""
+    if _raw_stream is not None and device.index is not None:
+        return _raw_stream(device.index)
     return torch.cuda.current_stream(device).cuda_stream
 
 
