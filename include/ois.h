@@ -173,7 +173,9 @@ typedef struct ois_config {
   float friction;             /* default mu (0.85 from scripts)    train_*.py:66-67 */
   float baumgarte;            /* penetration bias factor                          */
   float max_depenetration_velocity; /* 100                         KAMMA.py:105 */
-  float max_angular_velocity; /* 64 rad/s                          origin_v18.py:70 */
+  float max_angular_velocity; /* 64 rad/s                          origin_v18.py:70. (Linear speed has no cap; an arena whose
+                                 speed exceeds 50 m/s after a policy step's substeps, or whose state is not finite, is discarded
+                                 and reset as fallen: the safety net of docs/SPEC.md 3.9) */
   int32_t solver_iterations;  /* 4                                 KAMMA.py:96-97 */
   float wheel_limit_velocity; /* joint velocity limit [rad/s]: <limit velocity="10"/> urdf:117,125,133,141 */
   float wheel_limit_damping;  /* resistance above the limit [N m s/rad], CALIBRATED with wheel_damping
